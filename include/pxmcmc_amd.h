@@ -1,0 +1,153 @@
+/*
+ * pxmcmc_amd.h -- C-ABI of the MI355X (gfx950) implementation of pxmcmc's
+ * proximal-Langevin hot path (MYULA / PxMALA iteration).
+ *
+ * The reference (auggiemarignier/pxmcmc v1.0.1) has no FFI of its own: its hot
+ * path is a duck-typed Python protocol whose O(L^3) work is
+ * done by the pyssht / pys2let wheels.  These entry points are what a binding
+ * for that path replaces; each cites the reference interface (file:line in
+ * /root/reference) it stands in for.  Conventions:
+ *
+ *   - every function returns 0 on success, <0 on error (pxm_last_error() gives text);
+ *   - device buffers are caller-owned; nothing is allocated after plan creation;
+ *   - all device work is enqueued on the caller-supplied HIP stream (hipStream_t
+ *     passed as void*); plans are not shared across threads or devices;
+ *   - arrays carry a leading chain-batch dimension C (independent chains); inside
+ *     a chain the reference's own 1-D orders are kept: harmonic index el^2+el+m,
+ *     MW images theta-major (L, 2L-1) C-order, wavelet coefficient vectors
+ *     [scaling | j=J_min | ... | j=J_max] each block theta-major
+ *     (pxmcmc/utils.py:11-22,49-51);
+ *   - complex128 values are interleaved (re, im) doubles.
+ */
+#ifndef PXMCMC_AMD_H
+#define PXMCMC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pxm_sht_plan_s* pxm_sht_plan_t;
+typedef struct pxm_wav_plan_s* pxm_wav_plan_t;
+typedef void* pxm_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------ */
+int pxm_version(void);
+const char* pxm_last_error(void);
+/* number of visible HIP devices (0 when none; never fails) */
+int pxm_device_count(void);
+
+/* ---- host-side setup helpers (no GPU needed) ------------------------------ */
+/* pys2let.pys2let_j_max(B, L, J_min)            (pxmcmc/transforms.py:75) */
+int pxm_j_max(int L, double B);
+/* multiresolution bandlimits [scaling, j=J_min..J_max] (pxmcmc/utils.py:116-125);
+ * writes at most cap entries, returns the count or <0 */
+int pxm_wav_bandlimits(int L, double B, int J_min, int* bl_out, int cap);
+/* number of wavelet+scaling coefficients  (pxmcmc/transforms.py:156-166) */
+int64_t pxm_wav_ncoefs(int L, double B, int J_min, int64_t* nscal_out);
+/* axisymmetric tiling: kappa0[L], kappa[(J_max+1)*L]  (pys2let.wavelet_tiling,
+ * pxmcmc/utils.py:117; prior.py:121,132) */
+int pxm_tiling_axisym(int L, double B, int J_min, double* kappa0, double* kappa);
+/* MW quadrature weight per ring q[L] (pxmcmc/utils.py:262-283: mw_map_weights = outer(q, 1)) */
+int pxm_mw_ring_weights(int L, double* q);
+/* dense per-m ring tables for tests (small L): Binv[t*L+el] = (-1)^s N_el d^el_{m,-s}(theta_t),
+ * Afwd[el*L+t] = exact-quadrature forward matrix; either pointer may be NULL */
+int pxm_host_sht_tables(int L, int spin, int m, double* Binv, double* Afwd);
+
+/* ---- spin spherical-harmonic transforms on the MW grid ---------------------- */
+/* replaces pyssht.forward / inverse / inverse_adjoint / forward_adjoint
+ * (pxmcmc/measurements.py:223,225,237,239).  flm: [C][L*L] c128, f: [C][L*(2L-1)] c128. */
+int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht_plan_t* plan);
+int pxm_sht_plan_destroy(pxm_sht_plan_t plan);
+int pxm_sht_inverse(pxm_sht_plan_t plan, const void* flm, void* f, int C, pxm_stream_t stream);
+int pxm_sht_forward(pxm_sht_plan_t plan, const void* f, void* flm, int C, pxm_stream_t stream);
+int pxm_sht_inverse_adjoint(pxm_sht_plan_t plan, const void* f, void* flm, int C, pxm_stream_t stream);
+int pxm_sht_forward_adjoint(pxm_sht_plan_t plan, const void* flm, void* f, int C, pxm_stream_t stream);
+/* bytes of Legendre/Wigner ring table one transform launch streams (roofline accounting) */
+int64_t pxm_sht_table_bytes(pxm_sht_plan_t plan, int op /*0 inv,1 fwd,2 inv_adj,3 fwd_adj*/);
+
+/* ---- scale-discretised wavelet transform (N=1, spin 0, upsample=0) -------------- */
+/* replaces pys2let.synthesis_wav2px / synthesis_adjoint_px2wav / analysis_px2wav /
+ * analysis_adjoint_wav2px (pxmcmc/transforms.py:95-98).  X: [C][ncoefs] c128, f: [C][L*(2L-1)] c128. */
+int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned flags, pxm_wav_plan_t* plan);
+int pxm_wav_plan_destroy(pxm_wav_plan_t plan);
+int pxm_wav_synthesis(pxm_wav_plan_t plan, const void* X, void* f, int C, pxm_stream_t stream);
+int pxm_wav_synthesis_adjoint(pxm_wav_plan_t plan, const void* f, void* X, int C, pxm_stream_t stream);
+int pxm_wav_analysis(pxm_wav_plan_t plan, const void* f, void* X, int C, pxm_stream_t stream);
+int pxm_wav_analysis_adjoint(pxm_wav_plan_t plan, const void* X, void* f, int C, pxm_stream_t stream);
+int64_t pxm_wav_table_bytes(pxm_wav_plan_t plan, int op /*0 synthesis,1 synthesis_adjoint*/);
+
+/* Fused MYULA half-steps (pxmcmc/mcmc.py:158-161 with forward.py:66-72, prior.py:49-50):
+ *   pxm_wav_gradg_step: X_out = (1-d/l) X + (d/l) soft(X,T) - d * S^H( invcov .* (preds - data) ) + sqrt(2 d) w
+ * i.e. calc_gradg + proxf + chain_step in one pass over the coefficient vector, with the
+ * residual folded into the transform's input read and the update into its output write.
+ * data/invcov: [P] shared by all chains (invcov complex iff invcov_complex); T: [N] or NULL
+ * (then T_scalar); noise: [C][N] injected N(0,1) (c128 iff noise_complex) or NULL for the
+ * Philox stream keyed (seed, chain0 + c, iter). */
+int pxm_wav_gradg_step(pxm_wav_plan_t plan, const void* X, const void* preds, const void* data,
+                       const void* invcov, int invcov_complex, const double* T, double T_scalar,
+                       double delta, double lmda, const void* noise, int noise_complex,
+                       uint64_t seed, uint64_t chain0, uint64_t iter, void* X_out, int C,
+                       pxm_stream_t stream);
+
+/* ---- elementwise / reductions ---------------------------------------------------- */
+/* dtype: 0 = float64, 1 = complex128.  n = elements per chain. */
+/* utils.soft (pxmcmc/utils.py:55-67,84-88): T vector [n] (shared by chains) or NULL -> T_scalar */
+int pxm_soft(const void* X, const double* T, double T_scalar, void* out, int64_t n, int C, int dtype,
+             pxm_stream_t stream);
+/* ForwardOperator._gradg_analysis residual (pxmcmc/forward.py:66-69) with a diagonal invcov:
+ * out = invcov .* (preds - data); data, invcov are [n] shared by all chains */
+int pxm_residual_grad(const void* preds, const void* data, const void* invcov, int invcov_complex,
+                      void* out, int64_t n, int C, int dtype, pxm_stream_t stream);
+/* MYULA.chain_step fused with L1 prox (pxmcmc/mcmc.py:185-201 + prior.py:49-50).
+ * delta_dev: per-chain step sizes [C] on the device or NULL -> delta. */
+int pxm_myula_step(const void* X, const void* gradg, const double* T, double T_scalar,
+                   const double* delta_dev, double delta, double lmda, const void* noise,
+                   int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter, void* X_out,
+                   int64_t n, int C, int dtype, pxm_stream_t stream);
+/* chain_step with proxf given (PxMALA keeps proxf of the current state, mcmc.py:231) */
+int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const double* delta_dev,
+                   double delta, double lmda, const void* noise, int noise_complex, uint64_t seed,
+                   uint64_t chain0, uint64_t iter, void* X_out, int64_t n, int C, int dtype,
+                   pxm_stream_t stream);
+/* N(0,1) draws of the Philox4x32-10 stream keyed (seed, chain0+c, iter): out [C][n] (f64 or c128) */
+int pxm_randn(void* out, int64_t n, int C, int dtype, uint64_t seed, uint64_t chain0, uint64_t iter,
+              pxm_stream_t stream);
+/* L1.prior / S2_Wavelets_L1.prior (pxmcmc/prior.py:28-35,83-84): out[c] = sum_i |w_i X_ci| */
+int pxm_reduce_l1(const void* X, const double* w, double* out, int64_t n, int C, int dtype,
+                  pxm_stream_t stream);
+/* logpi's L2 = vdot(d, invcov d), d = data - preds (pxmcmc/mcmc.py:78-79): out[c] = (re, im) */
+int pxm_reduce_l2(const void* preds, const void* data, const void* invcov, int invcov_complex,
+                  double* out, int64_t n, int C, int dtype, pxm_stream_t stream);
+/* PxMALA.calc_logtransition, literal (pxmcmc/mcmc.py:281-289): out[c] = (re, im) */
+int pxm_logtransition(const void* X1, const void* X2, const void* proxf, const void* gradg,
+                      const double* delta_dev, double delta, double lmda, double* out, int64_t n,
+                      int C, int dtype, pxm_stream_t stream);
+/* Metropolis accept + state swap + delta adaptation for every chain (pxmcmc/mcmc.py:244-260,
+ * 277-279).  logalpha_terms: [C][4] = (logtrans_pc, logpi_p, logtrans_cp, logpi_c) real parts.
+ * For accepted chains copies prop -> curr for each of nbuf (buffer pairs, sizes in elements).
+ * u: injected uniforms [C] or NULL (Philox).  accept_out [C] int32; delta_dev updated when tune. */
+int pxm_pxmala_accept(const double* logalpha_terms, const double* u, uint64_t seed, uint64_t chain0,
+                      uint64_t iter, int32_t* accept_out, double* delta_dev, int tune, double lmda,
+                      int64_t it_index, int C, pxm_stream_t stream);
+/* per-chain conditional copy: dst[c] = src[c] where flag[c] != 0; n elements of esize bytes */
+int pxm_select_copy(const int32_t* flag, const void* src, void* dst, int64_t n, int esize, int C,
+                    pxm_stream_t stream);
+
+/* ---- weak-lensing measurement helpers (pxmcmc/measurements.py:151-171, 242-304) --------- */
+/* out = flm .* kernel with entries [0,4) zeroed: harmonic_mapping (:162-171). kernel: [L*L] */
+int pxm_wl_harmonic_mapping(const void* flm, const double* kernel, void* out, int64_t n, int C,
+                            pxm_stream_t stream);
+/* gather unmasked pixels and weight: out[c][k] = f[c][idx[k]] * w[k]   (mask_forward + cov_weight) */
+int pxm_wl_mask_gather(const void* f, const int64_t* idx, const double* w, void* out, int64_t npix,
+                       int64_t ndata, int C, pxm_stream_t stream);
+/* weight and scatter into zeros: f[c][idx[k]] = g[c][k] * w[k]          (cov_weight + mask_adjoint) */
+int pxm_wl_mask_scatter(const void* g, const int64_t* idx, const double* w, void* f, int64_t npix,
+                        int64_t ndata, int C, pxm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,50 @@
+// Shared declarations for the pxmcmc_amd native library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace pxm {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define PXM_HIP(x)                                                   \
+  do {                                                               \
+    hipError_t e_ = (x);                                             \
+    if (e_ != hipSuccess) return pxm::hip_fail(e_, #x, __FILE__, __LINE__); \
+  } while (0)
+
+#define PXM_REQUIRE(cond, msg)       \
+  do {                               \
+    if (!(cond)) {                   \
+      pxm::set_error(msg);           \
+      return -1;                     \
+    }                                \
+  } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int round_down(int x, int m) { return x / m * m; }
+
+// ---- host table math (tables.cpp) ------------------------------------------
+int j_max(int L, double B);
+std::vector<int> wav_bandlimits(int L, double B, int J_min);
+// kappa0[L]; kappa[(J_max+1)*L], rows j < J_min zero
+void tiling_axisym(int L, double B, int J_min, std::vector<double>& kappa0, std::vector<double>& kappa);
+void mw_ring_weights(int L, double* q);
+// B^m[t][el] = (-1)^s sqrt((2el+1)/4pi) d^el_{m,-s}(theta_t), written with leading dimension ld (>= L)
+void wigner_ring_table(int L, int spin, int m, double* out, int ld);
+// Q^{par}[t'][t] (L x L, leading dimension ld): MW exact-quadrature Gram matrix, par = +1 / -1
+void quadrature_gram(int L, int par, double* Q, int ld);
+
+struct BluesteinTables {
+  int n = 0, M = 0, logM = 0;
+  std::vector<double> chirp;  // [n][2]   c_j = exp(-i pi j^2 / n)
+  std::vector<double> bhat;   // [M][2]   FFT_M(conj chirp filter) / M, bit-reversed order
+  std::vector<double> tw;     // [M/2][2] exp(-2 pi i k / M)
+};
+BluesteinTables make_bluestein(int n);
+
+}  // namespace pxm

@@ -1,0 +1,472 @@
+// HBM-bound elementwise kernels and reductions of the MYULA / PxMALA iteration, and their C-ABI.
+// Every array is [C][n] (chain-major); T / data / invcov / weights are [n], shared by all chains.
+#include "../../include/pxmcmc_amd.h"
+#include "elem.h"
+#include "common.h"
+
+namespace pxm {
+
+static inline dim3 ew_grid(int64_t n, int C) {
+  int64_t bx = (n + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  if (bx < 1) bx = 1;
+  return dim3((unsigned)bx, (unsigned)C);
+}
+
+template <bool CPLX>
+__global__ void k_soft(const double* __restrict__ X, const double* __restrict__ T, double Ts, double* __restrict__ out,
+                       int64_t n) {
+  const int64_t base = (int64_t)blockIdx.y * n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double t = T ? T[i] : Ts;
+    if (CPLX) {
+      reinterpret_cast<double2*>(out)[base + i] = soft_cplx(reinterpret_cast<const double2*>(X)[base + i], t);
+    } else {
+      out[base + i] = soft_real(X[base + i], t);
+    }
+  }
+}
+
+template <bool CPLX, bool ICPLX>
+__global__ void k_residual(const double* __restrict__ preds, const double* __restrict__ data,
+                           const double* __restrict__ invcov, double* __restrict__ out, int64_t n) {
+  const int64_t base = (int64_t)blockIdx.y * n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (CPLX) {
+      double2 d = csub(reinterpret_cast<const double2*>(preds)[base + i], reinterpret_cast<const double2*>(data)[i]);
+      if (ICPLX) d = cmul(reinterpret_cast<const double2*>(invcov)[i], d);
+      else {
+        const double w = invcov[i];
+        d = double2{w * d.x, w * d.y};
+      }
+      reinterpret_cast<double2*>(out)[base + i] = d;
+    } else {
+      out[base + i] = invcov[i] * (preds[base + i] - data[i]);
+    }
+  }
+}
+
+struct NoiseSrc {
+  const double* noise;
+  int noise_complex;
+  uint64_t seed, chain0, iter;
+};
+
+template <bool CPLX>
+__device__ inline double2 draw_noise(const NoiseSrc& ns, int c, int64_t n, int64_t i) {
+  if (ns.noise) {
+    if (CPLX && ns.noise_complex) return reinterpret_cast<const double2*>(ns.noise)[(int64_t)c * n + i];
+    return double2{ns.noise[(int64_t)c * n + i], 0.0};
+  }
+  if (CPLX && ns.noise_complex) {
+    NormalPair q = philox_normal_pair(ns.seed, ns.chain0 + c, (uint64_t)i, ns.iter);
+    return double2{q.z0, q.z1};
+  }
+  return double2{philox_normal_real(ns.seed, ns.chain0 + c, (uint64_t)i, ns.iter), 0.0};
+}
+
+// X_out = (1-d/l) X + (d/l) P - d g + sqrt(2d) w, with P = soft(X,T) (FUSED_PROX) or given
+template <bool CPLX, bool FUSED_PROX>
+__global__ void k_chain_step(const double* __restrict__ X, const double* __restrict__ P, const double* __restrict__ g,
+                             const double* __restrict__ T, double Ts, const double* __restrict__ delta_dev,
+                             double delta, double lmda, NoiseSrc ns, double* __restrict__ out, int64_t n) {
+  const int c = blockIdx.y;
+  const int64_t base = (int64_t)c * n;
+  const double d = delta_dev ? delta_dev[c] : delta;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double2 w = draw_noise<CPLX>(ns, c, n, i);
+    if (CPLX) {
+      const double2 x = reinterpret_cast<const double2*>(X)[base + i];
+      const double2 px = FUSED_PROX ? soft_cplx(x, T ? T[i] : Ts) : reinterpret_cast<const double2*>(P)[base + i];
+      reinterpret_cast<double2*>(out)[base + i] =
+          chain_step_cplx(x, px, reinterpret_cast<const double2*>(g)[base + i], w, d, lmda);
+    } else {
+      const double x = X[base + i];
+      const double px = FUSED_PROX ? soft_real(x, T ? T[i] : Ts) : P[base + i];
+      out[base + i] = chain_step_real(x, px, g[base + i], w.x, d, lmda);
+    }
+  }
+}
+
+template <bool CPLX>
+__global__ void k_randn(double* __restrict__ out, int64_t n, NoiseSrc ns) {
+  const int c = blockIdx.y;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double2 w = draw_noise<CPLX>(ns, c, n, i);
+    if (CPLX) reinterpret_cast<double2*>(out)[(int64_t)c * n + i] = w;
+    else out[(int64_t)c * n + i] = w.x;
+  }
+}
+
+// ---- reductions: one workgroup per (chain, slice); deterministic two-stage sum -------------------
+__device__ inline double2 block_sum2(double2 v) {
+  __shared__ double2 part[16];
+  for (int off = 32; off > 0; off >>= 1) {
+    v.x += __shfl_down(v.x, off);
+    v.y += __shfl_down(v.y, off);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) part[wave] = v;
+  __syncthreads();
+  double2 tot{0.0, 0.0};
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot = cadd(tot, part[w]);
+  return tot;
+}
+
+constexpr int RED_SLICES = 64;
+
+template <bool CPLX>
+__global__ void k_l1_partial(const double* __restrict__ X, const double* __restrict__ w, double* __restrict__ part,
+                             int64_t n) {
+  const int c = blockIdx.y;
+  double acc = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double a;
+    if (CPLX) {
+      const double2 z = reinterpret_cast<const double2*>(X)[(int64_t)c * n + i];
+      a = hypot(z.x, z.y);
+    } else a = fabs(X[(int64_t)c * n + i]);
+    acc += w ? fabs(w[i]) * a : a;
+  }
+  double2 tot = block_sum2(double2{acc, 0.0});
+  if (threadIdx.x == 0) part[((int64_t)c * gridDim.x + blockIdx.x) * 2] = tot.x, part[((int64_t)c * gridDim.x + blockIdx.x) * 2 + 1] = 0.0;
+}
+
+// L2 = vdot(d, invcov d) = sum conj(d) * (invcov * d), d = data - preds   (pxmcmc/mcmc.py:78-79)
+template <bool CPLX, bool ICPLX>
+__global__ void k_l2_partial(const double* __restrict__ preds, const double* __restrict__ data,
+                             const double* __restrict__ invcov, double* __restrict__ part, int64_t n) {
+  const int c = blockIdx.y;
+  double2 acc{0.0, 0.0};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (CPLX) {
+      const double2 d = csub(reinterpret_cast<const double2*>(data)[i], reinterpret_cast<const double2*>(preds)[(int64_t)c * n + i]);
+      double2 wd;
+      if (ICPLX) wd = cmul(reinterpret_cast<const double2*>(invcov)[i], d);
+      else wd = double2{invcov[i] * d.x, invcov[i] * d.y};
+      // conj(d) * wd
+      acc.x += d.x * wd.x + d.y * wd.y;
+      acc.y += d.x * wd.y - d.y * wd.x;
+    } else {
+      const double d = data[i] - preds[(int64_t)c * n + i];
+      acc.x += d * (invcov[i] * d);
+    }
+  }
+  double2 tot = block_sum2(acc);
+  if (threadIdx.x == 0) reinterpret_cast<double2*>(part)[(int64_t)c * gridDim.x + blockIdx.x] = tot;
+}
+
+// S = sum (X2 - X1 - (d/2) g)^2 with g = -((X1 - proxf)/l) - gradg; complex squares, no abs (literal)
+template <bool CPLX>
+__global__ void k_logtrans_partial(const double* __restrict__ X1, const double* __restrict__ X2,
+                                   const double* __restrict__ P, const double* __restrict__ G,
+                                   const double* __restrict__ delta_dev, double delta, double lmda,
+                                   double* __restrict__ part, int64_t n) {
+  const int c = blockIdx.y;
+  const double d = delta_dev ? delta_dev[c] : delta;
+  const int64_t base = (int64_t)c * n;
+  double2 acc{0.0, 0.0};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (CPLX) {
+      const double2 x1 = reinterpret_cast<const double2*>(X1)[base + i], x2 = reinterpret_cast<const double2*>(X2)[base + i];
+      const double2 p = reinterpret_cast<const double2*>(P)[base + i], g = reinterpret_cast<const double2*>(G)[base + i];
+      const double2 gl{-((x1.x - p.x) / lmda) - g.x, -((x1.y - p.y) / lmda) - g.y};
+      const double2 r{x2.x - x1.x - (d / 2) * gl.x, x2.y - x1.y - (d / 2) * gl.y};
+      acc.x += r.x * r.x - r.y * r.y;
+      acc.y += 2 * r.x * r.y;
+    } else {
+      const double gl = -((X1[base + i] - P[base + i]) / lmda) - G[base + i];
+      const double r = X2[base + i] - X1[base + i] - (d / 2) * gl;
+      acc.x += r * r;
+    }
+  }
+  double2 tot = block_sum2(acc);
+  if (threadIdx.x == 0) reinterpret_cast<double2*>(part)[(int64_t)c * gridDim.x + blockIdx.x] = tot;
+}
+
+// mode 0: out[c] = sum of partials; mode 1 (logtransition): out[c] = -(d/2) * S^2 (complex)
+__global__ void k_reduce_final(const double* __restrict__ part, double* __restrict__ out, int slices, int mode,
+                               const double* __restrict__ delta_dev, double delta) {
+  const int c = blockIdx.x;
+  double2 v{0.0, 0.0};
+  if ((int)threadIdx.x < slices) v = reinterpret_cast<const double2*>(part)[(int64_t)c * slices + threadIdx.x];
+  for (int off = 32; off > 0; off >>= 1) {
+    v.x += __shfl_down(v.x, off);
+    v.y += __shfl_down(v.y, off);
+  }
+  if (threadIdx.x == 0) {
+    if (mode == 1) {
+      const double d = delta_dev ? delta_dev[c] : delta;
+      const double2 s2 = cmul(v, v);
+      v = double2{-(1.0 / 2 * d) * s2.x, -(1.0 / 2 * d) * s2.y};
+    }
+    reinterpret_cast<double2*>(out)[c] = v;
+  }
+}
+
+// scratch for partial sums: one per device, grown on demand outside of stream capture
+static double* g_part = nullptr;
+static size_t g_part_cap = 0;
+static int ensure_part(int C) {
+  size_t need = (size_t)C * RED_SLICES * 2 * sizeof(double);
+  if (need <= g_part_cap) return 0;
+  if (g_part) PXM_HIP(hipFree(g_part));
+  size_t cap = need < (1u << 20) ? (1u << 20) : need;
+  PXM_HIP(hipMalloc(&g_part, cap));
+  g_part_cap = cap;
+  return 0;
+}
+
+__global__ void k_l1_store(const double* __restrict__ red, double* __restrict__ out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) out[c] = red[2 * c];
+}
+
+__global__ void k_pxmala_accept(const double* __restrict__ terms, const double* __restrict__ u, uint64_t seed,
+                                uint64_t chain0, uint64_t iter, int32_t* __restrict__ accept, double* __restrict__ delta_dev,
+                                int tune, double lmda, int64_t it_index, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  // logalpha = logtransXpXc + logpiXp - logtransXcXp - logpiXc   (pxmcmc/mcmc.py:244)
+  const double logalpha = terms[4 * c + 0] + terms[4 * c + 1] - terms[4 * c + 2] - terms[4 * c + 3];
+  const double uu = u ? u[c] : philox_uniform(seed, chain0 + c, iter);
+  const int acc = log(uu) < logalpha ? 1 : 0;
+  accept[c] = acc;
+  if (tune) {  // pxmcmc/mcmc.py:277-279
+    double d = delta_dev[c] * (1 + (acc - 0.5) / pow((double)(it_index + 1), 0.75));
+    d = fmin(fmax(d, lmda * 1e-8), lmda / 2);
+    delta_dev[c] = d;
+  }
+}
+
+__global__ void k_select_copy(const int32_t* __restrict__ flag, const uint64_t* __restrict__ src, uint64_t* __restrict__ dst,
+                              int64_t nwords) {
+  const int c = blockIdx.y;
+  if (!flag[c]) return;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x)
+    dst[(int64_t)c * nwords + i] = src[(int64_t)c * nwords + i];
+}
+
+__global__ void k_wl_mapping(const double2* __restrict__ flm, const double* __restrict__ kernel, double2* __restrict__ out,
+                             int64_t n) {
+  const int64_t base = (int64_t)blockIdx.y * n;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double2 v = flm[base + i];
+    const double k = kernel[i];
+    v = (i < 4) ? double2{0.0, 0.0} : double2{v.x * k, v.y * k};
+    out[base + i] = v;
+  }
+}
+
+__global__ void k_wl_gather(const double2* __restrict__ f, const int64_t* __restrict__ idx, const double* __restrict__ w,
+                            double2* __restrict__ out, int64_t npix, int64_t ndata) {
+  const int c = blockIdx.y;
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < ndata; k += (int64_t)gridDim.x * blockDim.x) {
+    const double2 v = f[(int64_t)c * npix + idx[k]];
+    const double ww = w ? w[k] : 1.0;
+    out[(int64_t)c * ndata + k] = double2{v.x * ww, v.y * ww};
+  }
+}
+
+__global__ void k_wl_scatter(const double2* __restrict__ g, const int64_t* __restrict__ idx, const double* __restrict__ w,
+                             double2* __restrict__ f, int64_t npix, int64_t ndata) {
+  const int c = blockIdx.y;
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < ndata; k += (int64_t)gridDim.x * blockDim.x) {
+    const double2 v = g[(int64_t)c * ndata + k];
+    const double ww = w ? w[k] : 1.0;
+    f[(int64_t)c * npix + idx[k]] = double2{v.x * ww, v.y * ww};
+  }
+}
+
+}  // namespace pxm
+
+using namespace pxm;
+
+#define CHECK_ARGS(name)                                                          \
+  PXM_REQUIRE(n >= 0 && C >= 1 && (dtype == 0 || dtype == 1), name ": bad n / C / dtype"); \
+  if (n == 0) return 0;                                                           \
+  hipStream_t st = (hipStream_t)stream
+
+extern "C" {
+
+int pxm_soft(const void* X, const double* T, double T_scalar, void* out, int64_t n, int C, int dtype,
+             pxm_stream_t stream) {
+  CHECK_ARGS("pxm_soft");
+  PXM_REQUIRE(X && out, "pxm_soft: null buffer");
+  dim3 g = ew_grid(n, C), b(256);
+  if (dtype) hipLaunchKernelGGL(k_soft<true>, g, b, 0, st, (const double*)X, T, T_scalar, (double*)out, n);
+  else hipLaunchKernelGGL(k_soft<false>, g, b, 0, st, (const double*)X, T, T_scalar, (double*)out, n);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_residual_grad(const void* preds, const void* data, const void* invcov, int invcov_complex, void* out,
+                      int64_t n, int C, int dtype, pxm_stream_t stream) {
+  CHECK_ARGS("pxm_residual_grad");
+  PXM_REQUIRE(preds && data && invcov && out, "pxm_residual_grad: null buffer");
+  PXM_REQUIRE(dtype == 1 || !invcov_complex, "pxm_residual_grad: complex invcov needs complex data");
+  dim3 g = ew_grid(n, C), b(256);
+  const double *p = (const double*)preds, *d = (const double*)data, *ic = (const double*)invcov;
+  if (dtype && invcov_complex) hipLaunchKernelGGL((k_residual<true, true>), g, b, 0, st, p, d, ic, (double*)out, n);
+  else if (dtype) hipLaunchKernelGGL((k_residual<true, false>), g, b, 0, st, p, d, ic, (double*)out, n);
+  else hipLaunchKernelGGL((k_residual<false, false>), g, b, 0, st, p, d, ic, (double*)out, n);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_myula_step(const void* X, const void* gradg, const double* T, double T_scalar, const double* delta_dev,
+                   double delta, double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0,
+                   uint64_t iter, void* X_out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+  CHECK_ARGS("pxm_myula_step");
+  PXM_REQUIRE(X && gradg && X_out, "pxm_myula_step: null buffer");
+  PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_myula_step: complex noise needs a complex state");
+  dim3 g = ew_grid(n, C), b(256);
+  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter};
+  if (dtype)
+    hipLaunchKernelGGL((k_chain_step<true, true>), g, b, 0, st, (const double*)X, (const double*)nullptr,
+                       (const double*)gradg, T, T_scalar, delta_dev, delta, lmda, ns, (double*)X_out, n);
+  else
+    hipLaunchKernelGGL((k_chain_step<false, true>), g, b, 0, st, (const double*)X, (const double*)nullptr,
+                       (const double*)gradg, T, T_scalar, delta_dev, delta, lmda, ns, (double*)X_out, n);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const double* delta_dev, double delta,
+                   double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter,
+                   void* X_out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+  CHECK_ARGS("pxm_chain_step");
+  PXM_REQUIRE(X && proxf && gradg && X_out, "pxm_chain_step: null buffer");
+  PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_chain_step: complex noise needs a complex state");
+  dim3 g = ew_grid(n, C), b(256);
+  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter};
+  if (dtype)
+    hipLaunchKernelGGL((k_chain_step<true, false>), g, b, 0, st, (const double*)X, (const double*)proxf,
+                       (const double*)gradg, (const double*)nullptr, 0.0, delta_dev, delta, lmda, ns, (double*)X_out, n);
+  else
+    hipLaunchKernelGGL((k_chain_step<false, false>), g, b, 0, st, (const double*)X, (const double*)proxf,
+                       (const double*)gradg, (const double*)nullptr, 0.0, delta_dev, delta, lmda, ns, (double*)X_out, n);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_randn(void* out, int64_t n, int C, int dtype, uint64_t seed, uint64_t chain0, uint64_t iter,
+              pxm_stream_t stream) {
+  CHECK_ARGS("pxm_randn");
+  PXM_REQUIRE(out, "pxm_randn: null buffer");
+  dim3 g = ew_grid(n, C), b(256);
+  NoiseSrc ns{nullptr, dtype, seed, chain0, iter};
+  if (dtype) hipLaunchKernelGGL(k_randn<true>, g, b, 0, st, (double*)out, n, ns);
+  else hipLaunchKernelGGL(k_randn<false>, g, b, 0, st, (double*)out, n, ns);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_reduce_l1(const void* X, const double* w, double* out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+  PXM_REQUIRE(n >= 0 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_reduce_l1: bad n / C / dtype");
+  hipStream_t st = (hipStream_t)stream;
+  PXM_REQUIRE(X && out, "pxm_reduce_l1: null buffer");
+  int rc = ensure_part(C + 1);
+  if (rc) return rc;
+  dim3 g(RED_SLICES, C), b(256);
+  if (dtype) hipLaunchKernelGGL(k_l1_partial<true>, g, b, 0, st, (const double*)X, w, g_part, n);
+  else hipLaunchKernelGGL(k_l1_partial<false>, g, b, 0, st, (const double*)X, w, g_part, n);
+  double* red = g_part + (size_t)C * RED_SLICES * 2;
+  // final sums land in the tail of the scratch, then the real parts are compacted to out[C]
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, g_part, red, RED_SLICES, 0, (const double*)nullptr, 0.0);
+  hipLaunchKernelGGL(k_l1_store, dim3((C + 63) / 64), dim3(64), 0, st, red, out, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_reduce_l2(const void* preds, const void* data, const void* invcov, int invcov_complex, double* out, int64_t n,
+                  int C, int dtype, pxm_stream_t stream) {
+  PXM_REQUIRE(n >= 0 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_reduce_l2: bad n / C / dtype");
+  PXM_REQUIRE(dtype == 1 || !invcov_complex, "pxm_reduce_l2: complex invcov needs complex data");
+  hipStream_t st = (hipStream_t)stream;
+  PXM_REQUIRE(preds && data && invcov && out, "pxm_reduce_l2: null buffer");
+  int rc = ensure_part(C + 1);
+  if (rc) return rc;
+  dim3 g(RED_SLICES, C), b(256);
+  const double *p = (const double*)preds, *d = (const double*)data, *ic = (const double*)invcov;
+  if (dtype && invcov_complex) hipLaunchKernelGGL((k_l2_partial<true, true>), g, b, 0, st, p, d, ic, g_part, n);
+  else if (dtype) hipLaunchKernelGGL((k_l2_partial<true, false>), g, b, 0, st, p, d, ic, g_part, n);
+  else hipLaunchKernelGGL((k_l2_partial<false, false>), g, b, 0, st, p, d, ic, g_part, n);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, g_part, out, RED_SLICES, 0, (const double*)nullptr, 0.0);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_logtransition(const void* X1, const void* X2, const void* proxf, const void* gradg, const double* delta_dev,
+                      double delta, double lmda, double* out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+  PXM_REQUIRE(n >= 0 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_logtransition: bad n / C / dtype");
+  hipStream_t st = (hipStream_t)stream;
+  PXM_REQUIRE(X1 && X2 && proxf && gradg && out, "pxm_logtransition: null buffer");
+  int rc = ensure_part(C + 1);
+  if (rc) return rc;
+  dim3 g(RED_SLICES, C), b(256);
+  if (dtype)
+    hipLaunchKernelGGL(k_logtrans_partial<true>, g, b, 0, st, (const double*)X1, (const double*)X2, (const double*)proxf,
+                       (const double*)gradg, delta_dev, delta, lmda, g_part, n);
+  else
+    hipLaunchKernelGGL(k_logtrans_partial<false>, g, b, 0, st, (const double*)X1, (const double*)X2,
+                       (const double*)proxf, (const double*)gradg, delta_dev, delta, lmda, g_part, n);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, g_part, out, RED_SLICES, 1, delta_dev, delta);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_pxmala_accept(const double* logalpha_terms, const double* u, uint64_t seed, uint64_t chain0, uint64_t iter,
+                      int32_t* accept_out, double* delta_dev, int tune, double lmda, int64_t it_index, int C,
+                      pxm_stream_t stream) {
+  PXM_REQUIRE(C >= 1 && logalpha_terms && accept_out, "pxm_pxmala_accept: bad arguments");
+  PXM_REQUIRE(!tune || delta_dev, "pxm_pxmala_accept: tune needs delta_dev");
+  hipLaunchKernelGGL(k_pxmala_accept, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, logalpha_terms, u, seed,
+                     chain0, iter, accept_out, delta_dev, tune, lmda, it_index, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_select_copy(const int32_t* flag, const void* src, void* dst, int64_t n, int esize, int C, pxm_stream_t stream) {
+  PXM_REQUIRE(C >= 1 && flag && src && dst && n >= 0 && esize > 0 && esize % 8 == 0, "pxm_select_copy: bad arguments");
+  if (n == 0) return 0;
+  const int64_t nwords = n * (esize / 8);
+  hipLaunchKernelGGL(k_select_copy, ew_grid(nwords, C), dim3(256), 0, (hipStream_t)stream, flag, (const uint64_t*)src,
+                     (uint64_t*)dst, nwords);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_wl_harmonic_mapping(const void* flm, const double* kernel, void* out, int64_t n, int C, pxm_stream_t stream) {
+  PXM_REQUIRE(C >= 1 && flm && kernel && out && n >= 0, "pxm_wl_harmonic_mapping: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_wl_mapping, ew_grid(n, C), dim3(256), 0, (hipStream_t)stream, (const double2*)flm, kernel,
+                     (double2*)out, n);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_wl_mask_gather(const void* f, const int64_t* idx, const double* w, void* out, int64_t npix, int64_t ndata,
+                       int C, pxm_stream_t stream) {
+  PXM_REQUIRE(C >= 1 && f && idx && out && ndata >= 0 && npix >= ndata, "pxm_wl_mask_gather: bad arguments");
+  if (ndata == 0) return 0;
+  hipLaunchKernelGGL(k_wl_gather, ew_grid(ndata, C), dim3(256), 0, (hipStream_t)stream, (const double2*)f, idx, w,
+                     (double2*)out, npix, ndata);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_wl_mask_scatter(const void* g, const int64_t* idx, const double* w, void* f, int64_t npix, int64_t ndata, int C,
+                        pxm_stream_t stream) {
+  PXM_REQUIRE(C >= 1 && g && idx && f && ndata >= 0 && npix >= ndata, "pxm_wl_mask_scatter: bad arguments");
+  PXM_HIP(hipMemsetAsync(f, 0, (size_t)C * npix * 16, (hipStream_t)stream));
+  if (ndata == 0) return 0;
+  hipLaunchKernelGGL(k_wl_scatter, ew_grid(ndata, C), dim3(256), 0, (hipStream_t)stream, (const double2*)g, idx, w,
+                     (double2*)f, npix, ndata);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

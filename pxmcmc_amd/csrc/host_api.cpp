@@ -1,0 +1,90 @@
+// C-ABI entry points that need no GPU: error reporting and setup helpers.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+
+#include "../../include/pxmcmc_amd.h"
+#include "common.h"
+
+namespace pxm {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
+  return -2;
+}
+}  // namespace pxm
+
+extern "C" {
+
+int pxm_version(void) { return 100; }
+
+const char* pxm_last_error(void) { return pxm::g_err.c_str(); }
+
+int pxm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pxm_j_max(int L, double B) {
+  if (L < 1 || !(B > 1.0)) {
+    pxm::set_error("pxm_j_max: need L >= 1 and B > 1");
+    return -1;
+  }
+  return pxm::j_max(L, B);
+}
+
+int pxm_wav_bandlimits(int L, double B, int J_min, int* bl_out, int cap) {
+  PXM_REQUIRE(L >= 1 && B > 1.0 && J_min >= 0, "pxm_wav_bandlimits: bad (L, B, J_min)");
+  std::vector<int> bl = pxm::wav_bandlimits(L, B, J_min);
+  PXM_REQUIRE((int)bl.size() <= cap, "pxm_wav_bandlimits: output capacity too small");
+  for (size_t i = 0; i < bl.size(); ++i) bl_out[i] = bl[i];
+  return (int)bl.size();
+}
+
+int64_t pxm_wav_ncoefs(int L, double B, int J_min, int64_t* nscal_out) {
+  PXM_REQUIRE(L >= 1 && B > 1.0 && J_min >= 0, "pxm_wav_ncoefs: bad (L, B, J_min)");
+  std::vector<int> bl = pxm::wav_bandlimits(L, B, J_min);
+  int64_t n = 0;
+  for (int b : bl) n += (int64_t)b * (2 * b - 1);
+  if (nscal_out) *nscal_out = (int64_t)bl[0] * (2 * bl[0] - 1);
+  return n;
+}
+
+int pxm_tiling_axisym(int L, double B, int J_min, double* kappa0, double* kappa) {
+  PXM_REQUIRE(L >= 1 && B > 1.0 && J_min >= 0, "pxm_tiling_axisym: bad (L, B, J_min)");
+  std::vector<double> k0, k;
+  pxm::tiling_axisym(L, B, J_min, k0, k);
+  std::memcpy(kappa0, k0.data(), k0.size() * sizeof(double));
+  std::memcpy(kappa, k.data(), k.size() * sizeof(double));
+  return 0;
+}
+
+int pxm_mw_ring_weights(int L, double* q) {
+  PXM_REQUIRE(L >= 1, "pxm_mw_ring_weights: L must be >= 1");
+  pxm::mw_ring_weights(L, q);
+  return 0;
+}
+
+int pxm_host_sht_tables(int L, int spin, int m, double* Binv, double* Afwd) {
+  PXM_REQUIRE(L >= 1 && std::abs(m) < L, "pxm_host_sht_tables: need |m| < L");
+  std::vector<double> B((size_t)L * L);
+  pxm::wigner_ring_table(L, spin, m, B.data(), L);
+  if (Binv) std::memcpy(Binv, B.data(), B.size() * sizeof(double));
+  if (Afwd) {
+    std::vector<double> Q((size_t)L * L);
+    int par = ((m + spin) % 2 == 0) ? +1 : -1;
+    pxm::quadrature_gram(L, par, Q.data(), L);
+    const double sc = 2.0 * M_PI / (2 * L - 1);
+    for (int el = 0; el < L; ++el)
+      for (int t = 0; t < L; ++t) {
+        long double acc = 0;
+        for (int tp = 0; tp < L; ++tp) acc += (long double)B[(size_t)tp * L + el] * Q[(size_t)tp * L + t];
+        Afwd[(size_t)el * L + t] = (double)(sc * acc);
+      }
+  }
+  return 0;
+}
+
+}  // extern "C"

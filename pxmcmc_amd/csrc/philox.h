@@ -1,0 +1,63 @@
+// Counter-based Gaussian noise: Philox4x32-10 keyed by (seed, chain), counter (index, iteration).
+// Results do not depend on how chains are spread over GPUs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace pxm {
+
+struct NormalPair {
+  double z0, z1;
+};
+
+__host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0;
+    c[1] = n1;
+    c[2] = n2;
+    c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+// two independent N(0,1) draws for counter (index, iter) under key (seed, chain)
+__device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter) {
+  const uint64_t key = seed + chain * 0x9E3779B97F4A7C15ull;
+  uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)iter, (uint32_t)(iter >> 32)};
+  philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+  const uint64_t a = (((uint64_t)c[1] << 32) | c[0]) >> 11;
+  const uint64_t b = (((uint64_t)c[3] << 32) | c[2]) >> 11;
+  const double u1 = ((double)a + 0.5) * 0x1.0p-53;
+  const double u2 = ((double)b + 0.5) * 0x1.0p-53;
+  const double r = sqrt(-2.0 * log(u1));
+  double s, co;
+  sincospi(2.0 * u2, &s, &co);
+  return NormalPair{r * co, r * s};
+}
+
+// real stream: element e takes draw (e & 1) of pair (e >> 1); complex stream: element e takes pair e
+__device__ inline double philox_normal_real(uint64_t seed, uint64_t chain, uint64_t e, uint64_t iter) {
+  NormalPair p = philox_normal_pair(seed, chain, e >> 1, iter);
+  return (e & 1) ? p.z1 : p.z0;
+}
+
+// one uniform in (0,1) for the PxMALA accept test: counter index 2^63 + 0 keeps it off the noise stream
+__device__ inline double philox_uniform(uint64_t seed, uint64_t chain, uint64_t iter) {
+  const uint64_t key = seed + chain * 0x9E3779B97F4A7C15ull;
+  const uint64_t index = 0x8000000000000000ull;
+  uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)iter, (uint32_t)(iter >> 32)};
+  philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+  const uint64_t a = (((uint64_t)c[1] << 32) | c[0]) >> 11;
+  return ((double)a + 0.5) * 0x1.0p-53;
+}
+
+}  // namespace pxm

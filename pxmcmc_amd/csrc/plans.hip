@@ -1,0 +1,501 @@
+// Transform plans (tables + workspace + static task lists) and their C-ABI.
+#include "../../include/pxmcmc_amd.h"
+#include "elem.h"
+#include "sht_core.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace pxm {
+
+// ---- small helpers --------------------------------------------------------------------------
+struct TaskList {
+  GemmTask* d = nullptr;
+  int n = 0;
+  bool paired = false;
+};
+
+static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out) {
+  // longest first: workgroups are handed out in order, so this is the LPT rule for CU balance
+  std::stable_sort(v.begin(), v.end(), [](const GemmTask& a, const GemmTask& b) {
+    return (int64_t)(a.k_end - a.k_beg) * a.n_rt > (int64_t)(b.k_end - b.k_beg) * b.n_rt;
+  });
+  out->n = (int)v.size();
+  out->paired = paired;
+  if (v.empty()) return 0;
+  PXM_HIP(hipMalloc(&out->d, v.size() * sizeof(GemmTask)));
+  PXM_HIP(hipMemcpy(out->d, v.data(), v.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// run a task list over all chain groups (16 chains = 32 columns per launch)
+static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, hipStream_t st) {
+  for (int col0 = 0; col0 < ncol; col0 += 32) {
+    const int ct = (ncol - col0 >= 32) ? 2 : 1;
+    int rc = launch_gemm(tl.d, tl.n, tl.paired, X, Y, ncol, col0, ct, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+static inline int64_t arr_size(int L, int ncol) { return (int64_t)(2 * L - 1) * round_up(L, 16) * ncol; }
+
+}  // namespace pxm
+
+using namespace pxm;
+
+// =============================================================================================
+// SHT plan
+// =============================================================================================
+struct pxm_sht_plan_s {
+  int L = 0, spin = 0, Cmax = 0, Cp = 0, ncol = 0, Rp = 0;
+  ShtTables* T = nullptr;
+  DftPlan dft;
+  double* ws = nullptr;  // [G | H | scratch]
+  int64_t offG = 0, offH = 0, offS = 0;
+  TaskList tl[4];
+};
+
+extern "C" {
+
+int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht_plan_t* plan) {
+  (void)flags;
+  PXM_REQUIRE(plan, "pxm_sht_plan_create: null plan pointer");
+  PXM_REQUIRE(L >= 1, "pxm_sht_plan_create: Bandlimit must be greater than 0");
+  PXM_REQUIRE(std::abs(spin) < L || L == 1, "pxm_sht_plan_create: |spin| must be < L");
+  PXM_REQUIRE(max_chains >= 1, "pxm_sht_plan_create: max_chains must be >= 1");
+  PXM_REQUIRE(pxm_device_count() > 0, "pxm_sht_plan_create: no HIP device visible (the HIP path is the only path)");
+  pxm_sht_plan_s* p = new pxm_sht_plan_s();
+  p->L = L;
+  p->spin = spin;
+  p->Cmax = max_chains;
+  p->Cp = round_up(max_chains, 8);
+  p->ncol = 2 * p->Cp;
+  p->Rp = round_up(L, 16);
+  int rc = get_tables(L, spin, 0xF, &p->T);
+  if (rc) { delete p; return rc; }
+  rc = make_dft_plan(L, &p->dft);
+  if (rc) { delete p; return rc; }
+  const int64_t sz = arr_size(L, p->ncol);
+  p->offG = 0;
+  p->offH = sz;
+  p->offS = 2 * sz;
+  const size_t bytes = (size_t)(2 * sz + (int64_t)p->Rp * p->ncol) * sizeof(double);
+  PXM_HIP(hipMalloc(&p->ws, bytes));
+  PXM_HIP(hipMemset(p->ws, 0, bytes));
+  for (int k = 0; k < 4; ++k) {
+    std::vector<GemmTask> v;
+    const bool e2r = kind_el_to_ring(k);
+    append_gemm_tasks(*p->T, k, p->ncol, e2r ? p->offH : p->offG, L, p->Rp, e2r ? p->offG : p->offH, L, p->Rp, nullptr,
+                      p->offS, v);
+    rc = upload_tasks(v, p->T->paired, &p->tl[k]);
+    if (rc) return rc;
+  }
+  *plan = p;
+  return 0;
+}
+
+int pxm_sht_plan_destroy(pxm_sht_plan_t p) {
+  if (!p) return 0;
+  free_dft_plan(&p->dft);
+  if (p->ws) (void)hipFree(p->ws);
+  for (int k = 0; k < 4; ++k)
+    if (p->tl[k].d) (void)hipFree(p->tl[k].d);
+  delete p;
+  return 0;
+}
+
+static int sht_check(pxm_sht_plan_t p, const void* a, const void* b, int C, const char* who) {
+  if (!p || !a || !b) {
+    set_error(std::string(who) + ": null argument");
+    return -1;
+  }
+  if (C < 1 || C > p->Cmax) {
+    set_error(std::string(who) + ": C outside [1, max_chains]");
+    return -1;
+  }
+  return 0;
+}
+
+static int sht_el_to_ring(pxm_sht_plan_t p, int kind, const void* flm, void* f, int C, hipStream_t st) {
+  int rc = launch_lm_to_mel((const double*)flm, p->ws + p->offH, p->L, p->Rp, p->ncol, C, p->spin, st);
+  if (rc) return rc;
+  rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, st);
+  if (rc) return rc;
+  PxOut out;
+  out.f = (double*)f;
+  out.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  return launch_ring2px(p->dft, p->ws + p->offG, p->ncol, out, C, st);
+}
+
+static int sht_ring_to_el(pxm_sht_plan_t p, int kind, const void* f, void* flm, int C, hipStream_t st) {
+  PxIn in;
+  in.f = (const double*)f;
+  in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  int rc = launch_px2ring(p->dft, in, p->ws + p->offG, p->ncol, C, st);
+  if (rc) return rc;
+  rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, st);
+  if (rc) return rc;
+  return launch_mel_to_lm(p->ws + p->offH, (double*)flm, p->L, p->Rp, p->ncol, C, p->spin, st);
+}
+
+int pxm_sht_inverse(pxm_sht_plan_t p, const void* flm, void* f, int C, pxm_stream_t s) {
+  int rc = sht_check(p, flm, f, C, "pxm_sht_inverse");
+  return rc ? rc : sht_el_to_ring(p, TAB_INV, flm, f, C, (hipStream_t)s);
+}
+int pxm_sht_forward_adjoint(pxm_sht_plan_t p, const void* flm, void* f, int C, pxm_stream_t s) {
+  int rc = sht_check(p, flm, f, C, "pxm_sht_forward_adjoint");
+  return rc ? rc : sht_el_to_ring(p, TAB_FWD_ADJ, flm, f, C, (hipStream_t)s);
+}
+int pxm_sht_forward(pxm_sht_plan_t p, const void* f, void* flm, int C, pxm_stream_t s) {
+  int rc = sht_check(p, f, flm, C, "pxm_sht_forward");
+  return rc ? rc : sht_ring_to_el(p, TAB_FWD, f, flm, C, (hipStream_t)s);
+}
+int pxm_sht_inverse_adjoint(pxm_sht_plan_t p, const void* f, void* flm, int C, pxm_stream_t s) {
+  int rc = sht_check(p, f, flm, C, "pxm_sht_inverse_adjoint");
+  return rc ? rc : sht_ring_to_el(p, TAB_INV_ADJ, f, flm, C, (hipStream_t)s);
+}
+
+int64_t pxm_sht_table_bytes(pxm_sht_plan_t p, int op) {
+  if (!p || op < 0 || op > 3) return -1;
+  return (int64_t)p->T->bytes[op];
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// Wavelet plan (axisymmetric scale-discretised wavelets, multiresolution)
+// =============================================================================================
+namespace pxm {
+
+// H_L[m][el][col] = sum_i kc[i][el] * H_i[m][el][col]  over the scales whose band holds (el, m)
+struct CombineArgs {
+  int nsc;
+  int L, Rp, ncol;
+  int bl[16], Rp_i[16];
+  int64_t offH[16];
+  const double* kc;  // [nsc][Rp] synthesis coefficients c_s * kappa
+};
+
+__global__ void k_wav_combine(CombineArgs a, const double* __restrict__ ws, double* __restrict__ HL) {
+  const int64_t total = (int64_t)(2 * a.L - 1) * a.Rp * a.ncol;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % a.ncol);
+    const int el = (int)((i / a.ncol) % a.Rp);
+    const int m = (int)(i / ((int64_t)a.ncol * a.Rp)) - (a.L - 1);
+    const int am = m < 0 ? -m : m;
+    double acc = 0;
+    if (el < a.L && el >= am) {
+      for (int s = 0; s < a.nsc; ++s) {
+        if (el >= a.bl[s]) continue;
+        const double k = a.kc[s * a.Rp + el];
+        if (k == 0.0) continue;
+        acc += k * ws[a.offH[s] + ((int64_t)(m + a.bl[s] - 1) * a.Rp_i[s] + el) * a.ncol + col];
+      }
+    }
+    HL[i] = acc;
+  }
+}
+
+}  // namespace pxm
+
+struct pxm_wav_plan_s {
+  int L = 0, J_min = 0, J_max = 0, Cmax = 0, Cp = 0, ncol = 0, Rp = 0;
+  double B = 0;
+  int nsc = 0;  // scaling + wavelet scales
+  std::vector<int> bl;
+  std::vector<int64_t> coef_off;  // offset of each block in the coefficient vector (complex elements)
+  int64_t ncoefs = 0;
+  std::vector<ShtTables*> T;  // per scale
+  ShtTables* TL = nullptr;
+  std::vector<DftPlan> dft;  // per scale
+  DftPlan dftL;
+  double* ws = nullptr;
+  std::vector<int64_t> offG, offH;
+  int64_t offGL = 0, offHL = 0, offS = 0;
+  double* d_kc_syn = nullptr;  // [nsc][Rp]  c_s * kappa   (synthesis and its adjoint)
+  double* d_kc_ana = nullptr;  // [nsc][Rp]  c_a * kappa   (analysis and its adjoint)
+  TaskList syn_fwd, syn_inv, adj_invadj, adj_fwdadj;  // synthesis / synthesis-adjoint stages
+  TaskList ana_fwd, ana_inv, anadj_invadj, anadj_fwdadj;  // analysis / analysis-adjoint stages
+  CombineArgs comb_syn, comb_ana;
+  int64_t table_bytes[2] = {0, 0};
+};
+
+extern "C" {
+
+int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned flags, pxm_wav_plan_t* plan) {
+  (void)flags;
+  PXM_REQUIRE(plan, "pxm_wav_plan_create: null plan pointer");
+  PXM_REQUIRE(L >= 1 && B > 1.0 && J_min >= 0, "pxm_wav_plan_create: bad (L, B, J_min)");
+  PXM_REQUIRE(max_chains >= 1, "pxm_wav_plan_create: max_chains must be >= 1");
+  PXM_REQUIRE(pxm_device_count() > 0, "pxm_wav_plan_create: no HIP device visible (the HIP path is the only path)");
+  pxm_wav_plan_s* p = new pxm_wav_plan_s();
+  p->L = L;
+  p->B = B;
+  p->J_min = J_min;
+  p->J_max = j_max(L, B);
+  p->Cmax = max_chains;
+  p->Cp = round_up(max_chains, 8);
+  p->ncol = 2 * p->Cp;
+  p->Rp = round_up(L, 16);
+  p->bl = wav_bandlimits(L, B, J_min);
+  p->nsc = (int)p->bl.size();
+  PXM_REQUIRE(p->nsc <= 16, "pxm_wav_plan_create: more than 15 wavelet scales are not supported");
+  int64_t off = 0;
+  for (int b : p->bl) {
+    p->coef_off.push_back(off);
+    off += (int64_t)b * (2 * b - 1);
+  }
+  p->ncoefs = off;
+  int rc;
+  // tables: every scale needs the forward pair (synthesis: FWD, its adjoint: FWD_ADJ) and, for the
+  // analysis setting, the inverse pair at its own bandlimit; L needs all four.
+  p->T.resize(p->nsc);
+  p->dft.resize(p->nsc);
+  for (int s = 0; s < p->nsc; ++s) {
+    rc = get_tables(p->bl[s], 0, 0xF, &p->T[s]);
+    if (rc) return rc;
+    rc = make_dft_plan(p->bl[s], &p->dft[s]);
+    if (rc) return rc;
+  }
+  rc = get_tables(L, 0, 0xF, &p->TL);
+  if (rc) return rc;
+  rc = make_dft_plan(L, &p->dftL);
+  if (rc) return rc;
+  // workspace
+  int64_t w = 0;
+  p->offGL = w; w += arr_size(L, p->ncol);
+  p->offHL = w; w += arr_size(L, p->ncol);
+  for (int s = 0; s < p->nsc; ++s) {
+    p->offG.push_back(w); w += arr_size(p->bl[s], p->ncol);
+    p->offH.push_back(w); w += arr_size(p->bl[s], p->ncol);
+  }
+  p->offS = w; w += (int64_t)p->Rp * p->ncol;
+  PXM_HIP(hipMalloc(&p->ws, (size_t)w * sizeof(double)));
+  PXM_HIP(hipMemset(p->ws, 0, (size_t)w * sizeof(double)));
+  // wavelet kernels: synthesis f_lm = kappa0 W^phi + sqrt(2pi) sum_j kappa_j W^j; analysis W^j = kappa_j f / sqrt(2pi)
+  std::vector<double> k0, kap;
+  tiling_axisym(L, B, J_min, k0, kap);
+  std::vector<double> kc_syn((size_t)p->nsc * p->Rp, 0.0), kc_ana((size_t)p->nsc * p->Rp, 0.0);
+  const double cs = std::sqrt(2.0 * M_PI), ca = 1.0 / std::sqrt(2.0 * M_PI);
+  for (int s = 0; s < p->nsc; ++s)
+    for (int el = 0; el < p->bl[s]; ++el) {
+      const double k = (s == 0) ? k0[el] : kap[(size_t)(J_min + s - 1) * L + el];
+      kc_syn[(size_t)s * p->Rp + el] = (s == 0) ? k : cs * k;
+      kc_ana[(size_t)s * p->Rp + el] = (s == 0) ? k : ca * k;
+    }
+  PXM_HIP(hipMalloc(&p->d_kc_syn, kc_syn.size() * sizeof(double)));
+  PXM_HIP(hipMalloc(&p->d_kc_ana, kc_ana.size() * sizeof(double)));
+  PXM_HIP(hipMemcpy(p->d_kc_syn, kc_syn.data(), kc_syn.size() * sizeof(double), hipMemcpyHostToDevice));
+  PXM_HIP(hipMemcpy(p->d_kc_ana, kc_ana.data(), kc_ana.size() * sizeof(double), hipMemcpyHostToDevice));
+  // task lists
+  std::vector<GemmTask> v_syn_fwd, v_adj_fwdadj, v_ana_inv, v_anadj_invadj, v;
+  for (int s = 0; s < p->nsc; ++s) {
+    const int b = p->bl[s], Rb = round_up(b, 16);
+    // synthesis: G_s --A_s--> H_s
+    append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS, v_syn_fwd);
+    // synthesis adjoint: H_L (scaled by c_s kappa_s per el) --A_s^T--> G_s
+    append_gemm_tasks(*p->T[s], TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
+                      p->d_kc_syn + (size_t)s * p->Rp, p->offS, v_adj_fwdadj);
+    // analysis: H_L (scaled by c_a kappa_s) --B_s--> G_s
+    append_gemm_tasks(*p->T[s], TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
+                      p->d_kc_ana + (size_t)s * p->Rp, p->offS, v_ana_inv);
+    // analysis adjoint: G_s --B_s^T--> H_s
+    append_gemm_tasks(*p->T[s], TAB_INV_ADJ, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS,
+                      v_anadj_invadj);
+    p->table_bytes[0] += p->T[s]->bytes[TAB_FWD];
+    p->table_bytes[1] += p->T[s]->bytes[TAB_FWD_ADJ];
+  }
+  p->table_bytes[0] += p->TL->bytes[TAB_INV];
+  p->table_bytes[1] += p->TL->bytes[TAB_INV_ADJ];
+  if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd))) return rc;
+  if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj))) return rc;
+  if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv))) return rc;
+  if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj))) return rc;
+  v.clear();
+  append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, v);
+  if ((rc = upload_tasks(v, true, &p->syn_inv))) return rc;
+  v.clear();
+  append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, v);
+  if ((rc = upload_tasks(v, true, &p->adj_invadj))) return rc;
+  v.clear();
+  append_gemm_tasks(*p->TL, TAB_FWD, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, v);
+  if ((rc = upload_tasks(v, true, &p->ana_fwd))) return rc;
+  v.clear();
+  append_gemm_tasks(*p->TL, TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, v);
+  if ((rc = upload_tasks(v, true, &p->anadj_fwdadj))) return rc;
+  // combine descriptors
+  CombineArgs c;
+  c.nsc = p->nsc;
+  c.L = L;
+  c.Rp = p->Rp;
+  c.ncol = p->ncol;
+  for (int s = 0; s < p->nsc; ++s) {
+    c.bl[s] = p->bl[s];
+    c.Rp_i[s] = round_up(p->bl[s], 16);
+    c.offH[s] = p->offH[s];
+  }
+  c.kc = p->d_kc_syn;
+  p->comb_syn = c;
+  c.kc = p->d_kc_ana;
+  p->comb_ana = c;
+  *plan = p;
+  return 0;
+}
+
+int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
+  if (!p) return 0;
+  for (auto& d : p->dft) free_dft_plan(&d);
+  free_dft_plan(&p->dftL);
+  if (p->ws) (void)hipFree(p->ws);
+  if (p->d_kc_syn) (void)hipFree(p->d_kc_syn);
+  if (p->d_kc_ana) (void)hipFree(p->d_kc_ana);
+  TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj,
+                     &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj};
+  for (TaskList* t : tls)
+    if (t->d) (void)hipFree(t->d);
+  delete p;
+  return 0;
+}
+
+static int wav_check(pxm_wav_plan_t p, const void* a, const void* b, int C, const char* who) {
+  if (!p || !a || !b) {
+    set_error(std::string(who) + ": null argument");
+    return -1;
+  }
+  if (C < 1 || C > p->Cmax) {
+    set_error(std::string(who) + ": C outside [1, max_chains]");
+    return -1;
+  }
+  return 0;
+}
+
+static int launch_combine(const CombineArgs& c, const double* ws, double* HL, hipStream_t st) {
+  const int64_t total = (int64_t)(2 * c.L - 1) * c.Rp * c.ncol;
+  int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(k_wav_combine, dim3(blocks), dim3(256), 0, st, c, ws, HL);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+// coefficient blocks -> G_s (scales' px2ring) ; G_s -> coefficient blocks (ring2px with optional fused update)
+static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st) {
+  for (int s = 0; s < p->nsc; ++s) {
+    PxIn in;
+    in.f = (const double*)X;
+    in.chain_stride = p->ncoefs;
+    in.ring0 = p->coef_off[s];
+    int rc = launch_px2ring(p->dft[s], in, p->ws + p->offG[s], p->ncol, C, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
+  for (int s = 0; s < p->nsc; ++s) {
+    PxOut out = proto;
+    out.chain_stride = p->ncoefs;
+    out.ring0 = p->coef_off[s];
+    int rc = launch_ring2px(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, st);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+int pxm_wav_synthesis(pxm_wav_plan_t p, const void* X, void* f, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, X, f, C, "pxm_wav_synthesis");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
+  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
+  if ((rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, st))) return rc;
+  PxOut out;
+  out.f = (double*)f;
+  out.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  return launch_ring2px(p->dftL, p->ws + p->offGL, p->ncol, out, C, st);
+}
+
+static int wav_synthesis_adjoint_impl(pxm_wav_plan_t p, const PxIn& in, const PxOut& out, int C, hipStream_t st) {
+  int rc;
+  if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offGL, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->adj_invadj, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, st))) return rc;
+  return wav_rings_to_blocks(p, out, C, st);
+}
+
+int pxm_wav_synthesis_adjoint(pxm_wav_plan_t p, const void* f, void* X, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, f, X, C, "pxm_wav_synthesis_adjoint");
+  if (rc) return rc;
+  PxIn in;
+  in.f = (const double*)f;
+  in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  PxOut out;
+  out.f = (double*)X;
+  return wav_synthesis_adjoint_impl(p, in, out, C, (hipStream_t)stream);
+}
+
+int pxm_wav_gradg_step(pxm_wav_plan_t p, const void* X, const void* preds, const void* data, const void* invcov,
+                       int invcov_complex, const double* T, double T_scalar, double delta, double lmda,
+                       const void* noise, int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter,
+                       void* X_out, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, X, X_out, C, "pxm_wav_gradg_step");
+  if (rc) return rc;
+  PXM_REQUIRE(preds && data && invcov, "pxm_wav_gradg_step: null argument");
+  PXM_REQUIRE(X != X_out, "pxm_wav_gradg_step: X_out must not alias X");
+  PxIn in;
+  in.f = (const double*)preds;
+  in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  in.data = (const double*)data;
+  in.invcov = (const double*)invcov;
+  in.invcov_complex = invcov_complex;
+  PxOut out;
+  out.f = (double*)X_out;
+  out.X = (const double*)X;
+  out.T = T;
+  out.T_scalar = T_scalar;
+  out.delta = delta;
+  out.lmda = lmda;
+  out.noise = (const double*)noise;
+  out.noise_complex = noise_complex;
+  out.seed = seed;
+  out.chain0 = chain0;
+  out.iter = iter;
+  return wav_synthesis_adjoint_impl(p, in, out, C, (hipStream_t)stream);
+}
+
+int pxm_wav_analysis(pxm_wav_plan_t p, const void* f, void* X, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, f, X, C, "pxm_wav_analysis");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  PxIn in;
+  in.f = (const double*)f;
+  in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offGL, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->ana_fwd, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = run_tasks(p->ana_inv, p->ws, p->ws, p->ncol, st))) return rc;
+  PxOut out;
+  out.f = (double*)X;
+  return wav_rings_to_blocks(p, out, C, st);
+}
+
+int pxm_wav_analysis_adjoint(pxm_wav_plan_t p, const void* X, void* f, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, X, f, C, "pxm_wav_analysis_adjoint");
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
+  if ((rc = run_tasks(p->anadj_invadj, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = launch_combine(p->comb_ana, p->ws, p->ws + p->offHL, st))) return rc;
+  if ((rc = run_tasks(p->anadj_fwdadj, p->ws, p->ws, p->ncol, st))) return rc;
+  PxOut out;
+  out.f = (double*)f;
+  out.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  return launch_ring2px(p->dftL, p->ws + p->offGL, p->ncol, out, C, st);
+}
+
+int64_t pxm_wav_table_bytes(pxm_wav_plan_t p, int op) {
+  if (!p || op < 0 || op > 1) return -1;
+  return p->table_bytes[op];
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// Internal C++ interface of the SHT engine: ring tables, GEMM stage, DFT stage.
+//
+// Formulation.  Every MW transform is a phi-DFT stage and a
+// per-m "Legendre" stage that contracts a REAL table with complex data:
+//   inverse         : H[m][el] --(B^m  : ring<-el)--> G[m][t] --iDFT--> f(t,p)
+//   forward_adjoint : H[m][el] --(A^mT : ring<-el)--> G[m][t] --iDFT--> f(t,p)
+//   forward         : f(t,p) --DFT--> G[m][t] --(A^m  : el<-ring)--> H[m][el]
+//   inverse_adjoint : f(t,p) --DFT--> G[m][t] --(B^mT : el<-ring)--> H[m][el]
+// with B^m[t][el] = (-1)^s sqrt((2el+1)/4pi) d^el_{m,-s}(theta_t) and
+// A^m = (2pi/(2L-1)) B^mT Q^{parity(m+s)} the exact MW quadrature.  The chain batch
+// turns each per-m contraction into a real GEMM with 2*C columns (re/im of every
+// chain), run on v_mfma_f64_16x16x4_f64 with the table streamed from HBM exactly once.
+//
+// Internal layouts (row = ring t or degree el, padded to Rp = roundup(L,16)):
+//   G, H : [m_idx = m + L - 1][row][ncol]   ncol = 2*Cp doubles, Cp = roundup(C, 8)
+#pragma once
+#include "common.h"
+
+namespace pxm {
+
+enum TableKind { TAB_INV = 0, TAB_FWD = 1, TAB_INV_ADJ = 2, TAB_FWD_ADJ = 3 };
+inline bool kind_el_to_ring(int kind) { return kind == TAB_INV || kind == TAB_FWD_ADJ; }
+
+// One workgroup's share of a per-m GEMM: up to 4 row tiles of 16 output rows.
+struct GemmTask {
+  const double* tab;   // tiled table of this (m, first row tile): [rt][kk2][lane][2]
+  int64_t rt_stride;   // doubles between consecutive row tiles
+  int64_t x_off[2];    // operand slab offsets (doubles) for +m / -m
+  int64_t y_off[2];    // output slab offsets
+  const double* kscale;  // optional per-k scale (indexed by absolute k), or null
+  int k_beg, k_end;    // contraction range, multiples of 8
+  int row0;            // first output row of this task
+  int n_rt;            // row tiles in this task (1..4)
+  double sign1;        // factor on the -m output ((-1)^m)
+};
+
+struct ShtTables {
+  int L = 0, spin = 0, Rp = 0;
+  bool paired = false;           // spin 0: only m >= 0 stored, -m served with sign (-1)^m
+  int n_m = 0;                   // stored m count
+  double* d_tab[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t bytes[4] = {0, 0, 0, 0};
+  std::vector<int64_t> m_off[4];  // per stored-m offset (doubles) into d_tab[kind]
+  std::vector<int> k_beg[4];      // per stored-m contraction start (el->ring kinds) / first row tile*16 (ring->el)
+  int m_of(int i) const { return paired ? i : i - (L - 1); }
+};
+
+// builds (or returns cached) tables for (L, spin); kinds_mask selects which of the 4 to build
+int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out);
+
+// Append the tasks of one transform's GEMM stage.  x_base / y_base are offsets (doubles) of the
+// [2L-1][Rp][ncol] operand / output arrays inside the workspace; x rows may belong to a larger
+// array (x_Rp, x_L give the operand array's row padding and bandlimit for the m_idx mapping).
+void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, int x_L, int x_Rp,
+                       int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
+                       std::vector<GemmTask>& tasks);
+
+// launch: tasks on device; X/Y = workspace base; col0 = first column of this chain group, ct = column
+// tiles (1 or 2) of the group
+int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double* X, double* Y, int ncol,
+                int col0, int ct, hipStream_t stream);
+
+// ---- DFT stage ---------------------------------------------------------------
+struct DftPlan {
+  int L = 0, n = 0, M = 0, logM = 0, Rp = 0;
+  int R = 0;        // chains per workgroup
+  int threads = 0;  // workgroup size
+  size_t lds = 0;
+  double *d_chirp = nullptr, *d_bhat = nullptr, *d_tw = nullptr;
+};
+int make_dft_plan(int L, DftPlan* p);
+void free_dft_plan(DftPlan* p);
+
+// Input / output functors fused into the DFT stage's global reads / writes.
+struct PxIn {  // px2ring input: plain image, or residual invcov .* (preds - data)
+  const double* f = nullptr;   // [C][chain_stride] complex (image or preds)
+  int64_t chain_stride = 0;    // in complex elements
+  int64_t ring0 = 0;           // offset of ring 0 inside a chain (complex elements)
+  const double* data = nullptr;    // [P] complex, shared (residual mode when non-null)
+  const double* invcov = nullptr;  // [P] real or complex
+  int invcov_complex = 0;
+};
+struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a coefficient block
+  double* f = nullptr;
+  int64_t chain_stride = 0;
+  int64_t ring0 = 0;
+  // MYULA mode when X != null: f = (1-d/l) X + (d/l) soft(X,T) - d * value + sqrt(2d) w
+  const double* X = nullptr;
+  const double* T = nullptr;  // [N] thresholds (offset by ring0 like X) or null -> T_scalar
+  double T_scalar = 0, delta = 0, lmda = 0;
+  const double* noise = nullptr;  // injected noise or null -> Philox
+  int noise_complex = 0;
+  uint64_t seed = 0, chain0 = 0, iter = 0;
+};
+
+// f(t,p) -> G[m][t][c]  (unnormalised, e^{-i m phi});  G -> f (e^{+i m phi})
+int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream);
+int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t stream);
+
+// ---- layout repack (public harmonic layout el^2+el+m <-> internal [m][el][c]) ----------
+int launch_lm_to_mel(const double* flm, double* H, int L, int Rp, int ncol, int C, int spin, hipStream_t stream);
+int launch_mel_to_lm(const double* H, double* flm, int L, int Rp, int ncol, int C, int spin, hipStream_t stream);
+
+}  // namespace pxm

@@ -1,0 +1,355 @@
+"""
+Thin tensor-level wrappers over the C-ABI: torch supplies device memory and the stream,
+every operation is a hand-written HIP kernel behind ``include/pxmcmc_amd.h``.
+
+Conventions: arrays are ``[C, n]`` (chain batch first) or ``[n]`` (one chain); dtype is
+float64 or complex128; outputs are fresh tensors (the reference never mutates inputs,
+SURVEY.md section 8b).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import check, lib, require_gpu
+
+_CPLX, _REAL = torch.complex128, torch.float64
+
+
+def device():
+    require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def as_device(x, dtype=None):
+    """numpy / torch / sequence -> contiguous tensor on the GPU (float64 or complex128)."""
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if dtype is None:
+        dtype = _CPLX if t.is_complex() else _REAL
+    return t.to(device=device(), dtype=dtype).contiguous()
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _batched(x):
+    """[n] -> ([1, n], True); [C, n] -> (x, False)."""
+    if x.dim() == 1:
+        return x.unsqueeze(0), True
+    if x.dim() != 2:
+        raise ValueError("expected a 1-D (single chain) or 2-D (chain batch) array")
+    return x, False
+
+
+def _dt(x):
+    if x.dtype == _CPLX:
+        return 1
+    if x.dtype == _REAL:
+        return 0
+    raise TypeError(f"unsupported dtype {x.dtype}: float64 or complex128 only")
+
+
+def _vecT(T, n, dev):
+    """threshold / weight argument: python scalar -> (null, value); vector -> (tensor, 0)."""
+    if T is None:
+        return None, 0.0
+    if isinstance(T, (int, float)):
+        return None, float(T)
+    t = as_device(T, _REAL)
+    if t.numel() == 1:
+        return None, float(t.item())
+    if t.numel() != n:
+        raise ValueError("threshold / weight vector has the wrong length")
+    return t.reshape(-1), 0.0
+
+
+# ---- elementwise -----------------------------------------------------------------------
+def soft(X, T=0.1):
+    """utils.soft (pxmcmc/utils.py:55-67)."""
+    x, squeeze = _batched(as_device(X))
+    Tv, Ts = _vecT(T, x.shape[1], x.device)
+    out = torch.empty_like(x)
+    check(lib.pxm_soft(_p(x), _p(Tv), Ts, _p(out), x.shape[1], x.shape[0], _dt(x), _stream()))
+    return out[0] if squeeze else out
+
+
+def residual_grad(preds, data, invcov):
+    """invcov .* (preds - data), invcov diagonal (pxmcmc/forward.py:66-69)."""
+    p, squeeze = _batched(as_device(preds))
+    n = p.shape[1]
+    d = as_device(data, p.dtype).reshape(-1)
+    ic = as_device(invcov)
+    if ic.is_complex() and not p.is_complex():
+        raise TypeError("complex inverse covariance needs complex predictions")
+    ic = ic.reshape(-1)
+    if d.numel() != n or ic.numel() != n:
+        raise ValueError("data / invcov length mismatch")
+    out = torch.empty_like(p)
+    check(lib.pxm_residual_grad(_p(p), _p(d), _p(ic), int(ic.is_complex()), _p(out), n, p.shape[0], _dt(p), _stream()))
+    return out[0] if squeeze else out
+
+
+def _delta_args(delta, C_, dev):
+    if isinstance(delta, torch.Tensor):
+        dd = delta.to(device=dev, dtype=_REAL).contiguous()
+        if dd.numel() != C_:
+            raise ValueError("per-chain delta must have one entry per chain")
+        return dd, 0.0
+    return None, float(delta)
+
+
+def _noise_args(noise, x, noise_complex):
+    if noise is None:
+        return None, int(bool(noise_complex))
+    w = as_device(noise)
+    if w.dim() == 1:
+        w = w.unsqueeze(0)
+    if w.shape != x.shape:
+        raise ValueError("injected noise must have the state's shape")
+    if w.is_complex() and not x.is_complex():
+        raise TypeError("complex noise needs a complex state")
+    return w, int(w.is_complex())
+
+
+def myula_step(X, gradg, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0):
+    """chain_step(X, soft(X, T), gradg) in one pass (pxmcmc/mcmc.py:185-201 + prior.py:49-50)."""
+    x, squeeze = _batched(as_device(X))
+    g, _ = _batched(as_device(gradg, x.dtype))
+    if g.shape != x.shape:
+        raise ValueError("gradg shape mismatch")
+    Tv, Ts = _vecT(T, x.shape[1], x.device)
+    dd, ds = _delta_args(delta, x.shape[0], x.device)
+    w, wc = _noise_args(noise, x, noise_complex)
+    out = torch.empty_like(x)
+    check(
+        lib.pxm_myula_step(
+            _p(x), _p(g), _p(Tv), Ts, _p(dd), ds, float(lmda), _p(w), wc, seed, chain0, it, _p(out), x.shape[1], x.shape[0], _dt(x), _stream()
+        )
+    )
+    return out[0] if squeeze else out
+
+
+def chain_step(X, proxf, gradg, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0):
+    """MYULA.chain_step (pxmcmc/mcmc.py:185-201)."""
+    x, squeeze = _batched(as_device(X))
+    px, _ = _batched(as_device(proxf, x.dtype))
+    g, _ = _batched(as_device(gradg, x.dtype))
+    if g.shape != x.shape or px.shape != x.shape:
+        raise ValueError("shape mismatch")
+    dd, ds = _delta_args(delta, x.shape[0], x.device)
+    w, wc = _noise_args(noise, x, noise_complex)
+    out = torch.empty_like(x)
+    check(
+        lib.pxm_chain_step(
+            _p(x), _p(px), _p(g), _p(dd), ds, float(lmda), _p(w), wc, seed, chain0, it, _p(out), x.shape[1], x.shape[0], _dt(x), _stream()
+        )
+    )
+    return out[0] if squeeze else out
+
+
+def randn(n, C_=1, complex_=False, seed=0, chain0=0, it=0):
+    out = torch.empty((C_, n), dtype=_CPLX if complex_ else _REAL, device=device())
+    check(lib.pxm_randn(_p(out), n, C_, int(complex_), seed, chain0, it, _stream()))
+    return out
+
+
+def reduce_l1(X, w=None):
+    """sum |w X| per chain (pxmcmc/prior.py:28-35,83-84) -> float64 [C]."""
+    x, _ = _batched(as_device(X))
+    wv = None if w is None else as_device(w, _REAL).reshape(-1)
+    if wv is not None and wv.numel() != x.shape[1]:
+        raise ValueError("weight length mismatch")
+    out = torch.empty(x.shape[0], dtype=_REAL, device=x.device)
+    check(lib.pxm_reduce_l1(_p(x), _p(wv), _p(out), x.shape[1], x.shape[0], _dt(x), _stream()))
+    return out
+
+
+def reduce_l2(preds, data, invcov):
+    """vdot(d, invcov d), d = data - preds (pxmcmc/mcmc.py:78-79) -> complex128 [C]."""
+    p, _ = _batched(as_device(preds))
+    n = p.shape[1]
+    d = as_device(data, p.dtype).reshape(-1)
+    ic = as_device(invcov).reshape(-1)
+    if ic.is_complex() and not p.is_complex():
+        raise TypeError("complex inverse covariance needs complex predictions")
+    if d.numel() != n or ic.numel() != n:
+        raise ValueError("data / invcov length mismatch")
+    out = torch.empty(p.shape[0], dtype=_CPLX, device=p.device)
+    check(lib.pxm_reduce_l2(_p(p), _p(d), _p(ic), int(ic.is_complex()), _p(out), n, p.shape[0], _dt(p), _stream()))
+    return out
+
+
+def logtransition(X1, X2, proxf, gradg, delta, lmda):
+    """PxMALA.calc_logtransition, literal (pxmcmc/mcmc.py:281-289) -> complex128 [C]."""
+    x1, _ = _batched(as_device(X1))
+    x2, _ = _batched(as_device(X2, x1.dtype))
+    px, _ = _batched(as_device(proxf, x1.dtype))
+    g, _ = _batched(as_device(gradg, x1.dtype))
+    dd, ds = _delta_args(delta, x1.shape[0], x1.device)
+    out = torch.empty(x1.shape[0], dtype=_CPLX, device=x1.device)
+    check(lib.pxm_logtransition(_p(x1), _p(x2), _p(px), _p(g), _p(dd), ds, float(lmda), _p(out), x1.shape[1], x1.shape[0], _dt(x1), _stream()))
+    return out
+
+
+def pxmala_accept(terms, delta_dev, tune, lmda, it_index, u=None, seed=0, chain0=0, it=0):
+    """Metropolis test + delta adaptation per chain (pxmcmc/mcmc.py:244-260,277-279)."""
+    t = as_device(terms, _REAL)
+    C_ = t.shape[0]
+    uu = None if u is None else as_device(u, _REAL).reshape(-1)
+    acc = torch.empty(C_, dtype=torch.int32, device=t.device)
+    check(lib.pxm_pxmala_accept(_p(t), _p(uu), seed, chain0, it, _p(acc), _p(delta_dev), int(bool(tune)), float(lmda), int(it_index), C_, _stream()))
+    return acc
+
+
+def select_copy(flag, src, dst):
+    """dst[c] = src[c] for chains with flag[c] != 0 (in place on dst)."""
+    s, _ = _batched(src)
+    d, _ = _batched(dst)
+    if s.shape != d.shape or s.dtype != d.dtype:
+        raise ValueError("select_copy: shape / dtype mismatch")
+    check(lib.pxm_select_copy(_p(flag), _p(s), _p(d), s.shape[1], s.element_size(), s.shape[0], _stream()))
+    return dst
+
+
+# ---- transform plans -------------------------------------------------------------------
+class ShtPlan:
+    """MW spin spherical-harmonic transforms at bandlimit L (replaces the pyssht calls)."""
+
+    def __init__(self, L, spin=0, max_chains=1):
+        require_gpu()
+        self.L, self.spin, self.max_chains = int(L), int(spin), int(max_chains)
+        self.npix, self.nlm = L * (2 * L - 1), L * L
+        h = C.c_void_p()
+        check(lib.pxm_sht_plan_create(self.L, self.spin, self.max_chains, 0, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.pxm_sht_plan_destroy(h)
+            self._h = None
+
+    def _run(self, fn, x, n_in, n_out):
+        x, squeeze = _batched(as_device(x, _CPLX))
+        if x.shape[1] != n_in:
+            raise AssertionError(f"expected length {n_in}, got {x.shape[1]}")
+        if x.shape[0] > self.max_chains:
+            raise ValueError("more chains than the plan was created for")
+        out = torch.empty((x.shape[0], n_out), dtype=_CPLX, device=x.device)
+        check(fn(self._h, _p(x), _p(out), x.shape[0], _stream()))
+        return out[0] if squeeze else out
+
+    def inverse(self, flm):
+        return self._run(lib.pxm_sht_inverse, flm, self.nlm, self.npix)
+
+    def forward(self, f):
+        return self._run(lib.pxm_sht_forward, f, self.npix, self.nlm)
+
+    def inverse_adjoint(self, f):
+        return self._run(lib.pxm_sht_inverse_adjoint, f, self.npix, self.nlm)
+
+    def forward_adjoint(self, flm):
+        return self._run(lib.pxm_sht_forward_adjoint, flm, self.nlm, self.npix)
+
+    def table_bytes(self, op):
+        return int(lib.pxm_sht_table_bytes(self._h, op))
+
+
+class WavPlan:
+    """Axisymmetric scale-discretised wavelet transforms (replaces the pys2let calls)."""
+
+    def __init__(self, L, B, J_min, max_chains=1):
+        require_gpu()
+        self.L, self.B, self.J_min, self.max_chains = int(L), float(B), int(J_min), int(max_chains)
+        self.npix = L * (2 * L - 1)
+        nscal = C.c_int64()
+        self.ncoefs = int(check(lib.pxm_wav_ncoefs(self.L, self.B, self.J_min, C.byref(nscal))))
+        self.nscal = int(nscal.value)
+        h = C.c_void_p()
+        check(lib.pxm_wav_plan_create(self.L, self.B, self.J_min, self.max_chains, 0, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.pxm_wav_plan_destroy(h)
+            self._h = None
+
+    def _run(self, fn, x, n_in, n_out):
+        x, squeeze = _batched(as_device(x, _CPLX))
+        if x.shape[1] != n_in:
+            raise AssertionError(f"expected length {n_in}, got {x.shape[1]}")
+        if x.shape[0] > self.max_chains:
+            raise ValueError("more chains than the plan was created for")
+        out = torch.empty((x.shape[0], n_out), dtype=_CPLX, device=x.device)
+        check(fn(self._h, _p(x), _p(out), x.shape[0], _stream()))
+        return out[0] if squeeze else out
+
+    def synthesis(self, X):
+        return self._run(lib.pxm_wav_synthesis, X, self.ncoefs, self.npix)
+
+    def synthesis_adjoint(self, f):
+        return self._run(lib.pxm_wav_synthesis_adjoint, f, self.npix, self.ncoefs)
+
+    def analysis(self, f):
+        return self._run(lib.pxm_wav_analysis, f, self.npix, self.ncoefs)
+
+    def analysis_adjoint(self, X):
+        return self._run(lib.pxm_wav_analysis_adjoint, X, self.ncoefs, self.npix)
+
+    def gradg_step(self, X, preds, data, invcov, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0):
+        """Fused calc_gradg + proxf + chain_step (pxmcmc/mcmc.py:158-160) for the synthesis setting."""
+        x, squeeze = _batched(as_device(X, _CPLX))
+        p, _ = _batched(as_device(preds, _CPLX))
+        if x.shape[1] != self.ncoefs or p.shape[1] != self.npix or p.shape[0] != x.shape[0]:
+            raise AssertionError("gradg_step: shape mismatch")
+        d = as_device(data, _CPLX).reshape(-1)
+        ic = as_device(invcov).reshape(-1)
+        if d.numel() != self.npix or ic.numel() != self.npix:
+            raise ValueError("data / invcov length mismatch")
+        Tv, Ts = _vecT(T, self.ncoefs, x.device)
+        w, wc = _noise_args(noise, x, noise_complex)
+        out = torch.empty_like(x)
+        check(
+            lib.pxm_wav_gradg_step(
+                self._h, _p(x), _p(p), _p(d), _p(ic), int(ic.is_complex()), _p(Tv), Ts, float(delta), float(lmda),
+                _p(w), wc, seed, chain0, it, _p(out), x.shape[0], _stream(),
+            )
+        )
+        return out[0] if squeeze else out
+
+    def table_bytes(self, op):
+        return int(lib.pxm_wav_table_bytes(self._h, op))
+
+
+# ---- host helpers ------------------------------------------------------------------------
+def j_max(L, B):
+    return int(check(lib.pxm_j_max(int(L), float(B))))
+
+
+def wav_bandlimits(L, B, J_min):
+    buf = (C.c_int * 64)()
+    n = check(lib.pxm_wav_bandlimits(int(L), float(B), int(J_min), buf, 64))
+    return [int(buf[i]) for i in range(n)]
+
+
+def tiling_axisym(L, B, J_min):
+    J = j_max(L, B)
+    k0 = np.zeros(L)
+    k = np.zeros((J + 1, L))
+    check(lib.pxm_tiling_axisym(int(L), float(B), int(J_min), k0.ctypes.data, k.ctypes.data))
+    return k0, k
+
+
+def mw_ring_weights(L):
+    q = np.zeros(L)
+    check(lib.pxm_mw_ring_weights(int(L), q.ctypes.data))
+    return q
