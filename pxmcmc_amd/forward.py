@@ -1,0 +1,134 @@
+"""
+ForwardOperator plugin API of the reference (pxmcmc/forward.py:9-123) on the GPU.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .measurements import Identity
+from .transforms import SphericalWaveletTransform
+from .utils import mw_size, to_like
+
+
+class InverseCovariance:
+    """
+    Diagonal inverse covariance held on the GPU.  Supports ``invcov @ vec`` (the only way the
+    reference's sampler touches it, pxmcmc/mcmc.py:79) and ``.diagonal()``.
+    """
+
+    def __init__(self, diag):
+        self.diag = diag  # float64 or complex128 tensor [ndata]
+
+    def diagonal(self):
+        return self.diag.cpu().numpy()
+
+    def __matmul__(self, v):
+        if isinstance(v, torch.Tensor):
+            return self.diag * v
+        return self.diag.cpu().numpy() * np.asarray(v)
+
+    dot = __matmul__
+
+
+class ForwardOperator:
+    """
+    Base forward operator = Transform o Measurement + Gaussian inverse covariance
+    (pxmcmc/forward.py:9-88).
+
+    :param data: observed data vector
+    :param sig_d: observed data error: float or vector (a full covariance matrix is not supported)
+    :param string setting: ``analysis`` or ``synthesis``
+    """
+
+    def __init__(self, data, sig_d, setting, transform=None, measurement=None, nparams=None):
+        self.data = data
+        self.invcov = self._build_inverse_covariance_matrix(sig_d)
+        if setting not in ["analysis", "synthesis"]:
+            raise ValueError
+        self.setting = setting
+        if transform is not None:
+            self.transform = transform
+        if measurement is not None:
+            self.measurement = measurement
+        if nparams is not None:
+            self.nparams = nparams
+        self._data_dev = None
+
+    # ---- device views --------------------------------------------------------------
+    @property
+    def data_dev(self):
+        if self._data_dev is None:
+            self._data_dev = ops.as_device(self.data).reshape(-1)
+        return self._data_dev
+
+    def _resid_dtype(self, preds):
+        return torch.complex128 if (preds.is_complex() or self.data_dev.is_complex() or self.invcov.diag.is_complex()) else torch.float64
+
+    # ---- reference API ---------------------------------------------------------------
+    def forward(self, X):
+        """pxmcmc/forward.py:36-46."""
+        if self.setting == "analysis":
+            return self._forward_analysis(X)
+        return self._forward_synthesis(X)
+
+    def calc_gradg(self, preds):
+        """pxmcmc/forward.py:48-58: gradient of the Gaussian data fidelity."""
+        if self.setting == "analysis":
+            return self._gradg_analysis(preds)
+        return self._gradg_synthesis(preds)
+
+    def _forward_analysis(self, X):
+        return self.measurement.forward(X)
+
+    def _forward_synthesis(self, X):
+        return self.measurement.forward(self.transform.inverse(X))
+
+    def _residual(self, preds):
+        """invcov @ (preds - data) on the GPU (the dense->CSR round trip of forward.py:68 is not reproduced)."""
+        p = ops.as_device(preds)
+        dt = self._resid_dtype(p)
+        return ops.residual_grad(p.to(dt), self.data_dev.to(dt), self.invcov.diag)
+
+    def _gradg_analysis(self, preds):
+        return to_like(ops.as_device(self.measurement.adjoint(self._residual(preds))), preds)
+
+    def _gradg_synthesis(self, preds):
+        g = self.transform.inverse_adjoint(self.measurement.adjoint(self._residual(preds)))
+        return to_like(ops.as_device(g), preds)
+
+    def _build_inverse_covariance_matrix(self, sig_d):
+        """pxmcmc/forward.py:74-88, including the complex-variance rule of :81-82."""
+        if isinstance(sig_d, (np.ndarray, torch.Tensor)) and len(sig_d.shape) == 2:
+            if sig_d.shape[0] != sig_d.shape[1]:
+                raise ValueError("Covariance matrix should be square")
+            raise NotImplementedError("full covariance matrices are outside the hot path; pass a scalar or vector sig_d")
+        data = self.data
+        data_is_complex = data.is_complex() if isinstance(data, torch.Tensor) else np.iscomplexobj(data)
+        if isinstance(sig_d, torch.Tensor):
+            sig_d = sig_d.cpu().numpy()
+        var = sig_d ** 2
+        if data_is_complex and not np.iscomplexobj(var):
+            var = var / np.sqrt(2) * (1 + 1j)
+        ndata = len(data)
+        if isinstance(var, (float, int, complex)):
+            diag = np.full(ndata, 1 / var)
+        elif hasattr(var, "size") and var.size == ndata and len(var.shape) == 1:
+            diag = 1 / var
+        elif hasattr(var, "ndim") and var.ndim == 0:
+            diag = np.full(ndata, 1 / var[()])
+        else:
+            raise TypeError("sig_d must be a float scalar, vector or 2D matrix")
+        return InverseCovariance(ops.as_device(diag))
+
+
+class SphericalWaveletTransformOperator(ForwardOperator):
+    """Spherical wavelet transform + identity measurement (pxmcmc/forward.py:91-123)."""
+
+    def __init__(self, data, sig_d, setting, L, B, J_min, dirs=1, spin=0, max_chains=1):
+        transform = SphericalWaveletTransform(L, B, J_min, dirs=dirs, spin=spin, max_chains=max_chains)
+        measurement = Identity(len(data), mw_size(L))
+        if setting == "analysis":
+            nparams = mw_size(L)
+        else:
+            nparams = transform.ncoefs
+        super().__init__(data, sig_d, setting, transform=transform, measurement=measurement, nparams=nparams)

@@ -1,0 +1,417 @@
+"""
+Samplers of the reference (pxmcmc/mcmc.py:6-289: PxMCMCParams, PxMCMC, MYULA, PxMALA) driving
+the HIP kernels.  The plugin protocol is the reference's: the sampler only touches
+``forward.forward / calc_gradg / data / invcov / nparams`` and ``prior.proxf / prior.prior``.
+
+Extensions (all optional, defaults reproduce the reference's one-chain behaviour):
+
+* ``nchains``      -- C independent chains advanced together as one ``[C, N]`` batch;
+* ``rng``          -- ``"philox"`` (device counter-based stream keyed (seed, chain, iteration),
+  independent of how chains are spread over GPUs) or ``"numpy"`` (the reference's global
+  ``np.random`` stream in the reference's draw order, for parity runs);
+* ``chain_offset`` -- global index of this process's first chain (multi-GPU sharding).
+
+SKROCK (pxmcmc/mcmc.py:292-383) is out of scope.
+"""
+import numpy as np
+import torch
+from scipy.stats import laplace
+
+from . import ops
+from .measurements import Identity
+from .prior import L1
+from .transforms import SphericalWaveletTransform
+
+
+class PxMCMCParams:
+    """
+    Tuning and runtime parameters (pxmcmc/mcmc.py:6-43).
+
+    :param lmda: prox parameter
+    :param delta: Forward-Euler step size
+    :param mu: regularisation parameter
+    :param s: max order of Chebyshev polynomials (SKROCK; unused here)
+    :param nsamples: number of samples to save
+    :param nburn: burn-in size
+    :param ngap: thinning: iterations between saved samples
+    :param complex: ``True`` if the sampled parameters are complex
+    :param verbosity: print every ``verbosity`` iterations
+    :param track: list of variables to keep track of
+    """
+
+    def __init__(
+        self,
+        lmda=3e-5,
+        delta=1e-5,
+        s=1,
+        mu=1,
+        nsamples=int(1e6),
+        nburn=int(1e3),
+        ngap=int(1e2),
+        complex=False,
+        verbosity=100,
+        track=["logposterior", "L2", "prior", "chain"],
+    ):
+        self.lmda = lmda
+        self.delta = delta
+        self.mu = mu
+        self.s = s
+        self.nsamples = nsamples
+        self.nburn = nburn
+        self.ngap = ngap
+        self.complex = complex
+        self.verbosity = verbosity
+        self.track = track
+
+
+def _is_stock_l1(prior):
+    """True when prior.proxf is the library's own synthesis soft threshold (safe to fuse)."""
+    return isinstance(prior, L1) and type(prior).proxf is L1.proxf and type(prior)._proxf_synthesis is L1._proxf_synthesis and prior.setting == "synthesis"
+
+
+class PxMCMC:
+    """
+    Base class with the general functions (pxmcmc/mcmc.py:46-140).
+
+    :param forward: :class:`forward.ForwardOperator`-like object
+    :param prior: prior object implementing ``prior`` and ``proxf``
+    :param mcmcparams: :class:`PxMCMCParams`
+    """
+
+    def __init__(self, forward, prior, mcmcparams=PxMCMCParams(), nchains=1, rng="philox", seed=0, chain_offset=0):
+        self.forward = forward
+        self.prior = prior
+        for attr in mcmcparams.__dict__.keys():
+            setattr(self, attr, getattr(mcmcparams, attr))
+        if rng not in ("philox", "numpy"):
+            raise ValueError("rng must be 'philox' or 'numpy'")
+        self.nchains = int(nchains)
+        self.rng = rng
+        self.seed = int(seed)
+        self.chain_offset = int(chain_offset)
+        self.nsamples = int(self.nsamples)
+        for op in (getattr(forward, "transform", None), getattr(forward, "measurement", None)):
+            if hasattr(op, "ensure_chains"):
+                op.ensure_chains(self.nchains)
+        self._initialise_tracking_arrays()
+
+    def run(self, start_point=None):
+        raise NotImplementedError
+
+    # ---- device-side pieces -----------------------------------------------------------
+    def _state_dtype(self, start=None):
+        cplx = bool(self.complex) or isinstance(getattr(self.forward, "transform", None), SphericalWaveletTransform)
+        d = self.forward.data
+        cplx = cplx or (d.is_complex() if isinstance(d, torch.Tensor) else np.iscomplexobj(d))
+        if start is not None:
+            cplx = cplx or (start.is_complex() if isinstance(start, torch.Tensor) else np.iscomplexobj(start))
+        return torch.complex128 if cplx else torch.float64
+
+    def _logpi_dev(self, X, preds):
+        """per-chain (logPi, L2, prior) tensors; pxmcmc/mcmc.py:71-82 (L2 carries no factor 1/2)."""
+        p = ops.as_device(preds)
+        dt = self.forward._resid_dtype(p) if hasattr(self.forward, "_resid_dtype") else p.dtype
+        data = ops.as_device(self.forward.data).reshape(-1).to(dt)
+        invcov = self.forward.invcov.diag if hasattr(self.forward.invcov, "diag") else ops.as_device(self.forward.invcov.diagonal())
+        L2 = ops.reduce_l2(p.to(dt), data, invcov)
+        prior = self.prior.prior(X)
+        if not isinstance(prior, torch.Tensor):
+            prior = torch.as_tensor(np.atleast_1d(np.asarray(prior, dtype=float)), device=L2.device)
+        logPi = -self.mu * prior - L2
+        return logPi, L2, prior
+
+    def logpi(self, X, preds):
+        """log posterior, L2 norm and prior norm of a model (pxmcmc/mcmc.py:71-82)."""
+        logPi, L2, prior = self._logpi_dev(X, preds)
+        batched = (X.dim() if isinstance(X, torch.Tensor) else np.ndim(X)) == 2
+        if batched:
+            return logPi, L2, prior
+        cplx = L2.is_complex() and bool(abs(L2[0].imag.item()) > 0)
+        f = (lambda v: complex(v[0].item())) if cplx else (lambda v: float(v[0].real.item()))
+        return f(logPi), f(L2), float(prior[0].item())
+
+    def _print_progress(self, i, logpi, **kwargs):
+        print(
+            f"{i+1:,}/{self.nsamples:,} - logposterior: {logpi:.8e} - "
+            + " - ".join([f"{k}: {kwargs[k]:.8e}" for k in kwargs]),
+        )
+
+    def _initial_sample(self, initial_sample=None):
+        """pxmcmc/mcmc.py:97-111, returning GPU tensors [C, nparams], [C, ndata]."""
+        C, N = self.nchains, self.forward.nparams
+        if initial_sample is None:
+            if self.rng == "numpy":
+                draw = lambda: np.stack([laplace.rvs(size=N) for _ in range(C)])
+            else:
+                gens = [np.random.default_rng([self.seed, self.chain_offset + c, 0x1A91ACE]) for c in range(C)]
+                draw = lambda: np.stack([laplace.rvs(size=N, random_state=g) for g in gens])
+            X0 = draw()
+            if self.complex:
+                X0 = X0 + draw() * 1j
+        else:
+            if isinstance(initial_sample, torch.Tensor):
+                X0 = initial_sample
+            elif isinstance(initial_sample, np.ndarray):
+                X0 = initial_sample
+            else:
+                raise TypeError("Expected a 1D numpy array as an initial sample")
+            nd = X0.dim() if isinstance(X0, torch.Tensor) else np.ndim(X0)
+            if nd == 1:
+                if X0.shape[0] != N:
+                    raise ValueError("Inital sample given has incorrect size")
+                X0 = X0[None, :]
+                if C > 1:
+                    X0 = X0.repeat(C, 1) if isinstance(X0, torch.Tensor) else np.repeat(X0, C, axis=0)
+            elif nd == 2 and C > 1:
+                if tuple(X0.shape) != (C, N):
+                    raise ValueError("Inital sample given has incorrect size")
+            else:
+                raise TypeError("Expected a 1D numpy array as an initial sample")
+        X_curr = ops.as_device(X0, self._state_dtype(X0)).clone()  # never write into the caller's start point
+        curr_preds = ops.as_device(self.forward.forward(X_curr))
+        return X_curr, curr_preds
+
+    def _initialise_tracking_arrays(self):
+        """pxmcmc/mcmc.py:113-128; with nchains > 1 every array gains a leading chain axis."""
+        lead = () if self.nchains == 1 else (self.nchains,)
+        if "logposterior" in self.track:
+            self.logPi = np.zeros(lead + (self.nsamples,))
+        if "predictions" in self.track:
+            self.preds = np.zeros(lead + (self.nsamples, len(self.forward.data)), dtype=float)
+        if "chain" in self.track:
+            self.chain = np.zeros(lead + (self.nsamples, self.forward.nparams), dtype=complex if self.complex else float)
+        if "L2" in self.track:
+            self.L2s = np.zeros(lead + (self.nsamples,), dtype=float)
+        if "prior" in self.track:
+            self.priors = np.zeros(lead + (self.nsamples,), dtype=float)
+
+    def _tracking(self, j, X_curr, curr_preds, logPi, L2, prior, chains=None):
+        """pxmcmc/mcmc.py:130-140.  ``j`` is an int (all chains) or per-chain indices with ``chains``."""
+        def put(arr, val):
+            val = val.detach().cpu().numpy() if isinstance(val, torch.Tensor) else np.asarray(val)
+            if not np.iscomplexobj(arr):
+                val = np.real(val)  # the reference's float arrays silently drop the imaginary part
+            if self.nchains == 1:
+                arr[j] = val[0]
+            elif chains is None:
+                arr[:, j] = val
+            else:
+                for c, jc in zip(chains, j):
+                    arr[c, jc] = val[c]
+
+        if hasattr(self, "logPi"):
+            put(self.logPi, logPi)
+        if hasattr(self, "L2s"):
+            put(self.L2s, L2)
+        if hasattr(self, "priors"):
+            put(self.priors, prior)
+        if hasattr(self, "preds"):
+            put(self.preds, curr_preds)
+        if hasattr(self, "chain"):
+            put(self.chain, X_curr)
+
+    # ---- noise ---------------------------------------------------------------------------
+    def _host_noise(self, shape_like):
+        """the reference's draw order: randn(N) [+ 1j randn(N)] per chain (pxmcmc/mcmc.py:193-195)."""
+        C, N = shape_like.shape
+        w = np.stack([np.random.randn(N) + (np.random.randn(N) * 1j if self.complex else 0) for _ in range(C)])
+        return ops.as_device(w)
+
+
+class MYULA(PxMCMC):
+    """The MYULA chain (pxmcmc/mcmc.py:143-201)."""
+
+    def __init__(self, forward, prox, mcmcparams=PxMCMCParams(), **kwargs):
+        super().__init__(forward, prox, mcmcparams, **kwargs)
+
+    def _fusable_wavelet(self):
+        f = self.forward
+        return (
+            getattr(f, "setting", None) == "synthesis"
+            and type(f).calc_gradg.__qualname__.startswith("ForwardOperator")
+            and isinstance(getattr(f, "transform", None), SphericalWaveletTransform)
+            and isinstance(getattr(f, "measurement", None), Identity)
+            and f.measurement.ndata == f.measurement.npix
+            and _is_stock_l1(self.prior)
+            and type(self).chain_step is MYULA.chain_step
+        )
+
+    def _advance(self, X, preds, i, delta=None):
+        """one MYULA update X -> X_prop (pxmcmc/mcmc.py:158-160), fused where the operators allow"""
+        delta = self.delta if delta is None else delta
+        noise = self._host_noise(X) if self.rng == "numpy" else None
+        kw = dict(noise=noise, noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=i)
+        if self._fused_wav:
+            f = self.forward
+            return f.transform._plan.gradg_step(
+                X, preds, f.data_dev.to(torch.complex128), f.invcov.diag, self.prior.T_dev, delta, self.lmda, **kw
+            )
+        gradg = ops.as_device(self.forward.calc_gradg(preds), X.dtype)
+        if self._fused_prox:
+            return ops.myula_step(X, gradg, self.prior.T_dev, delta, self.lmda, **kw)
+        proxf = ops.as_device(self.prior.proxf(X), X.dtype)
+        if type(self).chain_step is not MYULA.chain_step:
+            return ops.as_device(self.chain_step(X, proxf, gradg), X.dtype)
+        return ops.chain_step(X, proxf, gradg, delta, self.lmda, **kw)
+
+    def _prepare(self):
+        self._fused_wav = self._fusable_wavelet() and isinstance(self.delta, float)
+        self._fused_prox = _is_stock_l1(self.prior) and type(self).chain_step is MYULA.chain_step
+        self._it = 0
+
+    def run(self, start_point=None):
+        """Run the algorithm (pxmcmc/mcmc.py:150-183)."""
+        self._prepare()
+        i = 0  # total samples
+        j = 0  # saved samples (excludes burn-in and thinned samples)
+        X_curr, curr_preds = self._initial_sample(start_point)
+        while j < self.nsamples:
+            X_prop = self._advance(X_curr, curr_preds, i)
+            prop_preds = ops.as_device(self.forward.forward(X_prop))
+
+            X_curr = X_prop
+            curr_preds = prop_preds
+
+            if i >= self.nburn:
+                if self.ngap == 0 or (i - self.nburn) % self.ngap == 0:
+                    logPi, L2, prior = self._logpi_dev(X_curr, curr_preds)
+                    self._tracking(j, X_curr, curr_preds, logPi, L2, prior)
+                    j += 1
+                if self.verbosity > 0 and (i + 1) % self.verbosity == 0:
+                    first = (lambda a: a[j - 1] if self.nchains == 1 else a[0, j - 1])
+                    self._print_progress(j - 1, first(self.logPi), L2=first(self.L2s), prior=first(self.priors))
+            else:
+                if self.verbosity > 0 and (i + 1) % self.verbosity == 0:
+                    print("Burning in...")
+            i += 1
+        self.X_curr, self.curr_preds, self.niter = X_curr, curr_preds, i
+        print("\nDONE")
+
+    def chain_step(self, X, proxf, gradg):
+        """
+        Takes a step in the chain (pxmcmc/mcmc.py:185-201):
+        ``(1 - delta/lmda) X + (delta/lmda) proxf - delta gradg + sqrt(2 delta) w``.
+        """
+        x = ops.as_device(X)
+        if self.rng == "numpy":
+            noise = self._host_noise(x if x.dim() == 2 else x[None])
+        else:
+            noise = None
+            self._it = getattr(self, "_it", 0) + 1
+        out = ops.chain_step(
+            x, proxf, gradg, self.delta, self.lmda, noise=noise, noise_complex=bool(self.complex),
+            seed=self.seed, chain0=self.chain_offset, it=getattr(self, "_it", 0),
+        )
+        return out if isinstance(X, torch.Tensor) else out.cpu().numpy()
+
+
+class PxMALA(MYULA):
+    """
+    PxMALA = MYULA proposal + Metropolis-Hastings acceptance (pxmcmc/mcmc.py:204-289).
+
+    :param bool tune_delta: tune ``delta`` towards an acceptance probability of 0.5
+    """
+
+    _CHUNK = 1024
+
+    def __init__(self, forward, prox, mcmcparams=PxMCMCParams(), tune_delta=True, **kwargs):
+        super().__init__(forward, prox, mcmcparams, **kwargs)
+        self.tune_delta = tune_delta
+
+    def run(self, start_point=None):
+        """Run the algorithm (pxmcmc/mcmc.py:218-275); every chain carries its own delta and accept flag."""
+        self._prepare()
+        self._fused_wav = False  # PxMALA needs gradg and proxf of the proposal separately
+        C = self.nchains
+        dev = ops.device()
+        acc_chunks, delta_chunks = [], []
+        acc_buf = torch.zeros((self._CHUNK, C), dtype=torch.int32, device=dev)
+        delta_buf = torch.zeros((self._CHUNK, C), dtype=torch.float64, device=dev)
+        delta_dev = torch.full((C,), float(self.delta), dtype=torch.float64, device=dev)
+        delta0 = float(self.delta)
+        i = 0
+        j = np.zeros(C, dtype=int)
+        X_curr, curr_preds = self._initial_sample(start_point)
+        dt = X_curr.dtype
+        gradg_curr = ops.as_device(self.forward.calc_gradg(curr_preds), dt)
+        proxf_curr = ops.as_device(self.prior.proxf(X_curr), dt)
+        logpiXc, L2Xc, priorXc = self._logpi_dev(X_curr, curr_preds)
+        n_acc = 0
+        while j.min() < self.nsamples:
+            noise = self._host_noise(X_curr) if self.rng == "numpy" else None
+            X_prop = ops.chain_step(
+                X_curr, proxf_curr, gradg_curr, delta_dev, self.lmda, noise=noise, noise_complex=bool(self.complex),
+                seed=self.seed, chain0=self.chain_offset, it=i,
+            )
+            prop_preds = ops.as_device(self.forward.forward(X_prop))
+            gradg_prop = ops.as_device(self.forward.calc_gradg(prop_preds), dt)
+            proxf_prop = ops.as_device(self.prior.proxf(X_prop), dt)
+
+            logtransXcXp = ops.logtransition(X_curr, X_prop, proxf_curr, gradg_curr, delta_dev, self.lmda)
+            logtransXpXc = ops.logtransition(X_prop, X_curr, proxf_prop, gradg_prop, delta_dev, self.lmda)
+            logpiXp, L2Xp, priorXp = self._logpi_dev(X_prop, prop_preds)
+
+            terms = torch.stack((logtransXpXc.real, logpiXp.real, logtransXcXp.real, logpiXc.real), dim=1).contiguous()
+            u = np.array([np.random.rand() for _ in range(C)]) if self.rng == "numpy" else None
+            accept = ops.pxmala_accept(
+                terms, delta_dev, self.tune_delta, self.lmda, i, u=u, seed=self.seed, chain0=self.chain_offset, it=i
+            )
+            for src, dst in ((X_prop, X_curr), (prop_preds, curr_preds), (gradg_prop, gradg_curr), (proxf_prop, proxf_curr)):
+                ops.select_copy(accept, src, dst)
+            a = accept.bool()
+            logpiXc = torch.where(a, logpiXp, logpiXc)
+            L2Xc = torch.where(a, L2Xp, L2Xc)
+            priorXc = torch.where(a, priorXp, priorXc)
+
+            k = i % self._CHUNK
+            acc_buf[k].copy_(accept)
+            delta_buf[k].copy_(delta_dev)
+            if k == self._CHUNK - 1:
+                acc_chunks.append(acc_buf.cpu().numpy().copy())
+                delta_chunks.append(delta_buf.cpu().numpy().copy())
+
+            gap_it = i >= self.nburn and (self.ngap == 0 or (i - self.nburn) % self.ngap == 0)
+            if gap_it:
+                acc_h = accept.cpu().numpy()  # the only per-iteration host sync, on save candidates only
+                chains = [c for c in range(C) if acc_h[c] and j[c] < self.nsamples]
+                if chains:
+                    self._tracking(j[chains] if C > 1 else int(j[0]), X_curr, curr_preds, logpiXc, L2Xc, priorXc,
+                                   chains=chains if C > 1 else None)
+                    j[chains] += 1
+            if self.verbosity > 0 and (i + 1) % self.verbosity == 0:
+                done = acc_chunks + [acc_buf[: k + 1].cpu().numpy()]
+                rate = np.concatenate(done)[:, 0].mean()
+                self._print_progress(
+                    int(j[0]) - 1, float(logpiXc[0].real), L2=float(L2Xc[0].real), prior=float(priorXc[0]), acceptanceRate=rate
+                )
+            i += 1
+        k = i % self._CHUNK
+        if k:
+            acc_chunks.append(acc_buf[:k].cpu().numpy().copy())
+            delta_chunks.append(delta_buf[:k].cpu().numpy().copy())
+        acc_all = np.concatenate(acc_chunks) if acc_chunks else np.zeros((0, C), dtype=np.int32)
+        del_all = np.concatenate([np.full((1, C), delta0)] + (delta_chunks if self.tune_delta else []))
+        if C == 1:
+            self.acceptance_trace = [int(v) for v in acc_all[:, 0]]
+            self.deltas_trace = [float(v) for v in del_all[:, 0]]
+        else:
+            self.acceptance_trace = acc_all
+            self.deltas_trace = del_all
+        self.delta = float(delta_dev[0].item())
+        self.delta_dev = delta_dev
+        self.X_curr, self.curr_preds, self.niter = X_curr, curr_preds, i
+        print("\nDONE")
+
+    def _tune_delta(self, i):
+        """pxmcmc/mcmc.py:277-279 (host form, one chain; the run loop adapts on the device)."""
+        delta = self.delta * (1 + (self.acceptance_trace[i] - 0.5) / ((i + 1) ** 0.75))
+        self.delta = min(max(delta, self.lmda * 1e-8), self.lmda / 2)
+
+    def calc_logtransition(self, X1, X2, proxf, gradg):
+        """q(X2|X1), literal (pxmcmc/mcmc.py:281-289)."""
+        r = ops.logtransition(X1, X2, proxf, gradg, self.delta, self.lmda)
+        batched = (X1.dim() if isinstance(X1, torch.Tensor) else np.ndim(X1)) == 2
+        if batched:
+            return r
+        v = complex(r[0].item())
+        return v if v.imag != 0 else v.real

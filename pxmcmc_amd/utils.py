@@ -1,0 +1,99 @@
+"""
+Host-side helpers mirroring the hot-path subset of pxmcmc/utils.py.
+
+``soft`` runs on the GPU; layout helpers and the MW quadrature weights are setup-time
+numpy, as in the reference.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def to_like(result, like):
+    """Return ``result`` (a GPU tensor) as numpy when the caller passed numpy, else as is."""
+    if isinstance(like, torch.Tensor):
+        return result
+    return result.cpu().numpy()
+
+
+def flatten_mlm(wav_lm, scal_lm):
+    """pxmcmc/utils.py:11-22: scaling coefficients first, wavelets flattened column-major."""
+    if isinstance(wav_lm, torch.Tensor):
+        buff = wav_lm.T.reshape(-1) if wav_lm.dim() > 1 else wav_lm
+        return torch.cat((scal_lm, buff))
+    buff = np.ravel(wav_lm, order="F")
+    return np.concatenate((scal_lm, buff))
+
+
+def expand_mlm(mlm, nscales=None, nscalcoefs=None, flatten_wavs=False):
+    """pxmcmc/utils.py:25-52."""
+    if nscales is None and nscalcoefs is None:
+        raise ValueError("Set either 'nscales', or 'nscalcoefs'")
+    elif nscales is not None and nscalcoefs is not None:
+        raise ValueError("Give only one of 'nscales' or 'nscalcoefs'")
+    elif nscales is not None:
+        mlm = np.asarray(mlm)
+        v_len = mlm.size // (nscales + 1)
+        assert v_len > 0
+        scal_lm = mlm[:v_len]
+        wav_lm = np.zeros((v_len, nscales), dtype=complex)
+        for i in range(nscales):
+            wav_lm[:, i] = mlm[(i + 1) * v_len : (i + 2) * v_len]
+        if flatten_wavs:
+            wav_lm = np.concatenate([wav_lm[:, i] for i in range(nscales)])
+    else:
+        scal_lm = mlm[..., :nscalcoefs]
+        wav_lm = mlm[..., nscalcoefs:]
+    return wav_lm, scal_lm
+
+
+def soft(X, T=0.1):
+    """pxmcmc/utils.py:55-67: soft thresholding (HIP kernel pxm_soft)."""
+    return to_like(ops.soft(X, T), X)
+
+
+def _multires_bandlimits(L, B, J_min, dirs=1, spin=0):
+    """pxmcmc/utils.py:116-125: highest non-zero el + 1 of the scaling function and every wavelet."""
+    k0, k = ops.tiling_axisym(L, B, J_min)
+    rows = [k0] + [k[j] for j in range(J_min, k.shape[0])]
+    return np.array([int(np.nonzero(r)[0].max()) + 1 for r in rows], dtype=int)
+
+
+def mw_weights(m):
+    """pxmcmc/utils.py:249-259."""
+    if m == 1:
+        return 1j * np.pi / 2
+    elif m == -1:
+        return -1j * np.pi / 2
+    elif m % 2 == 0:
+        return 2.0 / (1.0 - m * m)
+    return 0
+
+
+def weights_theta(L):
+    """pxmcmc/utils.py:262-267."""
+    wr = np.zeros(2 * L - 1, dtype=complex)
+    for i, m in enumerate(range(-(L - 1), L)):
+        wr[i] = mw_weights(m) * np.exp(-1j * m * np.pi / (2 * L - 1))
+    return (np.fft.fft(np.fft.ifftshift(wr)) * 2 * np.pi / (2 * L - 1) ** 2).real
+
+
+def mw_map_weights(L):
+    """pxmcmc/utils.py:270-283: exact MW quadrature weights, shape (L(2L-1),)."""
+    wr = weights_theta(L)
+    q = np.copy(wr[0:L])
+    for i, j in enumerate(range(2 * L - 2, L - 1, -1)):
+        q[i] = q[i] + wr[j]
+    return np.outer(q, np.ones(2 * L - 1)).flatten()
+
+
+def s2_integrate(f, L):
+    """pxmcmc/utils.py:286-301."""
+    f = f.cpu().numpy() if isinstance(f, torch.Tensor) else np.asarray(f)
+    return (mw_map_weights(L) * f).sum()
+
+
+def mw_size(L):
+    """[ext] pys2let.mw_size (pxmcmc/forward.py:1,109)."""
+    return L * (2 * L - 1)

@@ -1,0 +1,227 @@
+"""GPU parity of the samplers and the operator stack against golden trajectories and the oracle."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _toy(data, lmda, mu, setting="synthesis"):
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.measurements import Identity
+    from pxmcmc_amd.prior import L1
+    from pxmcmc_amd.transforms import IdentityTransform
+
+    N = data.size
+    op = ForwardOperator(data, 0.1, setting, IdentityTransform(), Identity(N, N), nparams=N)
+    reg = L1(setting, op.transform.inverse, op.transform.inverse_adjoint, lmda * mu)
+    return op, reg
+
+
+def test_myula_config1_trajectory_golden():
+    """BASELINE.json configs[0]: 1024-dim toy, 1000 MYULA iterations, the reference's own RNG stream."""
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+
+    g = golden("g5_myula_config1.npz")
+    lmda, delta, mu, nsamples, nburn, ngap, seed = g["params"]
+    op, reg = _toy(g["data"], lmda, mu)
+    p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=int(nsamples), nburn=int(nburn), ngap=int(ngap), verbosity=0)
+    s = MYULA(op, reg, p, rng="numpy")
+    np.random.seed(int(seed))
+    _quiet(s.run, start_point=np.zeros(1024))
+    np.testing.assert_allclose(s.chain[9], g["X_at_10"], rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(s.chain[-1], g["final_X"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(s.logPi, g["logPi"], rtol=1e-10)
+    np.testing.assert_allclose(s.L2s, g["L2s"], rtol=1e-10)
+    np.testing.assert_allclose(s.priors, g["priors"], rtol=1e-10)
+
+
+def test_pxmala_trajectory_golden():
+    from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams
+
+    g = golden("g4_pxmala.npz")
+    lmda, delta, mu, nsamples, nburn, ngap = g["params"]
+    op, reg = _toy(g["data"], lmda, mu)
+    p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=int(nsamples), nburn=int(nburn), ngap=int(ngap), verbosity=0,
+                     track=["logposterior", "L2", "prior", "chain", "predictions"])
+    s = PxMALA(op, reg, p, tune_delta=True, rng="numpy")
+    np.random.seed(5)
+    _quiet(s.run, start_point=g["X"].copy())
+    assert s.acceptance_trace == list(g["traj_acc"])
+    np.testing.assert_allclose(s.deltas_trace, g["traj_deltas"], rtol=1e-13)
+    np.testing.assert_allclose(s.chain, g["traj_chain"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(s.logPi, g["traj_logPi"], rtol=1e-10)
+    np.testing.assert_allclose(s.L2s, g["traj_L2"], rtol=1e-10)
+    np.testing.assert_allclose(s.priors, g["traj_prior"], rtol=1e-10)
+    np.testing.assert_allclose(s.preds, g["traj_preds"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("algo", ["myula", "pxmala"])
+@pytest.mark.parametrize("setting", ["analysis", "synthesis"])
+@pytest.mark.parametrize("sig", ["scalar", "vector"])
+def test_algorithms_run_reference_smoke(algo, setting, sig):
+    """reference tests/test_mcmc.py:11-60: run(), run(start_point), wrong-size start raises."""
+    from oracle import ssht
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMALA, PxMCMCParams
+    from pxmcmc_amd.measurements import Identity
+    from pxmcmc_amd.prior import L1
+    from pxmcmc_amd.transforms import IdentityTransform
+
+    L = 10
+    rng = np.random.default_rng(0)
+    flm = np.zeros(L * L, complex)
+    for el in range(L):
+        for m in range(el + 1):
+            r = rng.random()
+            flm[el * el + el - m] = (-1.0) ** m * r
+            flm[el * el + el + m] = r
+    data = ssht.inverse(flm, L).real.reshape(-1)
+    n = data.size
+    sig_d = 0.1 if sig == "scalar" else np.full(n, 0.1)
+    op = ForwardOperator(data, sig_d, setting, IdentityTransform(), Identity(n, n), nparams=n)
+    reg = L1(setting, op.transform.inverse, op.transform.inverse_adjoint, 1)
+    p = PxMCMCParams(nsamples=100, nburn=10, ngap=5, verbosity=0, s=5)
+    cls = MYULA if algo == "myula" else PxMALA
+    _quiet(cls(op, reg, p).run)
+    s = cls(op, reg, p)
+    _quiet(s.run, data)
+    assert s.chain.shape == (100, n) and np.isfinite(s.chain).all()
+    with pytest.raises(Exception):
+        _quiet(cls(op, reg, p).run, data[:5])
+    with pytest.raises(TypeError):
+        _quiet(cls(op, reg, p).run, list(data))
+
+
+def test_wavelet_myula_matches_oracle_with_injected_noise():
+    """Synthesis setting, wavelet transform + identity measurement + S2_Wavelets_L1: the fused GPU
+    iteration against the oracle's literal loop on the same noise, including the complex-variance quirk."""
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min = 16, 2, 2
+    rng = np.random.default_rng(3)
+    P = L * (2 * L - 1)
+    for cplx_data in (False, True):
+        data = rng.normal(size=P) + (1j * rng.normal(size=P) if cplx_data else 0)
+        lmda, delta, mu = 1e-3, 5e-4, 2.0
+        op = SphericalWaveletTransformOperator(data, 0.05, "synthesis", L, B, J_min)
+        reg = S2_Wavelets_L1("synthesis", op.transform.inverse, op.transform.inverse_adjoint, lmda * mu, L=L, B=B, J_min=J_min)
+        p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=6, nburn=2, ngap=2, verbosity=0)
+        s = MYULA(op, reg, p, rng="numpy")
+        assert s._fusable_wavelet()
+        N = op.nparams
+        X0 = rng.normal(size=N) * 0.1
+        np.random.seed(42)
+        _quiet(s.run, start_point=X0)
+        # oracle
+        T = ref.SphericalWaveletTransform(L, B, J_min)
+        oop = ref.ForwardOperator(data, 0.05, "synthesis", T, ref.Identity(P, P), T.ncoefs)
+        oreg = ref.S2_Wavelets_L1("synthesis", None, None, lmda * mu, L, B, J_min)
+        np.testing.assert_allclose(reg.map_weights, oreg.map_weights, rtol=1e-13)
+        np.random.seed(42)
+        out = ref.myula_run(oop, oreg, lmda, delta, mu, 6, 2, 2, X0.astype(complex), lambda i: np.random.randn(N))
+        np.testing.assert_allclose(s.chain, out["chain"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(s.X_curr[0].cpu().numpy(), out["X"], rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(s.logPi, np.real(out["logPi"]), rtol=1e-9)
+        np.testing.assert_allclose(s.priors, out["priors"], rtol=1e-10)
+        # unfused path (separate calc_gradg / proxf / chain_step kernels) gives the same trajectory
+        s2 = MYULA(op, reg, p, rng="numpy")
+        s2._fusable_wavelet = lambda: False
+        np.random.seed(42)
+        _quiet(s2.run, start_point=X0)
+        np.testing.assert_allclose(s2.chain, s.chain, rtol=1e-10, atol=1e-12)
+
+
+def test_multichain_batch_equals_single_chains():
+    """C chains in one batch == the same chains run one at a time (Philox keyed by chain id)."""
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min, C = 12, 2, 2, 3
+    rng = np.random.default_rng(4)
+    data = rng.normal(size=L * (2 * L - 1))
+    lmda, delta = 1e-3, 5e-4
+    op = SphericalWaveletTransformOperator(data, 0.1, "synthesis", L, B, J_min, max_chains=C)
+    reg = S2_Wavelets_L1("synthesis", None, None, lmda, L=L, B=B, J_min=J_min)
+    p = PxMCMCParams(lmda=lmda, delta=delta, nsamples=4, nburn=1, ngap=1, verbosity=0)
+    X0 = np.zeros(op.nparams)
+    batch = MYULA(op, reg, p, nchains=C, seed=7)
+    _quiet(batch.run, start_point=X0)
+    assert batch.chain.shape == (C, 4, op.nparams)
+    for c in range(C):
+        one = MYULA(op, reg, p, nchains=1, seed=7, chain_offset=c)
+        _quiet(one.run, start_point=X0)
+        np.testing.assert_allclose(one.chain, batch.chain[c], rtol=1e-12, atol=1e-14)
+    assert np.abs(batch.chain[0] - batch.chain[1]).max() > 1e-6
+
+
+def test_weaklensing_operator_dot_and_oracle():
+    """reference tests/test_measurements.py:73-130 on the GPU operator, plus parity with the oracle."""
+    from oracle import pxmcmc_np as ref
+    from oracle import ssht
+    from pxmcmc_amd.measurements import WeakLensing
+
+    L = 10
+    rng = np.random.default_rng(5)
+    for masked in (False, True):
+        mask = None
+        if masked:
+            mask = np.zeros(L * (2 * L - 1), dtype=int)
+            mask[: mask.size // 2] = 1
+            rng.shuffle(mask)
+            mask = mask.reshape(L, 2 * L - 1)
+        ngal = rng.integers(1, 40, size=(L, 2 * L - 1)).astype(float) if masked else None
+        op = WeakLensing(L, mask=mask, ngal=ngal, max_chains=2)
+        oop = ref.WeakLensing(L, mask=mask, ngal=ngal)
+        klm = rng.random(L * L) + 1j * rng.random(L * L)
+        klm[:4] = 0
+        glm = rng.random(L * L) + 1j * rng.random(L * L)
+        glm[:4] = 0
+        kappa = ssht.inverse(klm, L).reshape(-1)
+        gamma = ssht.inverse(glm, L)[op.mask]
+        k_to_g, g_to_k = op.forward(kappa), op.adjoint(gamma)
+        np.testing.assert_allclose(k_to_g, oop.forward(kappa), rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(g_to_k, oop.adjoint(gamma), rtol=1e-10, atol=1e-11)
+        a, b = abs(np.vdot(kappa, g_to_k)), abs(np.vdot(gamma, k_to_g))
+        assert np.count_nonzero(k_to_g) > 0 and np.isclose(a, b)
+        # batch of two
+        kb = np.stack([kappa, 2j * kappa])
+        np.testing.assert_allclose(op.forward(kb)[1], 2j * k_to_g, rtol=1e-10, atol=1e-11)
+
+
+def test_pxmala_weaklensing_runs():
+    """BASELINE.json configs[4] in miniature: weak-lensing operator, PxMALA with MH accept, 2 chains."""
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    L, B, J_min, C = 12, 2, 2, 2
+    rng = np.random.default_rng(6)
+    mask = np.ones((L, 2 * L - 1), dtype=int)
+    mask[L // 2 - 1 : L // 2 + 1] = 0
+    wl = WeakLensing(L, mask, ngal=np.full(mask.shape, 30.0), max_chains=C)
+    tr = SphericalWaveletTransform(L, B, J_min, max_chains=C)
+    gam = rng.normal(size=wl.ndata) + 1j * rng.normal(size=wl.ndata)
+    op = ForwardOperator(gam, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+    p = PxMCMCParams(nsamples=3, nburn=5, ngap=2, delta=1e-6, lmda=5e-7, verbosity=0)
+    reg = S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, p.lmda * p.mu, L=L, B=B, J_min=J_min)
+    s = PxMALA(op, reg, p, tune_delta=True, nchains=C, seed=1)
+    _quiet(s.run, start_point=np.zeros(tr.ncoefs))
+    assert s.chain.shape == (C, 3, tr.ncoefs) and np.isfinite(s.chain).all()
+    assert s.acceptance_trace.shape[1] == C and s.deltas_trace.shape == (s.niter + 1, C)
+    assert (s.deltas_trace <= p.lmda / 2 + 1e-20).all() and (s.deltas_trace >= p.lmda * 1e-8).all()

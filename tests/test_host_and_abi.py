@@ -1,0 +1,153 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol; host setup math
+(tables, tiling, weights, bandlimits) agrees with the oracle; host-side API logic and errors."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+
+def _lib():
+    from pxmcmc_amd import _lib
+
+    return _lib
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib()
+    header = open(os.path.join(ROOT, "include", "pxmcmc_amd.h")).read()
+    declared = set(re.findall(r"\b(pxm_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    raw = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert L.lib.pxm_version() >= 100
+
+
+def test_no_gpu_fails_loudly(have_gpu):
+    if have_gpu:
+        pytest.skip("GPU present")
+    from pxmcmc_amd import ops
+    from pxmcmc_amd._lib import PxmError
+
+    with pytest.raises(PxmError):
+        ops.ShtPlan(8)
+    with pytest.raises(PxmError):
+        ops.soft(np.ones(4), 0.5)
+
+
+def test_bad_arguments_set_error():
+    L = _lib()
+    assert L.lib.pxm_j_max(0, 2.0) < 0
+    assert b"pxm_j_max" in L.lib.pxm_last_error()
+    buf = (ctypes.c_int * 2)()
+    assert L.lib.pxm_wav_bandlimits(256, 2.0, 2, buf, 2) < 0  # capacity too small
+
+
+@pytest.mark.parametrize("spin", [0, 2, -2])
+def test_host_ring_tables_match_oracle(spin):
+    from oracle import ssht
+
+    L = 20
+    lib = _lib().lib
+    T = ssht.MWTransform(L, spin)
+    for m in range(-(L - 1), L):
+        B = np.zeros((L, L))
+        A = np.zeros((L, L))
+        assert lib.pxm_host_sht_tables(L, spin, m, B.ctypes.data, A.ctypes.data) == 0
+        assert np.abs(B - T.Binv[m + L - 1]).max() < 1e-13
+        assert np.abs(A - T.Afwd[m + L - 1]).max() < 1e-14
+
+
+def test_host_ring_table_large_L_finite():
+    # seeds ~ sin^m(theta/2) underflow double range; the long double recursion must give clean values
+    L = 300
+    lib = _lib().lib
+    B = np.zeros((L, L))
+    for m in (0, 150, 299, -299):
+        assert lib.pxm_host_sht_tables(L, 0, m, B.ctypes.data, None) == 0
+        assert np.isfinite(B).all()
+    assert lib.pxm_host_sht_tables(L, 0, 0, B.ctypes.data, None) == 0
+    from scipy.special import sph_harm_y
+
+    th = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+    np.testing.assert_allclose(B[:, 299], sph_harm_y(299, 0, th, 0.0).real, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("L,B,J", [(10, 2.0, 2), (64, 1.5, 2), (256, 2.0, 2), (512, 2.0, 2), (28, 2.0, 2)])
+def test_tiling_bandlimits_weights(L, B, J):
+    from oracle import pxmcmc_np as ref
+    from oracle import s2let
+    from pxmcmc_amd import ops, utils
+
+    k0, k = ops.tiling_axisym(L, B, J)
+    o0, o = s2let.tiling_axisym(B, L, J)
+    assert np.abs(k0 - o0).max() < 1e-10 and np.abs(k - o).max() < 1e-10
+    assert ops.wav_bandlimits(L, B, J) == s2let.bandlimits(B, L, J)
+    assert list(utils._multires_bandlimits(L, B, J)) == s2let.bandlimits(B, L, J)
+    assert ops.j_max(L, B) == s2let.j_max(B, L)
+    if L <= 64:
+        q = ops.mw_ring_weights(L)
+        np.testing.assert_allclose(np.repeat(q, 2 * L - 1), ref.mw_map_weights(L), rtol=1e-12, atol=1e-16)
+
+
+def test_utils_weights_against_golden():
+    from pxmcmc_amd import utils
+
+    g = golden("g6_mw_weights.npz")
+    for L in (4, 8, 10, 64):
+        np.testing.assert_allclose(utils.mw_map_weights(L), g[f"map_weights_{L}"], rtol=1e-13, atol=1e-17)
+        np.testing.assert_allclose(utils.weights_theta(L), g[f"weights_theta_{L}"], rtol=1e-13, atol=1e-17)
+
+
+def test_layout_helpers_against_golden():
+    from pxmcmc_amd import utils
+
+    g = golden("g8_layout.npz")
+    assert np.array_equal(utils.flatten_mlm(g["wav2d"], g["scal"]), g["flat2d"])
+    assert np.array_equal(utils.flatten_mlm(g["wav1d"], g["scal1"]), g["flat1d"])
+    w, s = utils.expand_mlm(g["flat1d"], nscalcoefs=6)
+    assert np.array_equal(w, g["exp_wav"]) and np.array_equal(s, g["exp_scal"])
+    w, s = utils.expand_mlm(g["flat2d"], nscales=3)
+    assert np.array_equal(w, g["exp2_wav"]) and np.array_equal(s, g["exp2_scal"])
+    # reference tests/test_utils.py:8-21
+    f_wav = np.ones((861, 9)) + np.arange(9)[None, :]
+    assert all(utils.flatten_mlm(f_wav, np.zeros(861)) == np.concatenate([[i] * 861 for i in range(10)]))
+    w, s = utils.expand_mlm(np.ones(8610), nscales=9)
+    assert w.shape == (861, 9) and s.shape == (861,)
+    with pytest.raises(ValueError):
+        utils.expand_mlm(np.ones(4))
+
+
+def test_weaklensing_kernel_against_golden():
+    from pxmcmc_amd.measurements import WeakLensingHarmonic
+
+    g = golden("g7_weaklensing.npz")
+    for L in (8, 16):
+        assert np.array_equal(WeakLensingHarmonic(L).harmonic_kernel, g[f"kernel_{L}"])
+    with pytest.raises(ValueError):
+        WeakLensingHarmonic(0)
+    with pytest.warns(UserWarning):
+        WeakLensingHarmonic(1025)
+
+
+def test_params_defaults_match_reference():
+    from pxmcmc_amd.mcmc import PxMCMCParams
+
+    p = PxMCMCParams()
+    assert (p.lmda, p.delta, p.s, p.mu, p.nsamples, p.nburn, p.ngap, p.complex, p.verbosity) == (3e-5, 1e-5, 1, 1, int(1e6), int(1e3), int(1e2), False, 100)
+    assert p.track == ["logposterior", "L2", "prior", "chain"]
+
+
+def test_philox_reference_vector():
+    """Known-answer test of the Philox4x32-10 block function (Random123 kat_vectors)."""
+    from oracle import philox
+
+    out = philox.philox4x32_10(np.array([0, 0, 0, 0], dtype=np.uint32), np.array([0, 0], dtype=np.uint32))
+    assert [hex(int(v)) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    out = philox.philox4x32_10(np.array([0xFFFFFFFF] * 4, dtype=np.uint32), np.array([0xFFFFFFFF] * 2, dtype=np.uint32))
+    assert [hex(int(v)) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
