@@ -224,4 +224,5 @@ def test_pxmala_weaklensing_runs():
     _quiet(s.run, start_point=np.zeros(tr.ncoefs))
     assert s.chain.shape == (C, 3, tr.ncoefs) and np.isfinite(s.chain).all()
     assert s.acceptance_trace.shape[1] == C and s.deltas_trace.shape == (s.niter + 1, C)
-    assert (s.deltas_trace <= p.lmda / 2 + 1e-20).all() and (s.deltas_trace >= p.lmda * 1e-8).all()
+    adapted = s.deltas_trace[1:]  # entry 0 is the user's starting delta, before the first clip
+    assert (adapted <= p.lmda / 2 + 1e-20).all() and (adapted >= p.lmda * 1e-8).all()
