@@ -39,6 +39,13 @@ const char* pxm_last_error(void);
 /* number of visible HIP devices (0 when none; never fails) */
 int pxm_device_count(void);
 
+/* ---- live kernel timing (bench.py roofline leg) --------------------------------
+ * When enabled, every launch of the SHT ring-GEMM kernel is bracketed by HIP events on the
+ * stream it is launched on.  pxm_profile_read synchronises those events and returns the summed
+ * kernel time (ms), the number of launches and the algorithmic bytes they moved, then resets. */
+int pxm_profile_enable(int on);
+int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes);
+
 /* ---- host-side setup helpers (no GPU needed) ------------------------------ */
 /* pys2let.pys2let_j_max(B, L, J_min)            (pxmcmc/transforms.py:75) */
 int pxm_j_max(int L, double B);

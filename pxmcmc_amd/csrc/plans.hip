@@ -13,9 +13,11 @@ struct TaskList {
   GemmTask* d = nullptr;
   int n = 0;
   bool paired = false;
+  std::vector<int> bls;  // bandlimits of the transforms grouped in this launch (roofline accounting)
 };
 
-static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out) {
+static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std::vector<int> bls) {
+  out->bls = bls;
   // longest first: workgroups are handed out in order, so this is the LPT rule for CU balance
   std::stable_sort(v.begin(), v.end(), [](const GemmTask& a, const GemmTask& b) {
     return (int64_t)(a.k_end - a.k_beg) * a.n_rt > (int64_t)(b.k_end - b.k_beg) * b.n_rt;
@@ -29,10 +31,13 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out) {
 }
 
 // run a task list over all chain groups (16 chains = 32 columns per launch)
-static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, hipStream_t st) {
+static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, int C, hipStream_t st) {
   for (int col0 = 0; col0 < ncol; col0 += 32) {
     const int ct = (ncol - col0 >= 32) ? 2 : 1;
-    int rc = launch_gemm(tl.d, tl.n, tl.paired, X, Y, ncol, col0, ct, st);
+    const int cg = std::max(0, std::min(C - col0 / 2, 8 * ct));  // live chains in this column group
+    double bytes = 0;
+    for (int b : tl.bls) bytes += gemm_alg_bytes(b, tl.paired, cg);
+    int rc = launch_gemm(tl.d, tl.n, tl.paired, X, Y, ncol, col0, ct, bytes, st);
     if (rc) return rc;
   }
   return 0;
@@ -88,7 +93,7 @@ int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht
     const bool e2r = kind_el_to_ring(k);
     append_gemm_tasks(*p->T, k, p->ncol, e2r ? p->offH : p->offG, L, p->Rp, e2r ? p->offG : p->offH, L, p->Rp, nullptr,
                       p->offS, v);
-    rc = upload_tasks(v, p->T->paired, &p->tl[k]);
+    rc = upload_tasks(v, p->T->paired, &p->tl[k], {L});
     if (rc) return rc;
   }
   *plan = p;
@@ -120,7 +125,7 @@ static int sht_check(pxm_sht_plan_t p, const void* a, const void* b, int C, cons
 static int sht_el_to_ring(pxm_sht_plan_t p, int kind, const void* flm, void* f, int C, hipStream_t st) {
   int rc = launch_lm_to_mel((const double*)flm, p->ws + p->offH, p->L, p->Rp, p->ncol, C, p->spin, st);
   if (rc) return rc;
-  rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, st);
+  rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, C, st);
   if (rc) return rc;
   PxOut out;
   out.f = (double*)f;
@@ -134,7 +139,7 @@ static int sht_ring_to_el(pxm_sht_plan_t p, int kind, const void* f, void* flm, 
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
   int rc = launch_px2ring(p->dft, in, p->ws + p->offG, p->ncol, C, st);
   if (rc) return rc;
-  rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, st);
+  rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, C, st);
   if (rc) return rc;
   return launch_mel_to_lm(p->ws + p->offH, (double*)flm, p->L, p->Rp, p->ncol, C, p->spin, st);
 }
@@ -308,22 +313,22 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   }
   p->table_bytes[0] += p->TL->bytes[TAB_INV];
   p->table_bytes[1] += p->TL->bytes[TAB_INV_ADJ];
-  if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd))) return rc;
-  if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj))) return rc;
-  if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv))) return rc;
-  if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj))) return rc;
+  if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl))) return rc;
+  if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl))) return rc;
+  if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl))) return rc;
+  if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl))) return rc;
   v.clear();
   append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, v);
-  if ((rc = upload_tasks(v, true, &p->syn_inv))) return rc;
+  if ((rc = upload_tasks(v, true, &p->syn_inv, {L}))) return rc;
   v.clear();
   append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, v);
-  if ((rc = upload_tasks(v, true, &p->adj_invadj))) return rc;
+  if ((rc = upload_tasks(v, true, &p->adj_invadj, {L}))) return rc;
   v.clear();
   append_gemm_tasks(*p->TL, TAB_FWD, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, v);
-  if ((rc = upload_tasks(v, true, &p->ana_fwd))) return rc;
+  if ((rc = upload_tasks(v, true, &p->ana_fwd, {L}))) return rc;
   v.clear();
   append_gemm_tasks(*p->TL, TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, v);
-  if ((rc = upload_tasks(v, true, &p->anadj_fwdadj))) return rc;
+  if ((rc = upload_tasks(v, true, &p->anadj_fwdadj, {L}))) return rc;
   // combine descriptors
   CombineArgs c;
   c.nsc = p->nsc;
@@ -407,9 +412,9 @@ int pxm_wav_synthesis(pxm_wav_plan_t p, const void* X, void* f, int C, pxm_strea
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
-  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
   if ((rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
-  if ((rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st))) return rc;
   PxOut out;
   out.f = (double*)f;
   out.chain_stride = (int64_t)p->L * (2 * p->L - 1);
@@ -419,8 +424,8 @@ int pxm_wav_synthesis(pxm_wav_plan_t p, const void* X, void* f, int C, pxm_strea
 static int wav_synthesis_adjoint_impl(pxm_wav_plan_t p, const PxIn& in, const PxOut& out, int C, hipStream_t st) {
   int rc;
   if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offGL, p->ncol, C, st))) return rc;
-  if ((rc = run_tasks(p->adj_invadj, p->ws, p->ws, p->ncol, st))) return rc;
-  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = run_tasks(p->adj_invadj, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;
   return wav_rings_to_blocks(p, out, C, st);
 }
 
@@ -472,8 +477,8 @@ int pxm_wav_analysis(pxm_wav_plan_t p, const void* f, void* X, int C, pxm_stream
   in.f = (const double*)f;
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
   if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offGL, p->ncol, C, st))) return rc;
-  if ((rc = run_tasks(p->ana_fwd, p->ws, p->ws, p->ncol, st))) return rc;
-  if ((rc = run_tasks(p->ana_inv, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = run_tasks(p->ana_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->ana_inv, p->ws, p->ws, p->ncol, C, st))) return rc;
   PxOut out;
   out.f = (double*)X;
   return wav_rings_to_blocks(p, out, C, st);
@@ -484,9 +489,9 @@ int pxm_wav_analysis_adjoint(pxm_wav_plan_t p, const void* X, void* f, int C, px
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
-  if ((rc = run_tasks(p->anadj_invadj, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = run_tasks(p->anadj_invadj, p->ws, p->ws, p->ncol, C, st))) return rc;
   if ((rc = launch_combine(p->comb_ana, p->ws, p->ws + p->offHL, st))) return rc;
-  if ((rc = run_tasks(p->anadj_fwdadj, p->ws, p->ws, p->ncol, st))) return rc;
+  if ((rc = run_tasks(p->anadj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;
   PxOut out;
   out.f = (double*)f;
   out.chain_stride = (int64_t)p->L * (2 * p->L - 1);

@@ -57,8 +57,21 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
 
 // launch: tasks on device; X/Y = workspace base; col0 = first column of this chain group, ct = column
 // tiles (1 or 2) of the group
+// alg_bytes: algorithmic bytes of this launch (table once + operand + result), for the live profiler
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double* X, double* Y, int ncol,
-                int col0, int ct, hipStream_t stream);
+                int col0, int ct, double alg_bytes, hipStream_t stream);
+
+// algorithmic bytes of one ring-GEMM stage at bandlimit L for C chains:
+// ring table 8*L*L*(L+1)/2 [paired] or 8*L*L*L [all m] read once, harmonic side 16*C*L*L,
+// ring side 16*C*L*(2L-1)
+inline double gemm_alg_bytes(int L, bool paired, int C) {
+  const double Ld = L;
+  const double tab = paired ? 8.0 * Ld * Ld * (Ld + 1) / 2 : 8.0 * Ld * (Ld * Ld);
+  return tab + 16.0 * C * (Ld * Ld + Ld * (2 * Ld - 1));
+}
+
+void profile_gemm_begin(hipStream_t st);
+void profile_gemm_end(hipStream_t st, double alg_bytes);
 
 // ---- DFT stage ---------------------------------------------------------------
 struct DftPlan {

@@ -6,6 +6,7 @@
 // double h of lane l is T[row = 16*rt + (l & 15)][k = k_beg + 8*kk2 + 4*h + (l >> 4)] -- exactly
 // the A-operand fragments of two consecutive MFMAs, so a wave streams its table with one
 // coalesced 16-B-per-lane load per two MFMA k-steps and the table never touches LDS.
+#include "../../include/pxmcmc_amd.h"
 #include "sht_core.h"
 
 #include <map>
@@ -92,10 +93,56 @@ __global__ __launch_bounds__(256) void k_sht_gemm(const GemmTask* __restrict__ t
   }
 }
 
+// ---- live profiler: event pairs around GEMM launches --------------------------------------
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+static size_t g_prof_used = 0;
+static double g_prof_bytes = 0;
+
+void profile_gemm_begin(hipStream_t st) {
+  if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return;
+  (void)hipEventRecord(g_prof_pool[g_prof_used].first, st);
+}
+void profile_gemm_end(hipStream_t st, double alg_bytes) {
+  if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return;
+  (void)hipEventRecord(g_prof_pool[g_prof_used].second, st);
+  g_prof_bytes += alg_bytes;
+  ++g_prof_used;
+}
+int profile_enable(int on) {
+  if (on && g_prof_pool.empty()) {
+    g_prof_pool.resize(16384);
+    for (auto& pr : g_prof_pool) {
+      PXM_HIP(hipEventCreate(&pr.first));
+      PXM_HIP(hipEventCreate(&pr.second));
+    }
+  }
+  g_prof_on = on != 0;
+  g_prof_used = 0;
+  g_prof_bytes = 0;
+  return 0;
+}
+int profile_read(double* ms, int64_t* launches, double* bytes) {
+  double tot = 0;
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    PXM_HIP(hipEventSynchronize(g_prof_pool[i].second));
+    float t = 0;
+    PXM_HIP(hipEventElapsedTime(&t, g_prof_pool[i].first, g_prof_pool[i].second));
+    tot += t;
+  }
+  if (ms) *ms = tot;
+  if (launches) *launches = (int64_t)g_prof_used;
+  if (bytes) *bytes = g_prof_bytes;
+  g_prof_used = 0;
+  g_prof_bytes = 0;
+  return 0;
+}
+
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double* X, double* Y, int ncol,
-                int col0, int ct, hipStream_t stream) {
+                int col0, int ct, double alg_bytes, hipStream_t stream) {
   if (n_tasks == 0) return 0;
   dim3 grid(n_tasks), block(256);
+  profile_gemm_begin(stream);
   if (paired) {
     if (ct == 1) hipLaunchKernelGGL((k_sht_gemm<1, 2>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
     else hipLaunchKernelGGL((k_sht_gemm<2, 2>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
@@ -103,6 +150,7 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double*
     if (ct == 1) hipLaunchKernelGGL((k_sht_gemm<1, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
     else hipLaunchKernelGGL((k_sht_gemm<2, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
   }
+  profile_gemm_end(stream, alg_bytes);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -190,6 +238,15 @@ __global__ void k_tile_table(const double* __restrict__ D, double* __restrict__ 
   const double v = transposed ? D[(int64_t)k * Rp + row] : D[(int64_t)row * Rp + k];
   out[((int64_t)rt * nk2 + kk2) * 128 + threadIdx.x] = v;
 }
+
+}  // namespace pxm
+extern "C" {
+int pxm_profile_enable(int on) { return pxm::profile_enable(on); }
+int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes) {
+  return pxm::profile_read(gemm_ms, gemm_launches, gemm_alg_bytes);
+}
+}
+namespace pxm {
 
 static std::mutex g_tab_mutex;
 static std::map<std::pair<int, int>, ShtTables*> g_tab_cache;
