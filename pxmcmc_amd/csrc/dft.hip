@@ -7,6 +7,8 @@
 #include "elem.h"
 #include "sht_core.h"
 
+#include <cstdlib>
+
 namespace pxm {
 
 struct DftArgs {
@@ -168,6 +170,20 @@ int make_dft_plan(int L, DftPlan* p) {
   PXM_HIP(hipMemcpy(p->d_chirp, b.chirp.data(), b.chirp.size() * sizeof(double), hipMemcpyHostToDevice));
   PXM_HIP(hipMemcpy(p->d_bhat, b.bhat.data(), b.bhat.size() * sizeof(double), hipMemcpyHostToDevice));
   PXM_HIP(hipMemcpy(p->d_tw, b.tw.data(), b.tw.size() * sizeof(double), hipMemcpyHostToDevice));
+  p->use2 = dft2_supported(b.M) && !getenv("PXM_DFT_RADIX2");
+  if (p->use2) {
+    int rc = dft2_make_tables(b, &p->d_bhatn, &p->d_twm);
+    if (rc) return rc;
+    const char* e = getenv("PXM_DFT_R");
+    int R2 = e ? atoi(e) : 4;
+    if (R2 != 1 && R2 != 2 && R2 != 4 && R2 != 8) R2 = 4;
+    for (;;) {
+      dft2_geometry(b.M, b.n, R2, &p->threads2, &p->lds2);
+      if (R2 == 1 || (p->lds2 <= 150 * 1024 && p->threads2 <= 1024)) break;
+      R2 >>= 1;
+    }
+    p->R2 = R2;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -183,7 +199,9 @@ void free_dft_plan(DftPlan* p) {
   if (p->d_chirp) (void)hipFree(p->d_chirp);
   if (p->d_bhat) (void)hipFree(p->d_bhat);
   if (p->d_tw) (void)hipFree(p->d_tw);
-  p->d_chirp = p->d_bhat = p->d_tw = nullptr;
+  if (p->d_bhatn) (void)hipFree(p->d_bhatn);
+  if (p->d_twm) (void)hipFree(p->d_twm);
+  p->d_chirp = p->d_bhat = p->d_tw = p->d_bhatn = p->d_twm = nullptr;
 }
 
 static DftArgs make_args(const DftPlan& p) {
@@ -201,6 +219,7 @@ static DftArgs make_args(const DftPlan& p) {
 }
 
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream) {
+  if (p.use2) return dft2_px2ring(p, in, G, ncol, C, stream);
   const int Cp = ncol / 2;
   dim3 grid(p.L, (Cp + p.R - 1) / p.R), block(p.threads);
   hipLaunchKernelGGL(k_px2ring, grid, block, p.lds, stream, make_args(p), in, G, ncol, C);
@@ -209,6 +228,7 @@ int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C,
 }
 
 int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
+  if (p.use2) return dft2_ring2px(p, G, ncol, out, C, stream);
   dim3 grid(p.L, (C + p.R - 1) / p.R), block(p.threads);
   hipLaunchKernelGGL(k_ring2px, grid, block, p.lds, stream, make_args(p), G, ncol, out, C);
   PXM_HIP(hipGetLastError());

@@ -92,7 +92,7 @@ int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht
     std::vector<GemmTask> v;
     const bool e2r = kind_el_to_ring(k);
     append_gemm_tasks(*p->T, k, p->ncol, e2r ? p->offH : p->offG, L, p->Rp, e2r ? p->offG : p->offH, L, p->Rp, nullptr,
-                      p->offS, v);
+                      p->offS, p->ws, v);
     rc = upload_tasks(v, p->T->paired, &p->tl[k], {L});
     if (rc) return rc;
   }
@@ -298,16 +298,16 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   for (int s = 0; s < p->nsc; ++s) {
     const int b = p->bl[s], Rb = round_up(b, 16);
     // synthesis: G_s --A_s--> H_s
-    append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS, v_syn_fwd);
+    append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS, p->ws, v_syn_fwd);
     // synthesis adjoint: H_L (scaled by c_s kappa_s per el) --A_s^T--> G_s
     append_gemm_tasks(*p->T[s], TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
-                      p->d_kc_syn + (size_t)s * p->Rp, p->offS, v_adj_fwdadj);
+                      p->d_kc_syn + (size_t)s * p->Rp, p->offS, p->ws, v_adj_fwdadj);
     // analysis: H_L (scaled by c_a kappa_s) --B_s--> G_s
     append_gemm_tasks(*p->T[s], TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
-                      p->d_kc_ana + (size_t)s * p->Rp, p->offS, v_ana_inv);
+                      p->d_kc_ana + (size_t)s * p->Rp, p->offS, p->ws, v_ana_inv);
     // analysis adjoint: G_s --B_s^T--> H_s
     append_gemm_tasks(*p->T[s], TAB_INV_ADJ, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS,
-                      v_anadj_invadj);
+                      p->ws, v_anadj_invadj);
     p->table_bytes[0] += p->T[s]->bytes[TAB_FWD];
     p->table_bytes[1] += p->T[s]->bytes[TAB_FWD_ADJ];
   }
@@ -318,16 +318,16 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl))) return rc;
   if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl))) return rc;
   v.clear();
-  append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, v);
+  append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->syn_inv, {L}))) return rc;
   v.clear();
-  append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, v);
+  append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->adj_invadj, {L}))) return rc;
   v.clear();
-  append_gemm_tasks(*p->TL, TAB_FWD, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, v);
+  append_gemm_tasks(*p->TL, TAB_FWD, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->ana_fwd, {L}))) return rc;
   v.clear();
-  append_gemm_tasks(*p->TL, TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, v);
+  append_gemm_tasks(*p->TL, TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->anadj_fwdadj, {L}))) return rc;
   // combine descriptors
   CombineArgs c;

@@ -21,16 +21,17 @@ namespace pxm {
 enum TableKind { TAB_INV = 0, TAB_FWD = 1, TAB_INV_ADJ = 2, TAB_FWD_ADJ = 3 };
 inline bool kind_el_to_ring(int kind) { return kind == TAB_INV || kind == TAB_FWD_ADJ; }
 
-// One workgroup's share of a per-m GEMM: up to 4 row tiles of 16 output rows.
+// One workgroup's share of a per-m GEMM: up to 8 row tiles of 16 output rows (two per wave).
 struct GemmTask {
-  const double* tab;   // tiled table of this (m, first row tile): [rt][kk2][lane][2]
+  int64_t tab_off;     // tiled table of this (m, first row tile), in doubles relative to the workspace base
+                       // (kernel-argument-relative so the loads are global_load, not flat_load)
   int64_t rt_stride;   // doubles between consecutive row tiles
   int64_t x_off[2];    // operand slab offsets (doubles) for +m / -m
   int64_t y_off[2];    // output slab offsets
-  const double* kscale;  // optional per-k scale (indexed by absolute k), or null
-  int k_beg, k_end;    // contraction range, multiples of 8
+  int64_t ks_off;      // optional per-k scale vector (indexed by absolute k) relative to the workspace base; 0 = none
+  int k_beg, k_end;    // contraction range, multiples of 16
   int row0;            // first output row of this task
-  int n_rt;            // row tiles in this task (1..4)
+  int n_rt;            // row tiles in this task (1..8)
   double sign1;        // factor on the -m output ((-1)^m)
 };
 
@@ -53,7 +54,7 @@ int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out);
 // array (x_Rp, x_L give the operand array's row padding and bandlimit for the m_idx mapping).
 void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, int x_L, int x_Rp,
                        int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
-                       std::vector<GemmTask>& tasks);
+                       const double* ws_base, std::vector<GemmTask>& tasks);
 
 // launch: tasks on device; X/Y = workspace base; col0 = first column of this chain group, ct = column
 // tiles (1 or 2) of the group
@@ -80,7 +81,13 @@ struct DftPlan {
   int threads = 0;  // workgroup size
   size_t lds = 0;
   double *d_chirp = nullptr, *d_bhat = nullptr, *d_tw = nullptr;
+  // two-factor register-FFT path (dft2.hip), used when M <= 1024
+  bool use2 = false;
+  int R2 = 0, threads2 = 0;
+  size_t lds2 = 0;
+  double *d_bhatn = nullptr, *d_twm = nullptr;
 };
+
 int make_dft_plan(int L, DftPlan* p);
 void free_dft_plan(DftPlan* p);
 
@@ -105,6 +112,12 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
   int noise_complex = 0;
   uint64_t seed = 0, chain0 = 0, iter = 0;
 };
+
+bool dft2_supported(int M);
+int dft2_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm);
+void dft2_geometry(int M, int n, int R, int* threads, size_t* lds);
+int dft2_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
+int dft2_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
 
 // f(t,p) -> G[m][t][c]  (unnormalised, e^{-i m phi});  G -> f (e^{+i m phi})
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream);

@@ -17,79 +17,136 @@ namespace pxm {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------
-// GEMM kernel.  One workgroup = one GemmTask = up to 4 row tiles (one per wave) x CT*NSLAB
-// column tiles of 16 columns.  Y[row][col] = sum_k T[row][k] * kscale[k] * X[k][col].
+// GEMM kernel.  One workgroup (4 waves) = one GemmTask = up to 8 row tiles of 16 output rows
+// (two per wave) x NCT = CT*NSLAB column tiles of 16 columns:
+//     Y[row][col] = sum_k T[row][k] * kscale[k] * X[k][col].
+// * the table T streams HBM -> registers in its pre-tiled MFMA A-fragment layout, prefetched two
+//   16-k chunks ahead (it is read exactly once per launch and never touches LDS);
+// * the operand X (shared by every row tile of the task) is staged once per workgroup through
+//   double-buffered LDS with 16-B coalesced loads issued one chunk ahead; the row pitch is
+//   = 128 B mod 256 B so the ds_read_b64 B-fragment reads of the two k-rows a 32-lane group
+//   touches fall on disjoint bank halves;
+// * one barrier per 16-k chunk (32 MFMAs per wave between barriers).
 // ---------------------------------------------------------------------------------------
+constexpr int KC = 16;  // contraction rows per staged chunk
+
 template <int CT, int NSLAB>
 __global__ __launch_bounds__(256) void k_sht_gemm(const GemmTask* __restrict__ tasks,
                                                   const double* __restrict__ X, double* __restrict__ Y,
                                                   int ncol, int col0) {
+  constexpr int NCT = CT * NSLAB;
+  constexpr int COLS = 16 * NCT;                          // staged operand columns
+  constexpr int PITCH = COLS + (COLS == 16 ? 0 : 16);     // doubles; PITCH*8 = 128 (mod 256)
+  constexpr int NV = KC * COLS / 2;                       // double2 per chunk
+  constexpr int IT = (NV + 255) / 256;                    // staging loads per thread per chunk
+  __shared__ double xs[2][KC][PITCH];
+
   const GemmTask t = tasks[blockIdx.x];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (wave >= t.n_rt) return;
-  const double2* __restrict__ tab =
-      reinterpret_cast<const double2*>(t.tab + (int64_t)wave * t.rt_stride) + lane;
-  const int nk2 = (t.k_end - t.k_beg) >> 3;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the row-tile tests scalar
   const int kq = lane >> 4, cl = lane & 15;
+  const int n_my = min(2, max(0, t.n_rt - 2 * wave));     // row tiles of this wave
+  const int nch = (t.k_end - t.k_beg) / KC;
 
-  d4 acc[NSLAB][CT];
+  // ---- operand staging map: thread -> (row kr, column pair) of the chunk
+  constexpr bool ALL = (NV % 256) == 0;  // every thread stages in every pass
+  const double* sp[IT];
+  int so[IT];
+  bool sv[IT];
 #pragma unroll
-  for (int s = 0; s < NSLAB; ++s)
-#pragma unroll
-    for (int c = 0; c < CT; ++c) acc[s][c] = d4{0, 0, 0, 0};
+  for (int i = 0; i < IT; ++i) {
+    const int q = tid + 256 * i;
+    sv[i] = ALL || q < NV;
+    const int kr = (q / (COLS / 2)) % KC, col = 2 * (q % (COLS / 2));
+    const int slab = col / (16 * CT), cin = col % (16 * CT);
+    sp[i] = X + (slab ? t.x_off[1] : t.x_off[0]) + col0 + cin + (int64_t)(t.k_beg + kr) * ncol;
+    so[i] = kr * PITCH + col;
+  }
+  double2 st[IT];
+#define PXM_STAGE_LOAD(CH)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i])                                   \
+      st[i] = *reinterpret_cast<const double2*>(sp[i] + (int64_t)(CH) * KC * ncol);
+#define PXM_STAGE_STORE(CH, BUF)                                                                    \
+  _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i]) {                                 \
+    double2 v = st[i];                                                                              \
+    if (t.ks_off) {                                                                                 \
+      const double sc = (X + t.ks_off)[t.k_beg + (CH) * KC + so[i] / PITCH];                        \
+      v.x *= sc;                                                                                    \
+      v.y *= sc;                                                                                    \
+    }                                                                                               \
+    *reinterpret_cast<double2*>(&xs[BUF][0][0] + so[i]) = v;                                         \
+  }
 
-  const double* xb[NSLAB];
-#pragma unroll
-  for (int s = 0; s < NSLAB; ++s) xb[s] = X + t.x_off[s] + col0 + cl + (int64_t)(t.k_beg + kq) * ncol;
+  // ---- table stream: per row tile two double2 per chunk (k-steps {0,1} and {2,3})
+  // rows this wave does not own alias row tile 0 (valid memory, results discarded); chunk indices are
+  // clamped so every load is unconditional: plain global_load_dwordx4, no select, no flat access
+  const double2* tab0 = reinterpret_cast<const double2*>(X + t.tab_off + (int64_t)(n_my > 0 ? 2 * wave : 0) * t.rt_stride) + lane;
+  const double2* tab1 = reinterpret_cast<const double2*>(X + t.tab_off + (int64_t)(n_my > 1 ? 2 * wave + 1 : 0) * t.rt_stride) + lane;
+  const bool v0 = n_my > 0;
+  // three register sets used round-robin with compile-time indices (no register rotation: a copy
+  // of an in-flight load would force a full vmcnt(0) drain every chunk)
+  double2 A[3][2][2];
+#define PXM_TAB_LOAD(SET, CH)                                                 \
+  {                                                                           \
+    const int cc = min((CH), nch - 1);                                        \
+    A[SET][0][0] = tab0[(int64_t)(2 * cc) * 64];                              \
+    A[SET][0][1] = tab0[(int64_t)(2 * cc + 1) * 64];                          \
+    A[SET][1][0] = tab1[(int64_t)(2 * cc) * 64];                              \
+    A[SET][1][1] = tab1[(int64_t)(2 * cc + 1) * 64];                          \
+  }
 
-  constexpr int PF = 4;  // table prefetch depth (chunks of 8 k)
-  double2 a[PF];
+  d4 acc[2][NCT];
 #pragma unroll
-  for (int i = 0; i < PF; ++i) a[i] = (i < nk2) ? tab[(int64_t)i * 64] : double2{0, 0};
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[r][c] = d4{0, 0, 0, 0};
 
-  for (int kk2 = 0; kk2 < nk2; kk2 += PF) {
+  PXM_STAGE_LOAD(0)
+  PXM_TAB_LOAD(0, 0)
+  PXM_TAB_LOAD(1, 1)
+  for (int ch0 = 0; ch0 < nch; ch0 += 3) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      const int kc = kk2 + i;
-      if (kc < nk2) {
-        double2 av = a[i];
-        const int kn = kc + PF;
-        a[i] = (kn < nk2) ? tab[(int64_t)kn * 64] : double2{0, 0};
-        double s0 = 1.0, s1 = 1.0;
-        if (t.kscale) {
-          s0 = t.kscale[t.k_beg + 8 * kc + kq];
-          s1 = t.kscale[t.k_beg + 8 * kc + 4 + kq];
+    for (int u = 0; u < 3; ++u) {
+      const int ch = ch0 + u;
+      if (ch < nch) {
+        const int buf = ch & 1;
+        PXM_STAGE_STORE(ch, buf)
+        if (ch + 1 < nch) { PXM_STAGE_LOAD(ch + 1) }
+        PXM_TAB_LOAD((u + 2) % 3, ch + 2)
+        __syncthreads();
+        if (v0) {
+#pragma unroll
+          for (int h4 = 0; h4 < 4; ++h4) {
+            double b[NCT];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) b[c] = xs[buf][4 * h4 + kq][16 * c + cl];
+            const double a0 = (h4 & 1) ? A[u][0][h4 >> 1].y : A[u][0][h4 >> 1].x;
+            const double a1 = (h4 & 1) ? A[u][1][h4 >> 1].y : A[u][1][h4 >> 1].x;
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[c], acc[0][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[c], acc[1][c], 0, 0, 0);
+          }
         }
-        double b0[NSLAB][CT], b1[NSLAB][CT];
-#pragma unroll
-        for (int s = 0; s < NSLAB; ++s)
-#pragma unroll
-          for (int c = 0; c < CT; ++c) {
-            const double* p = xb[s] + (int64_t)(8 * kc) * ncol + 16 * c;
-            b0[s][c] = p[0];
-            b1[s][c] = p[(int64_t)4 * ncol];
-          }
-        const double a0 = av.x * s0, a1 = av.y * s1;
-#pragma unroll
-        for (int s = 0; s < NSLAB; ++s)
-#pragma unroll
-          for (int c = 0; c < CT; ++c) {
-            acc[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0[s][c], acc[s][c], 0, 0, 0);
-            acc[s][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1[s][c], acc[s][c], 0, 0, 0);
-          }
       }
     }
   }
+#undef PXM_STAGE_LOAD
+#undef PXM_STAGE_STORE
+#undef PXM_TAB_LOAD
 
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-  for (int s = 0; s < NSLAB; ++s) {
-    const double sg = (s == 0) ? 1.0 : t.sign1;
-    double* yb = Y + t.y_off[s] + col0 + cl + (int64_t)(t.row0 + 16 * wave + kq) * ncol;
+  for (int r = 0; r < 2; ++r) {
+    if (r >= n_my) continue;
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
+    for (int c = 0; c < NCT; ++c) {
+      const int slab = c / CT, cin = 16 * (c % CT);
+      const double sg = (slab == 0) ? 1.0 : t.sign1;
+      double* yb = Y + (slab ? t.y_off[1] : t.y_off[0]) + col0 + cin + cl + (int64_t)(t.row0 + 16 * (2 * wave + r) + kq) * ncol;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) yb[(int64_t)(4 * r) * ncol + 16 * c] = sg * acc[s][c][r];
+      for (int q = 0; q < 4; ++q) yb[(int64_t)(4 * q) * ncol] = sg * acc[r][c][q];
+    }
   }
 }
 
@@ -160,7 +217,7 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double*
 // ---------------------------------------------------------------------------------------
 void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, int x_L, int x_Rp,
                        int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
-                       std::vector<GemmTask>& tasks) {
+                       const double* ws_base, std::vector<GemmTask>& tasks) {
   const bool e2r = kind_el_to_ring(kind);
   const int Rp = T.Rp;
   // heavy tasks first: the dispatcher hands workgroups out in order, so longest-first balances CUs
@@ -180,9 +237,9 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
     }
     rt_stride = (int64_t)((k_end - k_beg) / 8) * 128;
     const int n_rt_total = (Rp - row_beg) / 16;
-    for (int rt = 0; rt < n_rt_total; rt += 4) {
+    for (int rt = 0; rt < n_rt_total; rt += 8) {
       GemmTask g;
-      g.tab = T.d_tab[kind] + T.m_off[kind][i] + (int64_t)rt * rt_stride;
+      g.tab_off = (T.d_tab[kind] + T.m_off[kind][i] + (int64_t)rt * rt_stride) - ws_base;
       g.rt_stride = rt_stride;
       g.x_off[0] = x_base + (int64_t)(m + x_L - 1) * x_Rp * ncol;
       g.y_off[0] = y_base + (int64_t)(m + y_L - 1) * y_Rp * ncol;
@@ -198,11 +255,11 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
         g.x_off[1] = g.x_off[0];
         g.y_off[1] = g.y_off[0];
       }
-      g.kscale = kscale;
+      g.ks_off = kscale ? (kscale - ws_base) : 0;
       g.k_beg = k_beg;
       g.k_end = k_end;
       g.row0 = row_beg + 16 * rt;
-      g.n_rt = std::min(4, n_rt_total - rt);
+      g.n_rt = std::min(8, n_rt_total - rt);
       g.sign1 = (m & 1) ? -1.0 : 1.0;
       tasks.push_back(g);
     }
@@ -259,7 +316,7 @@ static int build_kind(ShtTables& T, int kind, const double* d_B, const double* d
   int64_t total = 0;
   for (int i = 0; i < T.n_m; ++i) {
     const int elmin = std::max(std::abs(T.m_of(i)), std::abs(T.spin));
-    const int kb = e2r ? round_down(elmin, 8) : round_down(elmin, 16);
+    const int kb = round_down(elmin, 16);  // contraction runs in 16-k chunks, output row tiles are 16 rows
     T.k_beg[kind][i] = kb;
     T.m_off[kind][i] = total;
     if (e2r) total += (int64_t)(Rp / 16) * ((Rp - kb) / 8) * 128;

@@ -61,6 +61,13 @@ class ForwardOperator:
             self._data_dev = ops.as_device(self.data).reshape(-1)
         return self._data_dev
 
+    @property
+    def data_dev_c128(self):
+        """data as complex128 on the GPU (cached: the fused wavelet step reads it every iteration)"""
+        if getattr(self, "_data_c128", None) is None:
+            self._data_c128 = self.data_dev.to(torch.complex128).contiguous()
+        return self._data_c128
+
     def _resid_dtype(self, preds):
         return torch.complex128 if (preds.is_complex() or self.data_dev.is_complex() or self.invcov.diag.is_complex()) else torch.float64
 

@@ -244,7 +244,7 @@ class MYULA(PxMCMC):
         if self._fused_wav:
             f = self.forward
             return f.transform._plan.gradg_step(
-                X, preds, f.data_dev.to(torch.complex128), f.invcov.diag, self.prior.T_dev, delta, self.lmda, **kw
+                X, preds, f.data_dev_c128, f.invcov.diag, self.prior.T_dev, delta, self.lmda, **kw
             )
         gradg = ops.as_device(self.forward.calc_gradg(preds), X.dtype)
         if self._fused_prox:
