@@ -183,6 +183,14 @@ int make_dft_plan(int L, DftPlan* p) {
       R2 >>= 1;
     }
     p->R2 = R2;
+    p->use3 = (b.M == 1024) && !getenv("PXM_DFT_NO_W");
+    if (p->use3) {
+      const char* e3 = getenv("PXM_DFT_R3");
+      int R3 = e3 ? atoi(e3) : 4;
+      if (R3 != 1 && R3 != 2 && R3 != 4 && R3 != 8) R3 = 4;
+      p->R3 = R3;
+      dft3_geometry(b.n, R3, &p->threads3, &p->lds3);
+    }
   }
   static bool attr_set = false;
   if (!attr_set) {
@@ -219,6 +227,7 @@ static DftArgs make_args(const DftPlan& p) {
 }
 
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream) {
+  if (p.use3) return dft3_px2ring(p, in, G, ncol, C, stream);
   if (p.use2) return dft2_px2ring(p, in, G, ncol, C, stream);
   const int Cp = ncol / 2;
   dim3 grid(p.L, (Cp + p.R - 1) / p.R), block(p.threads);
@@ -228,6 +237,7 @@ int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C,
 }
 
 int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
+  if (p.use3) return dft3_ring2px(p, G, ncol, out, C, stream);
   if (p.use2) return dft2_ring2px(p, G, ncol, out, C, stream);
   dim3 grid(p.L, (C + p.R - 1) / p.R), block(p.threads);
   hipLaunchKernelGGL(k_ring2px, grid, block, p.lds, stream, make_args(p), G, ncol, out, C);

@@ -87,9 +87,12 @@ struct Dft2Args {
 
 // Bluestein core on one ring.  On entry x[j1] (j1 < M1/2) holds a[j1*M2 + l] for this thread's
 // column l; on return x[j1] (j1 < M1/2) holds the circular convolution at j = j1*M2 + l.
+// The column<->row transposes go through LDS one real plane at a time (re, then im): the plane is
+// M1 x (M2+1) doubles, half the footprint of a complex tile, which doubles the workgroups per CU.
 template <int M1, int M2>
-__device__ __forceinline__ void bluestein2(double2 (&x)[M1], double2* mat, int l, const Dft2Args& a) {
+__device__ __forceinline__ void bluestein2(double2 (&x)[M1], double* mat, int l, const Dft2Args& a) {
   constexpr int PITCH = M2 + 1;
+  double2 y[M2];
   if (l < M2) {
 #pragma unroll
     for (int j1 = M1 / 2; j1 < M1; ++j1) x[j1] = double2{0.0, 0.0};
@@ -97,32 +100,57 @@ __device__ __forceinline__ void bluestein2(double2 (&x)[M1], double2* mat, int l
 #pragma unroll
     for (int i = 0; i < M1; ++i) {
       const int k1 = bitrev_c(i, M1);
-      mat[k1 * PITCH + l] = cmul(x[i], a.twm[l * M1 + k1]);
+      x[i] = cmul(x[i], a.twm[l * M1 + k1]);
+      mat[k1 * PITCH + l] = x[i].x;
     }
   }
   __syncthreads();
   if (l < M1) {
-    double2 y[M2];
 #pragma unroll
-    for (int j2 = 0; j2 < M2; ++j2) y[j2] = mat[l * PITCH + j2];
+    for (int j2 = 0; j2 < M2; ++j2) y[j2].x = mat[l * PITCH + j2];
+  }
+  __syncthreads();
+  if (l < M2) {
+#pragma unroll
+    for (int i = 0; i < M1; ++i) mat[bitrev_c(i, M1) * PITCH + l] = x[i].y;
+  }
+  __syncthreads();
+  if (l < M1) {
+#pragma unroll
+    for (int j2 = 0; j2 < M2; ++j2) y[j2].y = mat[l * PITCH + j2];
     fft_dif<M2, -1, false>(y);
 #pragma unroll
     for (int i = 0; i < M2; ++i) y[i] = cmul(y[i], a.bhatn[l + M1 * bitrev_c(i, M2)]);
     fft_dit<M2, +1, false>(y);
 #pragma unroll
-    for (int j2 = 0; j2 < M2; ++j2) mat[l * PITCH + j2] = cmulc(y[j2], a.twm[j2 * M1 + l]);
+    for (int j2 = 0; j2 < M2; ++j2) y[j2] = cmulc(y[j2], a.twm[j2 * M1 + l]);
+  }
+  __syncthreads();  // everyone has read the imaginary plane
+  if (l < M1) {
+#pragma unroll
+    for (int j2 = 0; j2 < M2; ++j2) mat[l * PITCH + j2] = y[j2].x;
   }
   __syncthreads();
   if (l < M2) {
 #pragma unroll
-    for (int i = 0; i < M1; ++i) x[i] = mat[bitrev_c(i, M1) * PITCH + l];
+    for (int i = 0; i < M1; ++i) x[i].x = mat[bitrev_c(i, M1) * PITCH + l];
+  }
+  __syncthreads();
+  if (l < M1) {
+#pragma unroll
+    for (int j2 = 0; j2 < M2; ++j2) mat[l * PITCH + j2] = y[j2].y;
+  }
+  __syncthreads();
+  if (l < M2) {
+#pragma unroll
+    for (int i = 0; i < M1; ++i) x[i].y = mat[bitrev_c(i, M1) * PITCH + l];
     fft_dit<M1, +1, true>(x);
   }
   __syncthreads();  // mat may now be reused as the layout-transpose stage
 }
 
 template <int M1, int M2>
-__global__ __launch_bounds__(256) void k_px2ring2(Dft2Args a, PxIn in, double* __restrict__ G, int ncol, int C) {
+__global__ __launch_bounds__(256, 2) void k_px2ring2(Dft2Args a, PxIn in, double* __restrict__ G, int ncol, int C) {
   constexpr int TPR = M1 > M2 ? M1 : M2, PITCH = M2 + 1;
   extern __shared__ double2 lds2[];
   const int R = a.R, n = a.n;
@@ -130,7 +158,7 @@ __global__ __launch_bounds__(256) void k_px2ring2(Dft2Args a, PxIn in, double* _
   const int t = blockIdx.x, c0 = blockIdx.y * R;
   const int c = c0 + r;
   const bool live = r < R;
-  double2* mat = lds2 + (live ? r : 0) * (M1 * PITCH);
+  double* mat = reinterpret_cast<double*>(lds2) + (live ? r : 0) * (M1 * PITCH);
   double2 x[M1];
   if (live && l < M2) {
 #pragma unroll
@@ -174,7 +202,7 @@ __global__ __launch_bounds__(256) void k_px2ring2(Dft2Args a, PxIn in, double* _
 }
 
 template <int M1, int M2>
-__global__ __launch_bounds__(256) void k_ring2px2(Dft2Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
+__global__ __launch_bounds__(256, 2) void k_ring2px2(Dft2Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
   constexpr int TPR = M1 > M2 ? M1 : M2, PITCH = M2 + 1;
   extern __shared__ double2 lds2[];
   const int R = a.R, n = a.n;
@@ -184,16 +212,33 @@ __global__ __launch_bounds__(256) void k_ring2px2(Dft2Args a, const double* __re
   const bool live = r < R;
   const int Cp = ncol >> 1;
   double2* stage = lds2;
-  for (int idx = threadIdx.x; idx < n * R; idx += blockDim.x) {
-    const int k = idx / R, rr = idx - k * R;
-    double2 v{0.0, 0.0};
-    if (c0 + rr < Cp) {
-      const int m = (k < a.L) ? k : k - n;
-      v = reinterpret_cast<const double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + t) * Cp + c0 + rr];
-      v.y = -v.y;  // inverse DFT by conjugation: y = conj(DFT(conj x))
-      v = cmul(v, a.chirp[k]);
+  {
+    // gather in batches of 8 independent loads so the memory latency is paid once per batch
+    constexpr int U = 8;
+    const int total = n * R;
+    for (int base = threadIdx.x; base < total; base += U * blockDim.x) {
+      double2 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * blockDim.x;
+        const int k = idx / R, rr = idx - k * R;
+        v[u] = double2{0.0, 0.0};
+        if (idx < total && c0 + rr < Cp) {
+          const int m = (k < a.L) ? k : k - n;
+          v[u] = reinterpret_cast<const double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + t) * Cp + c0 + rr];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * blockDim.x;
+        if (idx < total) {
+          const int k = idx / R, rr = idx - k * R;
+          double2 w = v[u];
+          w.y = -w.y;  // inverse DFT by conjugation: y = conj(DFT(conj x))
+          stage[k * (R + 1) + rr] = cmul(w, a.chirp[k]);
+        }
+      }
     }
-    stage[k * (R + 1) + rr] = v;
   }
   __syncthreads();
   double2 x[M1];
@@ -205,34 +250,62 @@ __global__ __launch_bounds__(256) void k_ring2px2(Dft2Args a, const double* __re
     }
   }
   __syncthreads();
-  double2* mat = lds2 + (live ? r : 0) * (M1 * PITCH);
+  double* mat = reinterpret_cast<double*>(lds2) + (live ? r : 0) * (M1 * PITCH);
   bluestein2<M1, M2>(x, mat, live ? l : TPR, a);
   if (!(live && l < M2) || c >= C) return;
+  constexpr int H = M1 / 2;
+  const int64_t e0 = out.ring0 + (int64_t)t * n + l;  // element of j1 = 0; j1 advances by M2
+  const int64_t ce0 = (int64_t)c * out.chain_stride + e0;
+  if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+    // in groups of EB elements: all loads of a group first (independent), then its arithmetic
+    constexpr int EB = H < 4 ? H : 4;
 #pragma unroll
-  for (int j1 = 0; j1 < M1 / 2; ++j1) {
-    const int p = j1 * M2 + l;
-    if (p >= n) continue;
-    double2 y = cmul(x[j1], a.chirp[p]);
-    y.y = -y.y;
-    const int64_t e = out.ring0 + (int64_t)t * n + p;
-    const int64_t ce = (int64_t)c * out.chain_stride + e;
-    if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
-      const double2 xs = reinterpret_cast<const double2*>(out.X)[ce];
-      const double T = out.T ? out.T[e] : out.T_scalar;
-      const double2 px = soft_cplx(xs, T);
-      double2 w;
-      if (out.noise) {
-        if (out.noise_complex) w = reinterpret_cast<const double2*>(out.noise)[ce];
-        else w = double2{out.noise[ce], 0.0};
-      } else if (out.noise_complex) {
-        NormalPair q = philox_normal_pair(out.seed, out.chain0 + c, (uint64_t)e, out.iter);
-        w = double2{q.z0, q.z1};
-      } else {
-        w = double2{philox_normal_real(out.seed, out.chain0 + c, (uint64_t)e, out.iter), 0.0};
+    for (int g0 = 0; g0 < H; g0 += EB) {
+      double2 xs[EB], wn[EB];
+      double Ts[EB];
+#pragma unroll
+      for (int u = 0; u < EB; ++u) {
+        const int j1 = g0 + u;
+        const bool ok = j1 * M2 + l < n;
+        const int64_t off = (int64_t)j1 * M2;
+        xs[u] = ok ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
+        Ts[u] = (ok && out.T) ? out.T[e0 + off] : out.T_scalar;
+        wn[u] = double2{0.0, 0.0};
+        if (ok && out.noise) {
+          if (out.noise_complex) wn[u] = reinterpret_cast<const double2*>(out.noise)[ce0 + off];
+          else wn[u].x = out.noise[ce0 + off];
+        }
       }
-      y = chain_step_cplx(xs, px, y, w, out.delta, out.lmda);
+#pragma unroll
+      for (int u = 0; u < EB; ++u) {
+        const int j1 = g0 + u;
+        const int p = j1 * M2 + l;
+        if (p >= n) continue;
+        const int64_t off = (int64_t)j1 * M2;
+        double2 y = cmul(x[j1], a.chirp[p]);
+        y.y = -y.y;
+        double2 w = wn[u];
+        if (!out.noise) {
+          if (out.noise_complex) {
+            NormalPair q = philox_normal_pair(out.seed, out.chain0 + c, (uint64_t)(e0 + off), out.iter);
+            w = double2{q.z0, q.z1};
+          } else {
+            w = double2{philox_normal_real(out.seed, out.chain0 + c, (uint64_t)(e0 + off), out.iter), 0.0};
+          }
+        }
+        reinterpret_cast<double2*>(out.f)[ce0 + off] =
+            chain_step_cplx(xs[u], soft_cplx(xs[u], Ts[u]), y, w, out.delta, out.lmda);
+      }
     }
-    reinterpret_cast<double2*>(out.f)[ce] = y;
+  } else {
+#pragma unroll
+    for (int j1 = 0; j1 < H; ++j1) {
+      const int p = j1 * M2 + l;
+      if (p >= n) continue;
+      double2 y = cmul(x[j1], a.chirp[p]);
+      y.y = -y.y;
+      reinterpret_cast<double2*>(out.f)[ce0 + (int64_t)j1 * M2] = y;
+    }
   }
 }
 
@@ -282,8 +355,8 @@ void dft2_geometry(int M, int n, int R, int* threads, size_t* lds) {
   dft2_factors(M, &M1, &M2);
   const int tpr = std::max(M1, M2);
   *threads = round_up(R * tpr, 64);
-  const size_t mat = (size_t)R * M1 * (M2 + 1), stage = (size_t)n * (R + 1);
-  *lds = std::max(mat, stage) * 16;
+  const size_t mat = (size_t)R * M1 * (M2 + 1) * 8, stage = (size_t)n * (R + 1) * 16;
+  *lds = std::max(mat, stage);
 }
 
 template <int M1, int M2>

@@ -86,6 +86,10 @@ struct DftPlan {
   int R2 = 0, threads2 = 0;
   size_t lds2 = 0;
   double *d_bhatn = nullptr, *d_twm = nullptr;
+  // wave-per-ring path (dft3.hip), used when M == 1024
+  bool use3 = false;
+  int R3 = 0, threads3 = 0;
+  size_t lds3 = 0;
 };
 
 int make_dft_plan(int L, DftPlan* p);
@@ -118,6 +122,9 @@ int dft2_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm)
 void dft2_geometry(int M, int n, int R, int* threads, size_t* lds);
 int dft2_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft2_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
+void dft3_geometry(int n, int R, int* threads, size_t* lds);
+int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
+int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
 
 // f(t,p) -> G[m][t][c]  (unnormalised, e^{-i m phi});  G -> f (e^{+i m phi})
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream);

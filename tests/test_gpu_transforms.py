@@ -11,7 +11,10 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(1.0, np.abs(b).max())
 
 
-@pytest.mark.parametrize("L,spin,C", [(10, 0, 1), (10, 2, 3), (24, 0, 16), (17, 2, 9), (64, 0, 4), (33, -2, 2)])
+# L = 129 / 160 exercise the wave-per-ring DFT (Bluestein M = 1024), L <= 128 the register-FFT path
+@pytest.mark.parametrize(
+    "L,spin,C", [(10, 0, 1), (10, 2, 3), (24, 0, 16), (17, 2, 9), (64, 0, 4), (33, -2, 2), (129, 0, 5), (160, 2, 3)]
+)
 def test_sht_four_ops_match_oracle(L, spin, C):
     from oracle import ssht
     from pxmcmc_amd import ops
@@ -49,7 +52,7 @@ def test_sht_single_chain_1d_and_roundtrip():
     assert _rel(back, flm) < TOL
 
 
-@pytest.mark.parametrize("L,B,J_min,C", [(10, 2, 2, 1), (10, 2, 2, 5), (32, 1.5, 2, 2), (64, 2, 2, 16)])
+@pytest.mark.parametrize("L,B,J_min,C", [(10, 2, 2, 1), (10, 2, 2, 5), (32, 1.5, 2, 2), (64, 2, 2, 16), (144, 2, 3, 3)])
 def test_wavelet_ops_match_oracle(L, B, J_min, C):
     from oracle import s2let
     from pxmcmc_amd import ops
@@ -69,3 +72,40 @@ def test_wavelet_ops_match_oracle(L, B, J_min, C):
         got = getattr(plan, name)(arg).cpu().numpy()
         ref = np.stack([fn(x) for x in arg])
         assert _rel(got, ref) < TOL, name
+
+
+def test_full_size_properties_L256():
+    """BASELINE.json full size (L=256, B=2, J_min=2, 16 chains): size-independent properties the
+    reference's own tests use -- exact round trip, adjoint dot tests, and int f = f00 sqrt(4 pi)."""
+    import torch
+
+    from pxmcmc_amd import ops, utils
+
+    L, C = 256, 16
+    g = torch.Generator(device="cpu").manual_seed(0)
+    sht = ops.ShtPlan(L, 0, max_chains=C)
+    flm = torch.randn(C, L * L, dtype=torch.complex128, generator=g)
+    f = sht.inverse(flm)
+    back = sht.forward(f).cpu()
+    assert (back - flm).abs().max() < 1e-10 * flm.abs().max()
+    x = torch.randn(C, L * (2 * L - 1), dtype=torch.complex128, generator=g)
+    for fwd, adj, a, b in ((sht.inverse, sht.inverse_adjoint, flm, x), (sht.forward, sht.forward_adjoint, x, flm)):
+        lhs = torch.sum(torch.conj(b.cuda()) * fwd(a), dim=1)
+        rhs = torch.sum(torch.conj(adj(b)) * a.cuda(), dim=1)
+        assert ((lhs - rhs).abs() / lhs.abs()).max() < 1e-10
+    w = torch.as_tensor(utils.mw_map_weights(L), device="cuda")
+    integ = (f * w).sum(dim=1).cpu()
+    assert (integ - flm[:, 0] * np.sqrt(4 * np.pi)).abs().max() < 1e-9
+    del sht
+    wav = ops.WavPlan(L, 2.0, 2, max_chains=C)
+    assert wav.ncoefs == 305060
+    # analysis then synthesis reproduces a band-limited image (admissibility of the tiling)
+    rec = wav.synthesis(wav.analysis(f))
+    assert (rec - f).abs().max() < 1e-9 * f.abs().max()
+    X = torch.randn(C, wav.ncoefs, dtype=torch.complex128, generator=g)
+    lhs = torch.sum(torch.conj(x.cuda()) * wav.synthesis(X), dim=1)
+    rhs = torch.sum(torch.conj(wav.synthesis_adjoint(x)) * X.cuda(), dim=1)
+    assert ((lhs - rhs).abs() / lhs.abs()).max() < 1e-10
+    # linearity across the chain batch: chain c of a batch == the same chain run alone
+    one = wav.synthesis(X[3])
+    assert (one - wav.synthesis(X)[3]).abs().max() == 0
