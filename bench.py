@@ -81,17 +81,15 @@ def main():
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    from pxmcmc_amd import distributed as D
+
+    rank, local_rank, world = D.env_rank_world()
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    D.init(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from pxmcmc_amd import ops
     from pxmcmc_amd._lib import lib
@@ -108,7 +106,8 @@ def main():
     op = SphericalWaveletTransformOperator(data, SIGMA, "synthesis", L, B, J_MIN, max_chains=C)
     reg = S2_Wavelets_L1("synthesis", op.transform.inverse, op.transform.inverse_adjoint, LMDA * MU, L=L, B=B, J_min=J_MIN)
     params = PxMCMCParams(lmda=LMDA, delta=DELTA, mu=MU, nsamples=1, nburn=0, ngap=1, verbosity=0)
-    sampler = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=rank * C)
+    first_chain, _ = D.shard_chains(world * C, rank, world)  # weak scaling: C chains per GPU
+    sampler = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain)
     sampler._prepare()
     assert sampler._fused_wav, "the fused wavelet path must be the one benchmarked"
     with contextlib.redirect_stdout(io.StringIO()):
@@ -119,10 +118,7 @@ def main():
         X = sampler._advance(X, preds, i)          # calc_gradg + proxf + chain_step
         preds = op.forward(X)                      # forward model of the proposal
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = D.barrier
 
     for i in range(args.warmup):
         step(i)
@@ -140,10 +136,7 @@ def main():
     lib.pxm_profile_enable(0)
     assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
 
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = D.max_over_ranks(dt)
 
     if rank == 0:
         value = world * C * args.steps / dt

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace pxm {
 
@@ -224,6 +225,12 @@ struct pxm_wav_plan_s {
   TaskList ana_fwd, ana_inv, anadj_invadj, anadj_fwdadj;  // analysis / analysis-adjoint stages
   CombineArgs comb_syn, comb_ana;
   int64_t table_bytes[2] = {0, 0};
+  // side streams: the DFT launches of the small scales are latency-bound (a few workgroups each);
+  // they run beside the large scales' launches instead of in front of them
+  static constexpr int NSIDE = 3;
+  hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
+  std::vector<int> lane_of;  // per scale: -1 = caller's stream, else side stream index
 };
 
 extern "C" {
@@ -344,6 +351,18 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   p->comb_syn = c;
   c.kc = p->d_kc_ana;
   p->comb_ana = c;
+  // scales at the full bandlimit stay on the caller's stream; the rest are dealt over the side streams
+  p->lane_of.assign(p->nsc, -1);
+  if (!getenv("PXM_NO_SIDE_STREAMS")) {
+    for (int i = 0; i < pxm_wav_plan_s::NSIDE; ++i) {
+      PXM_HIP(hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking));
+      PXM_HIP(hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming));
+    }
+    PXM_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    int k = 0;
+    for (int s = p->nsc - 1; s >= 0; --s)
+      if (p->bl[s] < L) p->lane_of[s] = (k++) % pxm_wav_plan_s::NSIDE;
+  }
   *plan = p;
   return 0;
 }
@@ -355,6 +374,11 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   if (p->ws) (void)hipFree(p->ws);
   if (p->d_kc_syn) (void)hipFree(p->d_kc_syn);
   if (p->d_kc_ana) (void)hipFree(p->d_kc_ana);
+  for (int i = 0; i < pxm_wav_plan_s::NSIDE; ++i) {
+    if (p->side[i]) (void)hipStreamDestroy(p->side[i]);
+    if (p->ev_join[i]) (void)hipEventDestroy(p->ev_join[i]);
+  }
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj,
                      &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj};
   for (TaskList* t : tls)
@@ -384,27 +408,61 @@ static int launch_combine(const CombineArgs& c, const double* ws, double* HL, hi
 }
 
 // coefficient blocks -> G_s (scales' px2ring) ; G_s -> coefficient blocks (ring2px with optional fused update)
-static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st) {
+// fork: side streams wait for everything already enqueued on the caller's stream
+static int wav_fork(pxm_wav_plan_t p, hipStream_t st, bool used[pxm_wav_plan_s::NSIDE]) {
+  for (int i = 0; i < pxm_wav_plan_s::NSIDE; ++i) used[i] = false;
+  if (!p->ev_fork) return 0;
+  PXM_HIP(hipEventRecord(p->ev_fork, st));
   for (int s = 0; s < p->nsc; ++s) {
+    const int ln = p->lane_of[s];
+    if (ln >= 0 && !used[ln]) {
+      used[ln] = true;
+      PXM_HIP(hipStreamWaitEvent(p->side[ln], p->ev_fork, 0));
+    }
+  }
+  return 0;
+}
+// join: the caller's stream waits for every side stream that got work
+static int wav_join(pxm_wav_plan_t p, hipStream_t st, const bool used[pxm_wav_plan_s::NSIDE]) {
+  for (int i = 0; i < pxm_wav_plan_s::NSIDE; ++i)
+    if (used[i]) {
+      PXM_HIP(hipEventRecord(p->ev_join[i], p->side[i]));
+      PXM_HIP(hipStreamWaitEvent(st, p->ev_join[i], 0));
+    }
+  return 0;
+}
+static inline hipStream_t wav_stream(pxm_wav_plan_t p, int s, hipStream_t st) {
+  return p->lane_of[s] >= 0 ? p->side[p->lane_of[s]] : st;
+}
+
+// coefficient blocks -> G_s (scales' px2ring) ; G_s -> coefficient blocks (ring2px with optional fused update)
+static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st) {
+  bool used[pxm_wav_plan_s::NSIDE];
+  int rc = wav_fork(p, st, used);
+  if (rc) return rc;
+  for (int s = p->nsc - 1; s >= 0; --s) {  // largest first
     PxIn in;
     in.f = (const double*)X;
     in.chain_stride = p->ncoefs;
     in.ring0 = p->coef_off[s];
-    int rc = launch_px2ring(p->dft[s], in, p->ws + p->offG[s], p->ncol, C, st);
+    rc = launch_px2ring(p->dft[s], in, p->ws + p->offG[s], p->ncol, C, wav_stream(p, s, st));
     if (rc) return rc;
   }
-  return 0;
+  return wav_join(p, st, used);
 }
 
 static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
-  for (int s = 0; s < p->nsc; ++s) {
+  bool used[pxm_wav_plan_s::NSIDE];
+  int rc = wav_fork(p, st, used);
+  if (rc) return rc;
+  for (int s = p->nsc - 1; s >= 0; --s) {
     PxOut out = proto;
     out.chain_stride = p->ncoefs;
     out.ring0 = p->coef_off[s];
-    int rc = launch_ring2px(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, st);
+    rc = launch_ring2px(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, wav_stream(p, s, st));
     if (rc) return rc;
   }
-  return 0;
+  return wav_join(p, st, used);
 }
 
 int pxm_wav_synthesis(pxm_wav_plan_t p, const void* X, void* f, int C, pxm_stream_t stream) {

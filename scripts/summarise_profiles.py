@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""Turn raw rocprofv3 output (gpurun_out/<tag>/...) into the committed summaries under profiles/.
+
+  python scripts/summarise_profiles.py r01a r01
+writes profiles/<name>_kernel_stats.csv (rocprofv3 --stats table, verbatim),
+       profiles/<name>_summary.md       (per-kernel table + GEMM launch classes + HBM traffic),
+       profiles/pmc_summary.json         (HBM bytes per k_sht_gemm launch, read by bench.py).
+HBM traffic follows MI355X_MICROARCH.md section HBM: FETCH_SIZE / WRITE_SIZE are in KiB, collected in
+separate --pmc passes; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, so the
+read side is doubled; WRITE_SIZE is taken as is.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    hits = sorted(glob.glob(os.path.join(src, pattern)))
+    return hits[-1] if hits else None
+
+
+stats = one("trace/*/*_kernel_stats.csv")
+shutil.copy(stats, os.path.join(dst, f"{name}_kernel_stats.csv"))
+rows = list(csv.DictReader(open(stats)))
+trace = list(csv.DictReader(open(one("trace/*/*_kernel_trace.csv"))))
+bench_line = [l for l in open(os.path.join(src, "trace.log")) if l.startswith("{")]
+bench = json.loads(bench_line[-1]) if bench_line else {}
+
+classes = collections.defaultdict(list)
+for r in trace:
+    if "k_sht_gemm" in r["Kernel_Name"]:
+        classes[int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+
+
+def pmc(counter, sub):
+    f = one(f"{sub}/*/*_counter_collection.csv")
+    per = collections.defaultdict(list)
+    if not f:
+        return per
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            per[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return per
+
+
+fetch, write = pmc("FETCH_SIZE", "pmc_fetch"), pmc("WRITE_SIZE", "pmc_write")
+out = [f"# rocprofv3 summary `{name}` (raw: gpurun_out/{tag}, command: bench.py --steps 100 --warmup 10)\n"]
+if bench:
+    out.append(f"bench line under the profiler: {bench['value']:.0f} samples/s, {bench['ms_per_step']:.3f} ms/step, "
+               f"GEMM avg launch {bench['roofline']['avg_launch_us']:.1f} us (live HIP events)\n")
+out.append("## kernel-trace --stats (top kernels)\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+for r in rows[:14]:
+    out.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
+out.append("\n## k_sht_gemm launch classes (by workgroup count)\n\n| workgroups | launches | avg us |\n|---|---|---|")
+for k, v in sorted(classes.items()):
+    if len(v) >= 10:
+        out.append(f"| {k} | {len(v)} | {sum(v)/len(v):.1f} |")
+summary = {}
+out.append("\n## HBM traffic per launch from PMC (FETCH_SIZE x2 gfx950 correction, WRITE_SIZE as is; KiB -> bytes)\n\n| kernel | launches | read MB | write MB | total MB |\n|---|---|---|---|---|")
+for k in sorted(fetch):
+    if k in write and len(fetch[k]) >= 4:
+        rd = 2 * 1024 * sum(fetch[k]) / len(fetch[k])
+        wr = 1024 * sum(write[k]) / len(write[k])
+        out.append(f"| `{k[:60]}` | {len(fetch[k])} | {rd/1e6:.1f} | {wr/1e6:.1f} | {(rd+wr)/1e6:.1f} |")
+        if "k_sht_gemm<2, 2>" in k:
+            summary["k_sht_gemm_hbm_bytes_per_launch"] = rd + wr
+            summary["k_sht_gemm_read_bytes"] = rd
+            summary["k_sht_gemm_write_bytes"] = wr
+open(os.path.join(dst, f"{name}_summary.md"), "w").write("\n".join(out) + "\n")
+if summary:
+    summary["source"] = f"profiles/{name}_summary.md"
+    json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+print("\n".join(out))
