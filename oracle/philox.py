@@ -3,7 +3,8 @@ numpy restatement of the device noise stream (pxmcmc_amd/csrc/philox.h) -- oracl
 infrastructure.  The reference draws from numpy's global MT19937 (pxmcmc/mcmc.py:193-195),
 which a counter-based device generator cannot reproduce; parity runs inject noise, and this
 file pins the device stream itself: Philox4x32-10 (Salmon et al. 2011) keyed by
-(seed, chain), counter (index, iteration), Box-Muller to N(0,1).
+(seed, chain), counter (index, iteration), Box-Muller to N(0,1) (float32 transcendentals,
+exact exponent handling so the tail reaches 8.5 sigma).
 """
 import numpy as np
 
@@ -51,8 +52,15 @@ def normal_pairs(seed, chain, index, it):
     b = ((r[..., 3] << np.uint64(32)) | r[..., 2]) >> np.uint64(11)
     u1 = (a.astype(np.float64) + 0.5) * 2.0 ** -53
     u2 = (b.astype(np.float64) + 0.5) * 2.0 ** -53
-    rad = np.sqrt(-2.0 * np.log(u1))
-    return rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)
+    # the device evaluates Box-Muller on its float transcendental units (csrc/philox.h box_muller_fast):
+    # the exponent of u1 exactly, log2 of the mantissa / sqrt / sin / cos in float32.  Mirrored here in
+    # float32; the hardware units differ from numpy's by a few float ulps (tests allow 2e-5 absolute).
+    mant, ex = np.frexp(u1)
+    log2u = ex.astype(np.float32) + np.log2(mant.astype(np.float32))
+    rad = np.sqrt(np.float32(-1.3862943611198906) * log2u)
+    turns = u2.astype(np.float32)
+    ang = np.float32(2 * np.pi) * turns
+    return (rad * np.cos(ang)).astype(np.float64), (rad * np.sin(ang)).astype(np.float64)
 
 
 def randn_real(n, seed, chain, it):

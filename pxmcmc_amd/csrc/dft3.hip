@@ -61,6 +61,8 @@ __device__ __forceinline__ double xchg1(double v) {
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double2 xchg2(double2 v) { return double2{xchg1(v.x), xchg1(v.y)}; }
+// lane-wise select (h is the lane's half index)
+__device__ __forceinline__ double2 sel(int h, double2 a, double2 b) { return double2{h ? a.x : b.x, h ? a.y : b.y}; }
 
 // all LDS traffic of a ring stays inside its wave: order it without a workgroup barrier
 __device__ __forceinline__ void wave_sync() {
@@ -91,11 +93,7 @@ constexpr int P33 = 33;  // LDS plane pitch (doubles)
 __device__ __forceinline__ void bluestein_w(double2 (&z)[16], double* mat, int c, int h, const Dft3Args& a) {
   // ---- step 1: column FFT over j1 (DIF, upper half zero): lane h takes the outputs k1 = 2q + h
 #pragma unroll
-  for (int p = 1; p < 16; ++p) {
-    const double2 w = w32<-1>(p);
-    const double2 t = double2{h ? w.x : 1.0, h ? w.y : 0.0};
-    z[p] = cmul(z[p], t);
-  }
+  for (int p = 1; p < 16; ++p) z[p] = sel(h, mulw<-1>(z[p], p), z[p]);
   dif16<-1>(z);  // z[i] = A[k1 = 2 br16(i) + h][c]
 #pragma unroll
   for (int i = 0; i < 16; ++i) z[i] = cmul(z[i], a.twm[c * 32 + 2 * br16(i) + h]);
@@ -106,10 +104,7 @@ __device__ __forceinline__ void bluestein_w(double2 (&z)[16], double* mat, int c
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
     const double2 o = xchg2(y[p]);
-    const double2 s = cadd(y[p], o), d = csub(o, y[p]);
-    const double2 r = double2{h ? d.x : s.x, h ? d.y : s.y};
-    const double2 w = w32<-1>(p);
-    y[p] = (p == 0) ? r : cmul(r, double2{h ? w.x : 1.0, h ? w.y : 0.0});
+    y[p] = sel(h, mulw<-1>(csub(o, y[p]), p), cadd(y[p], o));
   }
   dif16<-1>(y);  // y[i] = X[c + 32 k2], k2 = 2 br16(i) + h
 #pragma unroll
@@ -117,11 +112,9 @@ __device__ __forceinline__ void bluestein_w(double2 (&z)[16], double* mat, int c
   dit16<+1>(y);  // inverse over k2: E[p] (h = 0) / O[p] (h = 1)
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
-    const double2 w = w32<+1>(p);
-    const double2 v = (p == 0) ? y[p] : cmul(y[p], double2{h ? w.x : 1.0, h ? w.y : 0.0});
+    const double2 v = sel(h, mulw<+1>(y[p], p), y[p]);
     const double2 o = xchg2(v);
-    const double2 s = cadd(v, o), d = csub(o, v);
-    const double2 r = double2{h ? d.x : s.x, h ? d.y : s.y};  // C[c][j2 = p + 16 h]
+    const double2 r = sel(h, csub(o, v), cadd(v, o));  // C[c][j2 = p + 16 h]
     y[p] = cmulc(r, a.twm[(p + 16 * h) * 32 + c]);
   }
   // ---- step 1': column c, inverse over k1 (DIT), lane h takes the inputs k1 = 2q + h
@@ -129,17 +122,12 @@ __device__ __forceinline__ void bluestein_w(double2 (&z)[16], double* mat, int c
   PXM_PLANE_XPOSE(y, y, z, c * P33 + i + 16 * h, (2 * br16(i) + h) * P33 + c)
   dit16<+1>(z);  // E[p] / O[p]
 #pragma unroll
-  for (int p = 1; p < 16; ++p) {
-    const double2 w = w32<+1>(p);
-    z[p] = cmul(z[p], double2{h ? w.x : 1.0, h ? w.y : 0.0});
-  }
+  for (int p = 1; p < 16; ++p) z[p] = sel(h, mulw<+1>(z[p], p), z[p]);
   // wanted outputs j1 = p < 16: y[p] = E[p] + t[p]; lane 0 of the pair produces p < 8, lane 1 p >= 8
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    const double2 send = double2{h ? z[q].x : z[8 + q].x, h ? z[q].y : z[8 + q].y};
-    const double2 recv = xchg2(send);
-    const double2 mine = double2{h ? z[8 + q].x : z[q].x, h ? z[8 + q].y : z[q].y};
-    z[q] = cadd(mine, recv);
+    const double2 recv = xchg2(sel(h, z[q], z[8 + q]));
+    z[q] = cadd(sel(h, z[8 + q], z[q]), recv);
   }
 }
 

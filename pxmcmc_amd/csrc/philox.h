@@ -29,6 +29,20 @@ __host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
   }
 }
 
+// Box-Muller on the hardware transcendental units.  -2 ln(u1) keeps the full 53-bit tail range
+// (deviates up to 8.5 sigma): the exponent of u1 is taken exactly (frexp on the double), only the
+// mantissa goes through v_log_f32; the angle uses v_sin_f32 / v_cos_f32, whose argument is in turns.
+// Relative accuracy of the deviates ~1e-6 (float transcendental units) -- far below the Monte-Carlo
+// error of any chain statistic, and ~4x cheaper than the fp64 software log / sincospi.
+__device__ inline NormalPair box_muller_fast(double u1, double u2) {
+  const int ex = __builtin_amdgcn_frexp_exp(u1);                    // u1 = mant * 2^ex, mant in [0.5, 1)
+  const float mant = (float)__builtin_amdgcn_frexp_mant(u1);
+  const float log2u = (float)ex + __builtin_amdgcn_logf(mant);       // log2(u1) <= 0
+  const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * log2u);  // sqrt(-2 ln 2 * log2 u1)
+  const float turns = (float)u2;
+  return NormalPair{(double)(r * __builtin_amdgcn_cosf(turns)), (double)(r * __builtin_amdgcn_sinf(turns))};
+}
+
 // two independent N(0,1) draws for counter (index, iter) under key (seed, chain)
 __device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter) {
   const uint64_t key = seed + chain * 0x9E3779B97F4A7C15ull;
@@ -38,10 +52,7 @@ __device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, u
   const uint64_t b = (((uint64_t)c[3] << 32) | c[2]) >> 11;
   const double u1 = ((double)a + 0.5) * 0x1.0p-53;
   const double u2 = ((double)b + 0.5) * 0x1.0p-53;
-  const double r = sqrt(-2.0 * log(u1));
-  double s, co;
-  sincospi(2.0 * u2, &s, &co);
-  return NormalPair{r * co, r * s};
+  return box_muller_fast(u1, u2);
 }
 
 // real stream: element e takes draw (e & 1) of pair (e >> 1); complex stream: element e takes pair e

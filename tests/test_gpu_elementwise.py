@@ -147,11 +147,15 @@ def test_philox_stream_matches_oracle():
     r = _np(ops.randn(n, C_=3, complex_=False, seed=seed, chain0=10, it=it))
     c = _np(ops.randn(n, C_=2, complex_=True, seed=seed, chain0=4, it=it))
     for k in range(3):
-        np.testing.assert_allclose(r[k], philox.randn_real(n, seed, 10 + k, it), rtol=0, atol=5e-14)
+        np.testing.assert_allclose(r[k], philox.randn_real(n, seed, 10 + k, it), rtol=0, atol=2e-5)
     for k in range(2):
-        np.testing.assert_allclose(c[k], philox.randn_complex(n, seed, 4 + k, it), rtol=0, atol=5e-14)
+        np.testing.assert_allclose(c[k], philox.randn_complex(n, seed, 4 + k, it), rtol=0, atol=2e-5)
     big = _np(ops.randn(1 << 20, C_=1, seed=1))[0]
     assert abs(big.mean()) < 5e-3 and abs(big.std() - 1) < 5e-3
+    from scipy import stats
+
+    assert stats.kstest(big[:200000], "norm").pvalue > 1e-4  # distribution check, not only two moments
+    assert np.abs(big).max() > 4.5  # the tail is populated
     # stream is a function of (seed, chain, iteration) only: sharding-independent
     a = _np(ops.randn(100, C_=4, seed=9, chain0=0, it=3))
     b = _np(ops.randn(100, C_=2, seed=9, chain0=2, it=3))
