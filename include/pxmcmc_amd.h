@@ -46,6 +46,13 @@ int pxm_device_count(void);
 int pxm_profile_enable(int on);
 int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes);
 
+/* ---- device-resident iteration counter (HIP-graph replay of the MYULA step) -----------------
+ * When a counter is registered, every Philox-consuming kernel uses iteration = iter + *counter, read
+ * on the device at execution time, so a captured graph draws fresh noise at every replay.
+ * pxm_iter_counter_add enqueues "*counter += inc" on the stream.  NULL unregisters. */
+int pxm_set_iter_counter(uint64_t* counter_dev);
+int pxm_iter_counter_add(uint64_t inc, pxm_stream_t stream);
+
 /* ---- host-side setup helpers (no GPU needed) ------------------------------ */
 /* pys2let.pys2let_j_max(B, L, J_min)            (pxmcmc/transforms.py:75) */
 int pxm_j_max(int L, double B);

@@ -131,6 +131,7 @@ __global__ void k_ring2px(DftArgs a, const double* __restrict__ G, int ncol, PxO
     const int64_t e = out.ring0 + (int64_t)t * n + p;
     const int64_t ce = (int64_t)c * out.chain_stride + e;
     if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+    const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
       const double2 x = reinterpret_cast<const double2*>(out.X)[ce];
       const double T = out.T ? out.T[e] : out.T_scalar;
       const double2 px = soft_cplx(x, T);
@@ -139,10 +140,10 @@ __global__ void k_ring2px(DftArgs a, const double* __restrict__ G, int ncol, PxO
         if (out.noise_complex) w = reinterpret_cast<const double2*>(out.noise)[ce];
         else w = double2{out.noise[ce], 0.0};
       } else if (out.noise_complex) {
-        NormalPair q = philox_normal_pair(out.seed, out.chain0 + c, (uint64_t)e, out.iter);
+        NormalPair q = philox_normal_pair(out.seed, out.chain0 + c, (uint64_t)e, it_eff);
         w = double2{q.z0, q.z1};
       } else {
-        w = double2{philox_normal_real(out.seed, out.chain0 + c, (uint64_t)e, out.iter), 0.0};
+        w = double2{philox_normal_real(out.seed, out.chain0 + c, (uint64_t)e, it_eff), 0.0};
       }
       y = chain_step_cplx(x, px, y, w, out.delta, out.lmda);
     }

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_ring2px2(Dft2Args a, const double* _
   const int64_t e0 = out.ring0 + (int64_t)t * n + l;  // element of j1 = 0; j1 advances by M2
   const int64_t ce0 = (int64_t)c * out.chain_stride + e0;
   if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+    const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
     // in groups of EB elements: all loads of a group first (independent), then its arithmetic
     constexpr int EB = H < 4 ? H : 4;
 #pragma unroll
@@ -287,10 +288,10 @@ __global__ __launch_bounds__(256, 2) void k_ring2px2(Dft2Args a, const double* _
         double2 w = wn[u];
         if (!out.noise) {
           if (out.noise_complex) {
-            NormalPair q = philox_normal_pair(out.seed, out.chain0 + c, (uint64_t)(e0 + off), out.iter);
+            NormalPair q = philox_normal_pair(out.seed, out.chain0 + c, (uint64_t)(e0 + off), it_eff);
             w = double2{q.z0, q.z1};
           } else {
-            w = double2{philox_normal_real(out.seed, out.chain0 + c, (uint64_t)(e0 + off), out.iter), 0.0};
+            w = double2{philox_normal_real(out.seed, out.chain0 + c, (uint64_t)(e0 + off), it_eff), 0.0};
           }
         }
         reinterpret_cast<double2*>(out.f)[ce0 + off] =

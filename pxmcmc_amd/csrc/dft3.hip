@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, const double* 
   const int64_t e0 = out.ring0 + (int64_t)t * n + (8 * h) * 32 + c;  // element of q = 0; q advances by 32
   const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
   if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+    const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
 #pragma unroll
     for (int g0 = 0; g0 < 8; g0 += 4) {
       double2 xs[4], wn[4];
@@ -255,10 +256,10 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, const double* 
         double2 w = wn[u];
         if (!out.noise) {
           if (out.noise_complex) {
-            NormalPair nq = philox_normal_pair(out.seed, out.chain0 + ch, (uint64_t)(e0 + off), out.iter);
+            NormalPair nq = philox_normal_pair(out.seed, out.chain0 + ch, (uint64_t)(e0 + off), it_eff);
             w = double2{nq.z0, nq.z1};
           } else {
-            w = double2{philox_normal_real(out.seed, out.chain0 + ch, (uint64_t)(e0 + off), out.iter), 0.0};
+            w = double2{philox_normal_real(out.seed, out.chain0 + ch, (uint64_t)(e0 + off), it_eff), 0.0};
           }
         }
         reinterpret_cast<double2*>(out.f)[ce0 + off] =

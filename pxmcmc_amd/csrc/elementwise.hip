@@ -3,6 +3,7 @@
 #include "../../include/pxmcmc_amd.h"
 #include "elem.h"
 #include "common.h"
+#include "sht_core.h"
 
 namespace pxm {
 
@@ -50,6 +51,7 @@ struct NoiseSrc {
   const double* noise;
   int noise_complex;
   uint64_t seed, chain0, iter;
+  const uint64_t* iter_dev;
 };
 
 template <bool CPLX>
@@ -58,11 +60,12 @@ __device__ inline double2 draw_noise(const NoiseSrc& ns, int c, int64_t n, int64
     if (CPLX && ns.noise_complex) return reinterpret_cast<const double2*>(ns.noise)[(int64_t)c * n + i];
     return double2{ns.noise[(int64_t)c * n + i], 0.0};
   }
+  const uint64_t it = ns.iter + (ns.iter_dev ? *ns.iter_dev : 0);
   if (CPLX && ns.noise_complex) {
-    NormalPair q = philox_normal_pair(ns.seed, ns.chain0 + c, (uint64_t)i, ns.iter);
+    NormalPair q = philox_normal_pair(ns.seed, ns.chain0 + c, (uint64_t)i, it);
     return double2{q.z0, q.z1};
   }
-  return double2{philox_normal_real(ns.seed, ns.chain0 + c, (uint64_t)i, ns.iter), 0.0};
+  return double2{philox_normal_real(ns.seed, ns.chain0 + c, (uint64_t)i, it), 0.0};
 }
 
 // X_out = (1-d/l) X + (d/l) P - d g + sqrt(2d) w, with P = soft(X,T) (FUSED_PROX) or given
@@ -206,6 +209,10 @@ __global__ void k_reduce_final(const double* __restrict__ part, double* __restri
   }
 }
 
+static uint64_t* g_iter_counter = nullptr;
+const uint64_t* iter_counter() { return g_iter_counter; }
+__global__ void k_iter_add(uint64_t* c, uint64_t inc) { *c += inc; }
+
 // scratch for partial sums: one per device, grown on demand outside of stream capture
 static double* g_part = nullptr;
 static size_t g_part_cap = 0;
@@ -231,7 +238,7 @@ __global__ void k_pxmala_accept(const double* __restrict__ terms, const double* 
   if (c >= C) return;
   // logalpha = logtransXpXc + logpiXp - logtransXcXp - logpiXc   (pxmcmc/mcmc.py:244)
   const double logalpha = terms[4 * c + 0] + terms[4 * c + 1] - terms[4 * c + 2] - terms[4 * c + 3];
-  const double uu = u ? u[c] : philox_uniform(seed, chain0 + c, iter);
+  const double uu = u ? u[c] : philox_uniform(seed, chain0 + c, iter);  // iter is passed by the host every step
   const int acc = log(uu) < logalpha ? 1 : 0;
   accept[c] = acc;
   if (tune) {  // pxmcmc/mcmc.py:277-279
@@ -291,6 +298,18 @@ using namespace pxm;
 
 extern "C" {
 
+int pxm_set_iter_counter(uint64_t* counter_dev) {
+  g_iter_counter = counter_dev;
+  return 0;
+}
+
+int pxm_iter_counter_add(uint64_t inc, pxm_stream_t stream) {
+  PXM_REQUIRE(g_iter_counter, "pxm_iter_counter_add: no counter registered");
+  hipLaunchKernelGGL(k_iter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, g_iter_counter, inc);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
 int pxm_soft(const void* X, const double* T, double T_scalar, void* out, int64_t n, int C, int dtype,
              pxm_stream_t stream) {
   CHECK_ARGS("pxm_soft");
@@ -323,7 +342,7 @@ int pxm_myula_step(const void* X, const void* gradg, const double* T, double T_s
   PXM_REQUIRE(X && gradg && X_out, "pxm_myula_step: null buffer");
   PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_myula_step: complex noise needs a complex state");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter};
+  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, g_iter_counter};
   if (dtype)
     hipLaunchKernelGGL((k_chain_step<true, true>), g, b, 0, st, (const double*)X, (const double*)nullptr,
                        (const double*)gradg, T, T_scalar, delta_dev, delta, lmda, ns, (double*)X_out, n);
@@ -341,7 +360,7 @@ int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const do
   PXM_REQUIRE(X && proxf && gradg && X_out, "pxm_chain_step: null buffer");
   PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_chain_step: complex noise needs a complex state");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter};
+  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, g_iter_counter};
   if (dtype)
     hipLaunchKernelGGL((k_chain_step<true, false>), g, b, 0, st, (const double*)X, (const double*)proxf,
                        (const double*)gradg, (const double*)nullptr, 0.0, delta_dev, delta, lmda, ns, (double*)X_out, n);
@@ -357,7 +376,7 @@ int pxm_randn(void* out, int64_t n, int C, int dtype, uint64_t seed, uint64_t ch
   CHECK_ARGS("pxm_randn");
   PXM_REQUIRE(out, "pxm_randn: null buffer");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{nullptr, dtype, seed, chain0, iter};
+  NoiseSrc ns{nullptr, dtype, seed, chain0, iter, g_iter_counter};
   if (dtype) hipLaunchKernelGGL(k_randn<true>, g, b, 0, st, (double*)out, n, ns);
   else hipLaunchKernelGGL(k_randn<false>, g, b, 0, st, (double*)out, n, ns);
   PXM_HIP(hipGetLastError());

@@ -524,6 +524,7 @@ int pxm_wav_gradg_step(pxm_wav_plan_t p, const void* X, const void* preds, const
   out.seed = seed;
   out.chain0 = chain0;
   out.iter = iter;
+  out.iter_dev = iter_counter();
   return wav_synthesis_adjoint_impl(p, in, out, C, (hipStream_t)stream);
 }
 

@@ -115,7 +115,9 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
   const double* noise = nullptr;  // injected noise or null -> Philox
   int noise_complex = 0;
   uint64_t seed = 0, chain0 = 0, iter = 0;
+  const uint64_t* iter_dev = nullptr;  // optional device-resident addend to iter (graph replay)
 };
+const uint64_t* iter_counter();  // registered by pxm_set_iter_counter, or null
 
 bool dft2_supported(int M);
 int dft2_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm);

@@ -9,7 +9,8 @@ Extensions (all optional, defaults reproduce the reference's one-chain behaviour
 * ``rng``          -- ``"philox"`` (device counter-based stream keyed (seed, chain, iteration),
   independent of how chains are spread over GPUs) or ``"numpy"`` (the reference's global
   ``np.random`` stream in the reference's draw order, for parity runs);
-* ``chain_offset`` -- global index of this process's first chain (multi-GPU sharding).
+* ``chain_offset`` -- global index of this process's first chain (multi-GPU sharding);
+* ``use_graph``    -- replay the fused iteration from a captured HIP graph (default on).
 
 SKROCK (pxmcmc/mcmc.py:292-383) is out of scope.
 """
@@ -78,7 +79,8 @@ class PxMCMC:
     :param mcmcparams: :class:`PxMCMCParams`
     """
 
-    def __init__(self, forward, prior, mcmcparams=PxMCMCParams(), nchains=1, rng="philox", seed=0, chain_offset=0):
+    def __init__(self, forward, prior, mcmcparams=PxMCMCParams(), nchains=1, rng="philox", seed=0, chain_offset=0,
+                 use_graph=True):
         self.forward = forward
         self.prior = prior
         for attr in mcmcparams.__dict__.keys():
@@ -89,6 +91,7 @@ class PxMCMC:
         self.rng = rng
         self.seed = int(seed)
         self.chain_offset = int(chain_offset)
+        self.use_graph = bool(use_graph)
         self.nsamples = int(self.nsamples)
         for op in (getattr(forward, "transform", None), getattr(forward, "measurement", None)):
             if hasattr(op, "ensure_chains"):
@@ -259,12 +262,90 @@ class MYULA(PxMCMC):
         self._fused_prox = _is_stock_l1(self.prior) and type(self).chain_step is MYULA.chain_step
         self._it = 0
 
+    # ---- HIP-graph engine for the fused wavelet path ----------------------------------------------
+    def _graph_ok(self):
+        return self._fused_wav and self.rng == "philox" and self.use_graph and not bool(self.complex)
+
+    def _engine_start(self, X, preds, i0):
+        """Static ping-pong state (XA, XB, P), a device iteration counter and a captured 2-iteration graph."""
+        f = self.forward
+        plan = f.transform._plan
+        self._eng = eng = {}
+        eng["XA"], eng["XB"], eng["P"] = X.clone(), torch.empty_like(X), preds.clone()
+        eng["cnt"] = ops.IterCounter(i0)
+        eng["side"] = "A"  # which buffer holds the current state
+        args = (f.data_dev_c128, f.invcov.diag, self.prior.T_dev, float(self.delta), self.lmda)
+        kw = dict(noise_complex=False, seed=self.seed, chain0=self.chain_offset, it=0)
+
+        def one(src, dst):
+            plan.gradg_step(src, eng["P"], *args, out=dst, **kw)   # calc_gradg + proxf + chain_step
+            eng["cnt"].add(1)
+            plan.synthesis(dst, out=eng["P"])                       # forward model of the new state
+
+        eng["one"] = one
+        eng["graph"] = None
+        if self._graph_ok():
+            try:
+                stream = torch.cuda.Stream()
+                stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(stream):
+                    one(eng["XA"], eng["XB"])  # warm-up outside capture (lazy allocations, attributes)
+                    one(eng["XB"], eng["XA"])
+                torch.cuda.current_stream().wait_stream(stream)
+                torch.cuda.synchronize()
+                eng["XA"].copy_(X)
+                eng["P"].copy_(preds)
+                eng["cnt"].set(i0)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    one(eng["XA"], eng["XB"])
+                    one(eng["XB"], eng["XA"])
+                # capture does not execute: state is still (X, preds, i0)
+                eng["graph"] = g
+            except Exception as exc:  # capture unsupported in this environment: eager stepping, same results
+                eng["graph"] = None
+                eng["graph_error"] = repr(exc)
+                eng["XA"].copy_(X)
+                eng["P"].copy_(preds)
+                eng["cnt"].set(i0)
+        return eng
+
+    def _engine_advance(self, k):
+        """advance the engine's state by k MYULA iterations (graph replays of 2 + eager remainder)"""
+        eng = self._eng
+        if eng["side"] == "B" and k > 0:  # realign so that replays start from XA
+            eng["one"](eng["XB"], eng["XA"])
+            eng["side"] = "A"
+            k -= 1
+        if eng["graph"] is not None:
+            while k >= 2:
+                eng["graph"].replay()
+                k -= 2
+        while k >= 2:
+            eng["one"](eng["XA"], eng["XB"])
+            eng["one"](eng["XB"], eng["XA"])
+            k -= 2
+        if k == 1:
+            eng["one"](eng["XA"], eng["XB"])
+            eng["side"] = "B"
+
+    def _engine_state(self):
+        eng = self._eng
+        return (eng["XA"] if eng["side"] == "A" else eng["XB"]), eng["P"]
+
+    def _engine_stop(self):
+        eng = getattr(self, "_eng", None)
+        if eng is not None:
+            eng["cnt"].close()
+
     def run(self, start_point=None):
         """Run the algorithm (pxmcmc/mcmc.py:150-183)."""
         self._prepare()
         i = 0  # total samples
         j = 0  # saved samples (excludes burn-in and thinned samples)
         X_curr, curr_preds = self._initial_sample(start_point)
+        if self._fused_wav and self.rng == "philox":
+            return self._run_engine(X_curr, curr_preds)
         while j < self.nsamples:
             X_prop = self._advance(X_curr, curr_preds, i)
             prop_preds = ops.as_device(self.forward.forward(X_prop))
@@ -285,6 +366,47 @@ class MYULA(PxMCMC):
                     print("Burning in...")
             i += 1
         self.X_curr, self.curr_preds, self.niter = X_curr, curr_preds, i
+        print("\nDONE")
+
+    def _run_engine(self, X_curr, curr_preds):
+        """
+        Same schedule as the reference loop (pxmcmc/mcmc.py:157-181), but iterations between two events
+        (save / progress print) are advanced together: by HIP-graph replays when capture is available.
+        """
+        nburn, ngap, verb = int(self.nburn), int(self.ngap), int(self.verbosity)
+        self._engine_start(X_curr, curr_preds, 0)
+        try:
+            i = 0  # iterations done
+            j = 0
+            while j < self.nsamples:
+                # next iteration index (0-based) at which something observable happens
+                if i < nburn:
+                    nxt_save = nburn
+                elif ngap == 0:
+                    nxt_save = i
+                else:
+                    nxt_save = i + (-(i - nburn)) % ngap
+                nxt_print = i + (verb - 1 - i % verb) if verb > 0 else nxt_save
+                stop = min(nxt_save, nxt_print)
+                self._engine_advance(stop - i + 1)  # run iterations i..stop
+                i = stop
+                X_curr, curr_preds = self._engine_state()
+                if i >= nburn:
+                    if ngap == 0 or (i - nburn) % ngap == 0:
+                        logPi, L2, prior = self._logpi_dev(X_curr, curr_preds)
+                        self._tracking(j, X_curr, curr_preds, logPi, L2, prior)
+                        j += 1
+                    if verb > 0 and (i + 1) % verb == 0:
+                        first = (lambda a: a[j - 1] if self.nchains == 1 else a[0, j - 1])
+                        self._print_progress(j - 1, first(self.logPi), L2=first(self.L2s), prior=first(self.priors))
+                elif verb > 0 and (i + 1) % verb == 0:
+                    print("Burning in...")
+                i += 1
+            X_curr, curr_preds = self._engine_state()
+            self.X_curr, self.curr_preds, self.niter = X_curr.clone(), curr_preds.clone(), i
+            self.used_graph = self._eng["graph"] is not None
+        finally:
+            self._engine_stop()
         print("\nDONE")
 
     def chain_step(self, X, proxf, gradg):

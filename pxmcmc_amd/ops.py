@@ -283,18 +283,21 @@ class WavPlan:
             lib.pxm_wav_plan_destroy(h)
             self._h = None
 
-    def _run(self, fn, x, n_in, n_out):
+    def _run(self, fn, x, n_in, n_out, out=None):
         x, squeeze = _batched(as_device(x, _CPLX))
         if x.shape[1] != n_in:
             raise AssertionError(f"expected length {n_in}, got {x.shape[1]}")
         if x.shape[0] > self.max_chains:
             raise ValueError("more chains than the plan was created for")
-        out = torch.empty((x.shape[0], n_out), dtype=_CPLX, device=x.device)
+        if out is None:
+            out = torch.empty((x.shape[0], n_out), dtype=_CPLX, device=x.device)
+        elif out.shape != (x.shape[0], n_out) or out.dtype != _CPLX or not out.is_contiguous():
+            raise ValueError("out= buffer has the wrong shape / dtype / layout")
         check(fn(self._h, _p(x), _p(out), x.shape[0], _stream()))
         return out[0] if squeeze else out
 
-    def synthesis(self, X):
-        return self._run(lib.pxm_wav_synthesis, X, self.ncoefs, self.npix)
+    def synthesis(self, X, out=None):
+        return self._run(lib.pxm_wav_synthesis, X, self.ncoefs, self.npix, out=out)
 
     def synthesis_adjoint(self, f):
         return self._run(lib.pxm_wav_synthesis_adjoint, f, self.npix, self.ncoefs)
@@ -305,7 +308,7 @@ class WavPlan:
     def analysis_adjoint(self, X):
         return self._run(lib.pxm_wav_analysis_adjoint, X, self.ncoefs, self.npix)
 
-    def gradg_step(self, X, preds, data, invcov, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0):
+    def gradg_step(self, X, preds, data, invcov, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, out=None):
         """Fused calc_gradg + proxf + chain_step (pxmcmc/mcmc.py:158-160) for the synthesis setting."""
         x, squeeze = _batched(as_device(X, _CPLX))
         p, _ = _batched(as_device(preds, _CPLX))
@@ -317,7 +320,10 @@ class WavPlan:
             raise ValueError("data / invcov length mismatch")
         Tv, Ts = _vecT(T, self.ncoefs, x.device)
         w, wc = _noise_args(noise, x, noise_complex)
-        out = torch.empty_like(x)
+        if out is None:
+            out = torch.empty_like(x)
+        elif out.shape != x.shape or out.dtype != _CPLX or not out.is_contiguous() or out.data_ptr() == x.data_ptr():
+            raise ValueError("out= buffer must be a distinct contiguous complex128 tensor of the state's shape")
         check(
             lib.pxm_wav_gradg_step(
                 self._h, _p(x), _p(p), _p(d), _p(ic), int(ic.is_complex()), _p(Tv), Ts, float(delta), float(lmda),
@@ -328,6 +334,33 @@ class WavPlan:
 
     def table_bytes(self, op):
         return int(lib.pxm_wav_table_bytes(self._h, op))
+
+
+# ---- device-resident iteration counter (HIP-graph replay) -----------------------------------
+class IterCounter:
+    """Registers a device int64 as the Philox iteration counter for the lifetime of the object."""
+
+    def __init__(self, start=0):
+        self.t = torch.full((1,), int(start), dtype=torch.int64, device=device())
+        check(lib.pxm_set_iter_counter(C.c_void_p(self.t.data_ptr())))
+        self.active = True
+
+    def set(self, value):
+        self.t.fill_(int(value))
+
+    def add(self, inc=1):
+        check(lib.pxm_iter_counter_add(int(inc), _stream()))
+
+    def close(self):
+        if self.active:
+            lib.pxm_set_iter_counter(C.c_void_p(0))
+            self.active = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- host helpers ------------------------------------------------------------------------
