@@ -15,14 +15,49 @@ struct TaskList {
   int n = 0;
   bool paired = false;
   std::vector<int> bls;  // bandlimits of the transforms grouped in this launch (roofline accounting)
+  std::vector<int> los;  // their support cuts el_lo (0 = none)
 };
 
-static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std::vector<int> bls) {
+static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std::vector<int> bls,
+                        std::vector<int> los = {}) {
   out->bls = bls;
-  // longest first: workgroups are handed out in order, so this is the LPT rule for CU balance
-  std::stable_sort(v.begin(), v.end(), [](const GemmTask& a, const GemmTask& b) {
-    return (int64_t)(a.k_end - a.k_beg) * a.n_rt > (int64_t)(b.k_end - b.k_beg) * b.n_rt;
-  });
+  los.resize(bls.size(), 0);
+  out->los = los;
+  // Static balance.  Workgroups are placed round-robin over the CUs in launch order, and for these
+  // launches (almost) all of them are resident at once, so the order IS the schedule: assign tasks to
+  // one bin per CU by the LPT rule (longest first, always into the lightest bin), then emit round by
+  // round -- workgroup r*nbins + b is the r-th task of bin b.  A plain descending order would give
+  // CU i the tasks i and i + nbins: heaviest + median on one CU, median + lightest on another.
+  auto work = [](const GemmTask& a) { return (int64_t)(a.k_end - a.k_beg) * a.n_rt; };
+  std::stable_sort(v.begin(), v.end(), [&](const GemmTask& a, const GemmTask& b) { return work(a) > work(b); });
+  int nbins = 256;
+  if (!getenv("PXM_GEMM_PLAIN_ORDER") && (int)v.size() > nbins) {
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      nbins = prop.multiProcessorCount;
+    std::vector<std::vector<GemmTask>> bins(nbins);
+    std::vector<int64_t> load(nbins, 0);
+    for (const GemmTask& t : v) {
+      int best = 0;
+      for (int b = 1; b < nbins; ++b)
+        if (load[b] < load[best] || (load[b] == load[best] && bins[b].size() < bins[best].size())) best = b;
+      bins[best].push_back(t);
+      load[best] += work(t);
+    }
+    std::vector<GemmTask> ordered;
+    ordered.reserve(v.size());
+    for (size_t r = 0;; ++r) {
+      bool any = false;
+      for (int b = 0; b < nbins; ++b)
+        if (r < bins[b].size()) {
+          ordered.push_back(bins[b][r]);
+          any = true;
+        }
+      if (!any) break;
+    }
+    v.swap(ordered);
+  }
   out->n = (int)v.size();
   out->paired = paired;
   if (v.empty()) return 0;
@@ -37,7 +72,7 @@ static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, i
     const int ct = (ncol - col0 >= 32) ? 2 : 1;
     const int cg = std::max(0, std::min(C - col0 / 2, 8 * ct));  // live chains in this column group
     double bytes = 0;
-    for (int b : tl.bls) bytes += gemm_alg_bytes(b, tl.paired, cg);
+    for (size_t i = 0; i < tl.bls.size(); ++i) bytes += gemm_alg_bytes(tl.bls[i], tl.paired, cg, tl.los[i]);
     int rc = launch_gemm(tl.d, tl.n, tl.paired, X, Y, ncol, col0, ct, bytes, st);
     if (rc) return rc;
   }
@@ -300,30 +335,39 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   PXM_HIP(hipMalloc(&p->d_kc_ana, kc_ana.size() * sizeof(double)));
   PXM_HIP(hipMemcpy(p->d_kc_syn, kc_syn.data(), kc_syn.size() * sizeof(double), hipMemcpyHostToDevice));
   PXM_HIP(hipMemcpy(p->d_kc_ana, kc_ana.data(), kc_ana.size() * sizeof(double), hipMemcpyHostToDevice));
+  // support cut per scale: first degree with a non-zero kernel (compact support of kappa_j)
+  std::vector<int> el_lo(p->nsc, 0);
+  if (!getenv("PXM_NO_SUPPORT_CUT"))
+    for (int s = 0; s < p->nsc; ++s) {
+      int lo = 0;
+      while (lo < p->bl[s] && kc_syn[(size_t)s * p->Rp + lo] == 0.0) ++lo;
+      el_lo[s] = lo;
+    }
   // task lists
   std::vector<GemmTask> v_syn_fwd, v_adj_fwdadj, v_ana_inv, v_anadj_invadj, v;
   for (int s = 0; s < p->nsc; ++s) {
     const int b = p->bl[s], Rb = round_up(b, 16);
     // synthesis: G_s --A_s--> H_s
-    append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS, p->ws, v_syn_fwd);
+    append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS, p->ws, v_syn_fwd,
+                      el_lo[s]);
     // synthesis adjoint: H_L (scaled by c_s kappa_s per el) --A_s^T--> G_s
     append_gemm_tasks(*p->T[s], TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
-                      p->d_kc_syn + (size_t)s * p->Rp, p->offS, p->ws, v_adj_fwdadj);
+                      p->d_kc_syn + (size_t)s * p->Rp, p->offS, p->ws, v_adj_fwdadj, el_lo[s]);
     // analysis: H_L (scaled by c_a kappa_s) --B_s--> G_s
     append_gemm_tasks(*p->T[s], TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
-                      p->d_kc_ana + (size_t)s * p->Rp, p->offS, p->ws, v_ana_inv);
+                      p->d_kc_ana + (size_t)s * p->Rp, p->offS, p->ws, v_ana_inv, el_lo[s]);
     // analysis adjoint: G_s --B_s^T--> H_s
     append_gemm_tasks(*p->T[s], TAB_INV_ADJ, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS,
-                      p->ws, v_anadj_invadj);
+                      p->ws, v_anadj_invadj, el_lo[s]);
     p->table_bytes[0] += p->T[s]->bytes[TAB_FWD];
     p->table_bytes[1] += p->T[s]->bytes[TAB_FWD_ADJ];
   }
   p->table_bytes[0] += p->TL->bytes[TAB_INV];
   p->table_bytes[1] += p->TL->bytes[TAB_INV_ADJ];
-  if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl))) return rc;
-  if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl))) return rc;
-  if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl))) return rc;
-  if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl))) return rc;
+  if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl, el_lo))) return rc;
+  if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl, el_lo))) return rc;
+  if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl, el_lo))) return rc;
+  if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl, el_lo))) return rc;
   v.clear();
   append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->syn_inv, {L}))) return rc;

@@ -54,7 +54,7 @@ int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out);
 // array (x_Rp, x_L give the operand array's row padding and bandlimit for the m_idx mapping).
 void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, int x_L, int x_Rp,
                        int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
-                       const double* ws_base, std::vector<GemmTask>& tasks);
+                       const double* ws_base, std::vector<GemmTask>& tasks, int el_lo = 0);
 
 // launch: tasks on device; X/Y = workspace base; col0 = first column of this chain group, ct = column
 // tiles (1 or 2) of the group
@@ -65,12 +65,23 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double*
 // algorithmic bytes of one ring-GEMM stage at bandlimit L for C chains:
 // ring table 8*L*L*(L+1)/2 [paired] or 8*L*L*L [all m] read once, harmonic side 16*C*L*L,
 // ring side 16*C*L*(2L-1)
-inline double gemm_alg_bytes(int L, bool paired, int C) {
-  const double Ld = L;
-  const double tab = paired ? 8.0 * Ld * Ld * (Ld + 1) / 2 : 8.0 * Ld * (Ld * Ld);
-  return tab + 16.0 * C * (Ld * Ld + Ld * (2 * Ld - 1));
+// With a support cut el_lo only the degrees el >= el_lo count on the table and harmonic sides.
+inline double gemm_alg_bytes(int L, bool paired, int C, int el_lo = 0) {
+  double tab_entries = 0, lm_entries = 0;  // (m, el) pairs with el >= max(|m|, el_lo)
+  for (int m = paired ? 0 : -(L - 1); m < L; ++m) {
+    const int am = m < 0 ? -m : m;
+    const int n = L - (am > el_lo ? am : el_lo);
+    if (n > 0) tab_entries += n;
+  }
+  for (int m = -(L - 1); m < L; ++m) {
+    const int am = m < 0 ? -m : m;
+    const int n = L - (am > el_lo ? am : el_lo);
+    if (n > 0) lm_entries += n;
+  }
+  return 8.0 * L * tab_entries + 16.0 * C * (lm_entries + (double)L * (2 * L - 1));
 }
 
+int gemm_rows_per_task();
 void profile_gemm_begin(hipStream_t st);
 void profile_gemm_end(hipStream_t st, double alg_bytes);
 

@@ -9,6 +9,7 @@
 #include "../../include/pxmcmc_amd.h"
 #include "sht_core.h"
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -30,32 +31,34 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------
 constexpr int KC = 16;  // contraction rows per staged chunk
 
-template <int CT, int NSLAB>
-__global__ __launch_bounds__(256) void k_sht_gemm(const GemmTask* __restrict__ tasks,
-                                                  const double* __restrict__ X, double* __restrict__ Y,
-                                                  int ncol, int col0) {
+// NW waves per workgroup, RT row tiles of 16 rows per wave: a task covers NW*RT row tiles.
+template <int CT, int NSLAB, int NW, int RT>
+__global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict__ tasks,
+                                                      const double* __restrict__ X, double* __restrict__ Y,
+                                                      int ncol, int col0) {
   constexpr int NCT = CT * NSLAB;
   constexpr int COLS = 16 * NCT;                          // staged operand columns
   constexpr int PITCH = COLS + (COLS == 16 ? 0 : 16);     // doubles; PITCH*8 = 128 (mod 256)
   constexpr int NV = KC * COLS / 2;                       // double2 per chunk
-  constexpr int IT = (NV + 255) / 256;                    // staging loads per thread per chunk
+  constexpr int NT = 64 * NW;                             // threads per workgroup
+  constexpr int IT = (NV + NT - 1) / NT;                  // staging loads per thread per chunk
   __shared__ double xs[2][KC][PITCH];
 
   const GemmTask t = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the row-tile tests scalar
   const int kq = lane >> 4, cl = lane & 15;
-  const int n_my = min(2, max(0, t.n_rt - 2 * wave));     // row tiles of this wave
+  const int n_my = min(RT, max(0, t.n_rt - RT * wave));       // row tiles of this wave
   const int nch = (t.k_end - t.k_beg) / KC;
 
   // ---- operand staging map: thread -> (row kr, column pair) of the chunk
-  constexpr bool ALL = (NV % 256) == 0;  // every thread stages in every pass
+  constexpr bool ALL = (NV % NT) == 0;  // every thread stages in every pass
   const double* sp[IT];
   int so[IT];
   bool sv[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    const int q = tid + 256 * i;
+    const int q = tid + NT * i;
     sv[i] = ALL || q < NV;
     const int kr = (q / (COLS / 2)) % KC, col = 2 * (q % (COLS / 2));
     const int slab = col / (16 * CT), cin = col % (16 * CT);
@@ -77,27 +80,29 @@ __global__ __launch_bounds__(256) void k_sht_gemm(const GemmTask* __restrict__ t
     *reinterpret_cast<double2*>(&xs[BUF][0][0] + so[i]) = v;                                         \
   }
 
-  // ---- table stream: per row tile two double2 per chunk (k-steps {0,1} and {2,3})
+  // ---- table stream: per row tile two double2 per chunk (k-steps {0,1} and {2,3}).
   // rows this wave does not own alias row tile 0 (valid memory, results discarded); chunk indices are
   // clamped so every load is unconditional: plain global_load_dwordx4, no select, no flat access
-  const double2* tab0 = reinterpret_cast<const double2*>(X + t.tab_off + (int64_t)(n_my > 0 ? 2 * wave : 0) * t.rt_stride) + lane;
-  const double2* tab1 = reinterpret_cast<const double2*>(X + t.tab_off + (int64_t)(n_my > 1 ? 2 * wave + 1 : 0) * t.rt_stride) + lane;
+  const double2* tab[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r)
+    tab[r] = reinterpret_cast<const double2*>(X + t.tab_off + (int64_t)(n_my > r ? RT * wave + r : 0) * t.rt_stride) + lane;
   const bool v0 = n_my > 0;
   // three register sets used round-robin with compile-time indices (no register rotation: a copy
   // of an in-flight load would force a full vmcnt(0) drain every chunk)
-  double2 A[3][2][2];
+  double2 A[3][RT][2];
 #define PXM_TAB_LOAD(SET, CH)                                                 \
   {                                                                           \
     const int cc = min((CH), nch - 1);                                        \
-    A[SET][0][0] = tab0[(int64_t)(2 * cc) * 64];                              \
-    A[SET][0][1] = tab0[(int64_t)(2 * cc + 1) * 64];                          \
-    A[SET][1][0] = tab1[(int64_t)(2 * cc) * 64];                              \
-    A[SET][1][1] = tab1[(int64_t)(2 * cc + 1) * 64];                          \
+    _Pragma("unroll") for (int r = 0; r < RT; ++r) {                          \
+      A[SET][r][0] = tab[r][(int64_t)(2 * cc) * 64];                          \
+      A[SET][r][1] = tab[r][(int64_t)(2 * cc + 1) * 64];                      \
+    }                                                                         \
   }
 
-  d4 acc[2][NCT];
+  d4 acc[RT][NCT];
 #pragma unroll
-  for (int r = 0; r < 2; ++r)
+  for (int r = 0; r < RT; ++r)
 #pragma unroll
     for (int c = 0; c < NCT; ++c) acc[r][c] = d4{0, 0, 0, 0};
 
@@ -120,12 +125,12 @@ __global__ __launch_bounds__(256) void k_sht_gemm(const GemmTask* __restrict__ t
             double b[NCT];
 #pragma unroll
             for (int c = 0; c < NCT; ++c) b[c] = xs[buf][4 * h4 + kq][16 * c + cl];
-            const double a0 = (h4 & 1) ? A[u][0][h4 >> 1].y : A[u][0][h4 >> 1].x;
-            const double a1 = (h4 & 1) ? A[u][1][h4 >> 1].y : A[u][1][h4 >> 1].x;
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b[c], acc[0][c], 0, 0, 0);
+            for (int r = 0; r < RT; ++r) {
+              const double av = (h4 & 1) ? A[u][r][h4 >> 1].y : A[u][r][h4 >> 1].x;
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b[c], acc[1][c], 0, 0, 0);
+              for (int c = 0; c < NCT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[c], acc[r][c], 0, 0, 0);
+            }
           }
         }
       }
@@ -137,13 +142,13 @@ __global__ __launch_bounds__(256) void k_sht_gemm(const GemmTask* __restrict__ t
 
   // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+  for (int r = 0; r < RT; ++r) {
     if (r >= n_my) continue;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
       const int slab = c / CT, cin = 16 * (c % CT);
       const double sg = (slab == 0) ? 1.0 : t.sign1;
-      double* yb = Y + (slab ? t.y_off[1] : t.y_off[0]) + col0 + cin + cl + (int64_t)(t.row0 + 16 * (2 * wave + r) + kq) * ncol;
+      double* yb = Y + (slab ? t.y_off[1] : t.y_off[0]) + col0 + cin + cl + (int64_t)(t.row0 + 16 * (RT * wave + r) + kq) * ncol;
 #pragma unroll
       for (int q = 0; q < 4; ++q) yb[(int64_t)(4 * q) * ncol] = sg * acc[r][c][q];
     }
@@ -195,18 +200,34 @@ int profile_read(double* ms, int64_t* launches, double* bytes) {
   return 0;
 }
 
+// GEMM workgroup geometry: NW waves x RT row tiles per wave (a task covers NW*RT row tiles).
+// Default 8 x 1: same operand staging traffic as 4 x 2, twice the waves to hide latency, <= 128 VGPR.
+// PXM_GEMM_GEOM=42 selects 4 waves x 2 row tiles.
+int gemm_geom() {
+  static int g = 0;
+  if (!g) {
+    const char* e = getenv("PXM_GEMM_GEOM");
+    g = (e && atoi(e) == 42) ? 42 : 81;
+  }
+  return g;
+}
+int gemm_rows_per_task() { return 8; }
+
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double* X, double* Y, int ncol,
                 int col0, int ct, double alg_bytes, hipStream_t stream) {
   if (n_tasks == 0) return 0;
-  dim3 grid(n_tasks), block(256);
+  const int geom = gemm_geom();
+  dim3 grid(n_tasks), block(geom == 81 ? 512 : 256);
   profile_gemm_begin(stream);
+#define PXM_GEMM_LAUNCH(A, B)                                                                                         \
+  if (geom == 81) hipLaunchKernelGGL((k_sht_gemm<A, B, 8, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);     \
+  else hipLaunchKernelGGL((k_sht_gemm<A, B, 4, 2>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
   if (paired) {
-    if (ct == 1) hipLaunchKernelGGL((k_sht_gemm<1, 2>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
-    else hipLaunchKernelGGL((k_sht_gemm<2, 2>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
+    if (ct == 1) { PXM_GEMM_LAUNCH(1, 2) } else { PXM_GEMM_LAUNCH(2, 2) }
   } else {
-    if (ct == 1) hipLaunchKernelGGL((k_sht_gemm<1, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
-    else hipLaunchKernelGGL((k_sht_gemm<2, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
+    if (ct == 1) { PXM_GEMM_LAUNCH(1, 1) } else { PXM_GEMM_LAUNCH(2, 1) }
   }
+#undef PXM_GEMM_LAUNCH
   profile_gemm_end(stream, alg_bytes);
   PXM_HIP(hipGetLastError());
   return 0;
@@ -217,29 +238,36 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double*
 // ---------------------------------------------------------------------------------------
 void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, int x_L, int x_Rp,
                        int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
-                       const double* ws_base, std::vector<GemmTask>& tasks) {
+                       const double* ws_base, std::vector<GemmTask>& tasks, int el_lo) {
+  // el_lo: harmonic degrees below it carry no signal for this transform (compact support of a wavelet
+  // kernel): the rows (ring->el kinds) or contraction steps (el->ring kinds) below it are skipped.
   const bool e2r = kind_el_to_ring(kind);
   const int Rp = T.Rp;
-  // heavy tasks first: the dispatcher hands workgroups out in order, so longest-first balances CUs
+  const int lo16 = round_down(std::max(el_lo, 0), 16);
+  const int rpt = gemm_rows_per_task();  // row tiles per task
   for (int i = 0; i < T.n_m; ++i) {
     const int m = T.m_of(i);
-    const int kb = T.k_beg[kind][i];
+    const int kb = T.k_beg[kind][i];  // table start of this m: multiple of 16
+    const int start = std::max(kb, lo16);
+    if (start >= Rp) continue;
     int k_beg, k_end, row_beg;
-    int64_t rt_stride;
-    if (e2r) {  // rows = rings (all), k = el from kb
-      k_beg = kb;
+    int64_t tab_skip;  // doubles to skip inside the m-table (per row tile for el->ring, whole tiles otherwise)
+    const int64_t rt_stride = e2r ? (int64_t)((Rp - kb) / 8) * 128 : (int64_t)(Rp / 8) * 128;
+    if (e2r) {  // rows = rings (all), k = el from start
+      k_beg = start;
       k_end = Rp;
       row_beg = 0;
-    } else {    // rows = el from kb (multiple of 16), k = rings (all)
+      tab_skip = (int64_t)((start - kb) / 8) * 128;
+    } else {    // rows = el from start (multiple of 16), k = rings (all)
       k_beg = 0;
       k_end = Rp;
-      row_beg = kb;
+      row_beg = start;
+      tab_skip = (int64_t)((start - kb) / 16) * rt_stride;
     }
-    rt_stride = (int64_t)((k_end - k_beg) / 8) * 128;
     const int n_rt_total = (Rp - row_beg) / 16;
-    for (int rt = 0; rt < n_rt_total; rt += 8) {
+    for (int rt = 0; rt < n_rt_total; rt += rpt) {
       GemmTask g;
-      g.tab_off = (T.d_tab[kind] + T.m_off[kind][i] + (int64_t)rt * rt_stride) - ws_base;
+      g.tab_off = (T.d_tab[kind] + T.m_off[kind][i] + tab_skip + (int64_t)rt * rt_stride) - ws_base;
       g.rt_stride = rt_stride;
       g.x_off[0] = x_base + (int64_t)(m + x_L - 1) * x_Rp * ncol;
       g.y_off[0] = y_base + (int64_t)(m + y_L - 1) * y_Rp * ncol;
@@ -259,7 +287,7 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
       g.k_beg = k_beg;
       g.k_end = k_end;
       g.row0 = row_beg + 16 * rt;
-      g.n_rt = std::min(8, n_rt_total - rt);
+      g.n_rt = std::min(rpt, n_rt_total - rt);
       g.sign1 = (m & 1) ? -1.0 : 1.0;
       tasks.push_back(g);
     }
