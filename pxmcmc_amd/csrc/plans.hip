@@ -254,6 +254,8 @@ struct pxm_wav_plan_s {
   double* ws = nullptr;
   std::vector<int64_t> offG, offH;
   int64_t offGL = 0, offHL = 0, offS = 0;
+  int64_t offHA = 0, offHB = 0;  // L-layout class buffers of the fused combine (disjoint l-supports per class)
+  bool fused_combine = true;
   double* d_kc_syn = nullptr;  // [nsc][Rp]  c_s * kappa   (synthesis and its adjoint)
   double* d_kc_ana = nullptr;  // [nsc][Rp]  c_a * kappa   (analysis and its adjoint)
   TaskList syn_fwd, syn_inv, adj_invadj, adj_fwdadj;  // synthesis / synthesis-adjoint stages
@@ -313,6 +315,9 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   int64_t w = 0;
   p->offGL = w; w += arr_size(L, p->ncol);
   p->offHL = w; w += arr_size(L, p->ncol);
+  p->offHA = w; w += arr_size(L, p->ncol);
+  p->offHB = w; w += arr_size(L, p->ncol);
+  p->fused_combine = !getenv("PXM_NO_FUSED_COMBINE");
   for (int s = 0; s < p->nsc; ++s) {
     p->offG.push_back(w); w += arr_size(p->bl[s], p->ncol);
     p->offH.push_back(w); w += arr_size(p->bl[s], p->ncol);
@@ -348,8 +353,21 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   for (int s = 0; s < p->nsc; ++s) {
     const int b = p->bl[s], Rb = round_up(b, 16);
     // synthesis: G_s --A_s--> H_s
-    append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS, p->ws, v_syn_fwd,
-                      el_lo[s]);
+    // class of the scale: the scaling function only overlaps the first wavelet scale, so it joins the
+    // other parity class; within a class the kernels' l-supports are disjoint
+    const int cls = (s == 0) ? 1 : ((s - 1) & 1);
+    GemmFuse fz;
+    fz.row_lo = el_lo[s];
+    fz.row_hi = b;
+    if (p->fused_combine) {
+      // synthesis: G_s --A_s--> c_s kappa_s(l) * (...) written straight into the class buffer in L layout
+      fz.rscale = p->d_kc_syn + (size_t)s * p->Rp;
+      append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, cls ? p->offHB : p->offHA, L, p->Rp, nullptr, p->offS,
+                        p->ws, v_syn_fwd, el_lo[s], fz);
+    } else {
+      append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS, p->ws, v_syn_fwd,
+                        el_lo[s]);
+    }
     // synthesis adjoint: H_L (scaled by c_s kappa_s per el) --A_s^T--> G_s
     append_gemm_tasks(*p->T[s], TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
                       p->d_kc_syn + (size_t)s * p->Rp, p->offS, p->ws, v_adj_fwdadj, el_lo[s]);
@@ -357,8 +375,14 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
     append_gemm_tasks(*p->T[s], TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
                       p->d_kc_ana + (size_t)s * p->Rp, p->offS, p->ws, v_ana_inv, el_lo[s]);
     // analysis adjoint: G_s --B_s^T--> H_s
-    append_gemm_tasks(*p->T[s], TAB_INV_ADJ, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS,
-                      p->ws, v_anadj_invadj, el_lo[s]);
+    if (p->fused_combine) {
+      fz.rscale = p->d_kc_ana + (size_t)s * p->Rp;
+      append_gemm_tasks(*p->T[s], TAB_INV_ADJ, p->ncol, p->offG[s], b, Rb, cls ? p->offHB : p->offHA, L, p->Rp, nullptr,
+                        p->offS, p->ws, v_anadj_invadj, el_lo[s], fz);
+    } else {
+      append_gemm_tasks(*p->T[s], TAB_INV_ADJ, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS,
+                        p->ws, v_anadj_invadj, el_lo[s]);
+    }
     p->table_bytes[0] += p->T[s]->bytes[TAB_FWD];
     p->table_bytes[1] += p->T[s]->bytes[TAB_FWD_ADJ];
   }
@@ -369,7 +393,10 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl, el_lo))) return rc;
   if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl, el_lo))) return rc;
   v.clear();
-  append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v);
+  GemmFuse sum2;
+  sum2.x2_base = p->offHB;
+  if (p->fused_combine) append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHA, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v, 0, sum2);
+  else append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->syn_inv, {L}))) return rc;
   v.clear();
   append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
@@ -378,7 +405,8 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   append_gemm_tasks(*p->TL, TAB_FWD, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->ana_fwd, {L}))) return rc;
   v.clear();
-  append_gemm_tasks(*p->TL, TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v);
+  if (p->fused_combine) append_gemm_tasks(*p->TL, TAB_FWD_ADJ, p->ncol, p->offHA, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v, 0, sum2);
+  else append_gemm_tasks(*p->TL, TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->anadj_fwdadj, {L}))) return rc;
   // combine descriptors
   CombineArgs c;
@@ -515,7 +543,7 @@ int pxm_wav_synthesis(pxm_wav_plan_t p, const void* X, void* f, int C, pxm_strea
   hipStream_t st = (hipStream_t)stream;
   if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
   if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
-  if ((rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
+  if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
   if ((rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st))) return rc;
   PxOut out;
   out.f = (double*)f;
@@ -593,7 +621,7 @@ int pxm_wav_analysis_adjoint(pxm_wav_plan_t p, const void* X, void* f, int C, px
   hipStream_t st = (hipStream_t)stream;
   if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
   if ((rc = run_tasks(p->anadj_invadj, p->ws, p->ws, p->ncol, C, st))) return rc;
-  if ((rc = launch_combine(p->comb_ana, p->ws, p->ws + p->offHL, st))) return rc;
+  if (!p->fused_combine && (rc = launch_combine(p->comb_ana, p->ws, p->ws + p->offHL, st))) return rc;
   if ((rc = run_tasks(p->anadj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;
   PxOut out;
   out.f = (double*)f;

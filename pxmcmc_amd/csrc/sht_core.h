@@ -33,6 +33,16 @@ struct GemmTask {
   int row0;            // first output row of this task
   int n_rt;            // row tiles in this task (1..8)
   double sign1;        // factor on the -m output ((-1)^m)
+  int64_t x2_off[2];   // optional second operand (same layout) added to the first while staging; 0 = none
+  int64_t rs_off;      // optional per-output-row scale vector (absolute row) relative to the base; 0 = none
+  int row_lo, row_hi;  // only output rows in [row_lo, row_hi) are written
+};
+
+// extras of append_gemm_tasks for the fused wavelet combine
+struct GemmFuse {
+  int64_t x2_base = -1;           // second operand array (same L / Rp as x), -1 = none
+  const double* rscale = nullptr;  // per-output-row scale
+  int row_lo = 0, row_hi = 1 << 30;
 };
 
 struct ShtTables {
@@ -54,7 +64,8 @@ int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out);
 // array (x_Rp, x_L give the operand array's row padding and bandlimit for the m_idx mapping).
 void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, int x_L, int x_Rp,
                        int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
-                       const double* ws_base, std::vector<GemmTask>& tasks, int el_lo = 0);
+                       const double* ws_base, std::vector<GemmTask>& tasks, int el_lo = 0,
+                       const GemmFuse& fuse = GemmFuse());
 
 // launch: tasks on device; X/Y = workspace base; col0 = first column of this chain group, ct = column
 // tiles (1 or 2) of the group

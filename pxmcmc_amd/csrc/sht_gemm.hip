@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   // ---- operand staging map: thread -> (row kr, column pair) of the chunk
   constexpr bool ALL = (NV % NT) == 0;  // every thread stages in every pass
   const double* sp[IT];
+  int64_t sd[IT];
   int so[IT];
   bool sv[IT];
 #pragma unroll
@@ -63,15 +64,23 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     const int kr = (q / (COLS / 2)) % KC, col = 2 * (q % (COLS / 2));
     const int slab = col / (16 * CT), cin = col % (16 * CT);
     sp[i] = X + (slab ? t.x_off[1] : t.x_off[0]) + col0 + cin + (int64_t)(t.k_beg + kr) * ncol;
+    sd[i] = (slab ? t.x2_off[1] : t.x2_off[0]) - (slab ? t.x_off[1] : t.x_off[0]);
     so[i] = kr * PITCH + col;
   }
-  double2 st[IT];
+  const bool two = t.x2_off[0] != 0;  // second operand summed in while staging (fused wavelet combine)
+  double2 st[IT], st2[IT];
 #define PXM_STAGE_LOAD(CH)                                                                          \
-  _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i])                                   \
-      st[i] = *reinterpret_cast<const double2*>(sp[i] + (int64_t)(CH) * KC * ncol);
+  _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i]) {                                 \
+      st[i] = *reinterpret_cast<const double2*>(sp[i] + (int64_t)(CH) * KC * ncol);                 \
+      if (two) st2[i] = *reinterpret_cast<const double2*>(sp[i] + sd[i] + (int64_t)(CH) * KC * ncol); \
+  }
 #define PXM_STAGE_STORE(CH, BUF)                                                                    \
   _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i]) {                                 \
     double2 v = st[i];                                                                              \
+    if (two) {                                                                                      \
+      v.x += st2[i].x;                                                                              \
+      v.y += st2[i].y;                                                                              \
+    }                                                                                               \
     if (t.ks_off) {                                                                                 \
       const double sc = (X + t.ks_off)[t.k_beg + (CH) * KC + so[i] / PITCH];                        \
       v.x *= sc;                                                                                    \
@@ -148,9 +157,16 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     for (int c = 0; c < NCT; ++c) {
       const int slab = c / CT, cin = 16 * (c % CT);
       const double sg = (slab == 0) ? 1.0 : t.sign1;
-      double* yb = Y + (slab ? t.y_off[1] : t.y_off[0]) + col0 + cin + cl + (int64_t)(t.row0 + 16 * (RT * wave + r) + kq) * ncol;
+      const int rowb = t.row0 + 16 * (RT * wave + r) + kq;
+      double* yb = Y + (slab ? t.y_off[1] : t.y_off[0]) + col0 + cin + cl + (int64_t)rowb * ncol;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) yb[(int64_t)(4 * q) * ncol] = sg * acc[r][c][q];
+      for (int q = 0; q < 4; ++q) {
+        const int row = rowb + 4 * q;
+        if (row >= t.row_lo && row < t.row_hi) {
+          const double rs = t.rs_off ? (X + t.rs_off)[row] : 1.0;
+          yb[(int64_t)(4 * q) * ncol] = sg * rs * acc[r][c][q];
+        }
+      }
     }
   }
 }
@@ -238,7 +254,7 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double*
 // ---------------------------------------------------------------------------------------
 void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, int x_L, int x_Rp,
                        int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
-                       const double* ws_base, std::vector<GemmTask>& tasks, int el_lo) {
+                       const double* ws_base, std::vector<GemmTask>& tasks, int el_lo, const GemmFuse& fuse) {
   // el_lo: harmonic degrees below it carry no signal for this transform (compact support of a wavelet
   // kernel): the rows (ring->el kinds) or contraction steps (el->ring kinds) below it are skipped.
   const bool e2r = kind_el_to_ring(kind);
@@ -284,6 +300,14 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
         g.y_off[1] = g.y_off[0];
       }
       g.ks_off = kscale ? (kscale - ws_base) : 0;
+      g.rs_off = fuse.rscale ? (fuse.rscale - ws_base) : 0;
+      g.row_lo = fuse.row_lo;
+      g.row_hi = fuse.row_hi;
+      g.x2_off[0] = g.x2_off[1] = 0;
+      if (fuse.x2_base >= 0) {
+        g.x2_off[0] = fuse.x2_base + (int64_t)(m + x_L - 1) * x_Rp * ncol;
+        g.x2_off[1] = (T.paired && m != 0) ? fuse.x2_base + (int64_t)(-m + x_L - 1) * x_Rp * ncol : g.x2_off[0];
+      }
       g.k_beg = k_beg;
       g.k_end = k_end;
       g.row0 = row_beg + 16 * rt;

@@ -233,7 +233,7 @@ class ShtPlan:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:  # lib is None during interpreter shutdown
             lib.pxm_sht_plan_destroy(h)
             self._h = None
 
@@ -279,7 +279,7 @@ class WavPlan:
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:
             lib.pxm_wav_plan_destroy(h)
             self._h = None
 
