@@ -264,9 +264,10 @@ struct pxm_wav_plan_s {
   int64_t table_bytes[2] = {0, 0};
   // side streams: the DFT launches of the small scales are latency-bound (a few workgroups each);
   // they run beside the large scales' launches instead of in front of them
-  static constexpr int NSIDE = 3;
+  static constexpr int NSIDE = 3;  // capacity; PXM_NSIDE (default 2) of them are used
   hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
+  int nside = 2;
   std::vector<int> lane_of;  // per scale: -1 = caller's stream, else side stream index
 };
 
@@ -426,14 +427,15 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   // scales at the full bandlimit stay on the caller's stream; the rest are dealt over the side streams
   p->lane_of.assign(p->nsc, -1);
   if (!getenv("PXM_NO_SIDE_STREAMS")) {
-    for (int i = 0; i < pxm_wav_plan_s::NSIDE; ++i) {
+    if (const char* e = getenv("PXM_NSIDE")) p->nside = std::max(1, std::min((int)pxm_wav_plan_s::NSIDE, atoi(e)));
+    for (int i = 0; i < p->nside; ++i) {
       PXM_HIP(hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking));
       PXM_HIP(hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming));
     }
     PXM_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     int k = 0;
     for (int s = p->nsc - 1; s >= 0; --s)
-      if (p->bl[s] < L) p->lane_of[s] = (k++) % pxm_wav_plan_s::NSIDE;
+      if (p->bl[s] < L) p->lane_of[s] = (k++) % p->nside;
   }
   *plan = p;
   return 0;
