@@ -106,6 +106,24 @@ int pxm_wav_gradg_step(pxm_wav_plan_t plan, const void* X, const void* preds, co
                        uint64_t seed, uint64_t chain0, uint64_t iter, void* X_out, int C,
                        pxm_stream_t stream);
 
+/* Ring-space MYULA iteration: identity measurement + UNIFORM inverse covariance w (complex scalar), i.e.
+ * ForwardOperator(data, scalar sig_d, "synthesis", SphericalWaveletTransform, Identity).  Between
+ * forward() and calc_gradg() the reference forms the image-space residual w (preds - data)
+ * (pxmcmc/forward.py:63-72).  On every ring DFT o iDFT = (2L-1) I, so DFT(residual) =
+ * w ((2L-1) G - DFT(data)) with G the rings of S X: the L-level iDFT / DFT pair is never executed and
+ * the image `preds` is produced only on demand (saved iterations).  Results equal pxm_wav_gradg_step +
+ * pxm_wav_synthesis to round-off.  The rings of the current state are carried inside the plan:
+ *   pxm_wav_ring_set_data : rings of the data image (once per data set)
+ *   pxm_wav_ring_init     : rings <- S X                           (start of a run)
+ *   pxm_wav_ring_step     : X_out = MYULA update of X (as pxm_wav_gradg_step); rings <- S X_out
+ *   pxm_wav_ring_preds    : preds = forward(X) of the carried state, [C][L(2L-1)] */
+int pxm_wav_ring_set_data(pxm_wav_plan_t plan, const void* data, pxm_stream_t stream);
+int pxm_wav_ring_init(pxm_wav_plan_t plan, const void* X, int C, pxm_stream_t stream);
+int pxm_wav_ring_step(pxm_wav_plan_t plan, const void* X, double w_re, double w_im, const double* T,
+                      double T_scalar, double delta, double lmda, const void* noise, int noise_complex,
+                      uint64_t seed, uint64_t chain0, uint64_t iter, void* X_out, int C, pxm_stream_t stream);
+int pxm_wav_ring_preds(pxm_wav_plan_t plan, void* preds, int C, pxm_stream_t stream);
+
 /* ---- elementwise / reductions ---------------------------------------------------- */
 /* dtype: 0 = float64, 1 = complex128.  n = elements per chain. */
 /* utils.soft (pxmcmc/utils.py:55-67,84-88): T vector [n] (shared by chains) or NULL -> T_scalar */

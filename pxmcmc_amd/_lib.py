@@ -46,6 +46,13 @@ SIGNATURES = {
         c_int,
         [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_int, c_vp],
     ),
+    "pxm_wav_ring_set_data": (c_int, [c_vp, c_vp, c_vp]),
+    "pxm_wav_ring_init": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "pxm_wav_ring_step": (
+        c_int,
+        [c_vp, c_vp, c_dbl, c_dbl, c_vp, c_dbl, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_int, c_vp],
+    ),
+    "pxm_wav_ring_preds": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "pxm_soft": (c_int, [c_vp, c_vp, c_dbl, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_residual_grad": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_myula_step": (

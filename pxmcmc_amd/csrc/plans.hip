@@ -254,11 +254,14 @@ struct pxm_wav_plan_s {
   double* ws = nullptr;
   std::vector<int64_t> offG, offH;
   int64_t offGL = 0, offHL = 0, offS = 0;
+  int64_t offGR = 0, offGD = 0;  // ring-space residual buffer and the rings of the data (ring-space MYULA step)
+  bool have_data_rings = false;
   int64_t offHA = 0, offHB = 0;  // L-layout class buffers of the fused combine (disjoint l-supports per class)
   bool fused_combine = true;
   double* d_kc_syn = nullptr;  // [nsc][Rp]  c_s * kappa   (synthesis and its adjoint)
   double* d_kc_ana = nullptr;  // [nsc][Rp]  c_a * kappa   (analysis and its adjoint)
   TaskList syn_fwd, syn_inv, adj_invadj, adj_fwdadj;  // synthesis / synthesis-adjoint stages
+  TaskList adj_invadj_R;                               // same as adj_invadj, operand = residual rings G_R
   TaskList ana_fwd, ana_inv, anadj_invadj, anadj_fwdadj;  // analysis / analysis-adjoint stages
   CombineArgs comb_syn, comb_ana;
   int64_t table_bytes[2] = {0, 0};
@@ -316,6 +319,8 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   int64_t w = 0;
   p->offGL = w; w += arr_size(L, p->ncol);
   p->offHL = w; w += arr_size(L, p->ncol);
+  p->offGR = w; w += arr_size(L, p->ncol);
+  p->offGD = w; w += arr_size(L, p->ncol);
   p->offHA = w; w += arr_size(L, p->ncol);
   p->offHB = w; w += arr_size(L, p->ncol);
   p->fused_combine = !getenv("PXM_NO_FUSED_COMBINE");
@@ -403,6 +408,9 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->adj_invadj, {L}))) return rc;
   v.clear();
+  append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGR, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
+  if ((rc = upload_tasks(v, true, &p->adj_invadj_R, {L}))) return rc;
+  v.clear();
   append_gemm_tasks(*p->TL, TAB_FWD, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
   if ((rc = upload_tasks(v, true, &p->ana_fwd, {L}))) return rc;
   v.clear();
@@ -453,7 +461,7 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
     if (p->ev_join[i]) (void)hipEventDestroy(p->ev_join[i]);
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj,
+  TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj, &p->adj_invadj_R,
                      &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj};
   for (TaskList* t : tls)
     if (t->d) (void)hipFree(t->d);
@@ -600,6 +608,86 @@ int pxm_wav_gradg_step(pxm_wav_plan_t p, const void* X, const void* preds, const
   out.iter = iter;
   out.iter_dev = iter_counter();
   return wav_synthesis_adjoint_impl(p, in, out, C, (hipStream_t)stream);
+}
+
+// ---- ring-space MYULA step (identity measurement, uniform inverse covariance) -------------------------
+}  // extern "C"
+namespace pxm {
+// G_R[m][t][c] = w * (n * G_L[m][t][c] - G_D[m][t][0]) : the DFT of the image-space residual w (preds - data)
+__global__ void k_ring_residual(const double2* __restrict__ GL, const double2* __restrict__ GD, double2* __restrict__ GR,
+                                int64_t total, int Cp, double n, double2 w) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const double2 g = GL[i], d = GD[(i / Cp) * Cp];
+    GR[i] = cmul(w, double2{n * g.x - d.x, n * g.y - d.y});
+  }
+}
+}  // namespace pxm
+extern "C" {
+
+int pxm_wav_ring_set_data(pxm_wav_plan_t p, const void* data, pxm_stream_t stream) {
+  PXM_REQUIRE(p && data, "pxm_wav_ring_set_data: null argument");
+  PxIn in;
+  in.f = (const double*)data;
+  in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  int rc = launch_px2ring(p->dftL, in, p->ws + p->offGD, p->ncol, 1, (hipStream_t)stream);  // chain 0 of G_D
+  if (rc) return rc;
+  p->have_data_rings = true;
+  return 0;
+}
+
+static int wav_coeffs_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st) {
+  int rc;
+  if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
+  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
+  return run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st);
+}
+
+int pxm_wav_ring_init(pxm_wav_plan_t p, const void* X, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, X, X, C, "pxm_wav_ring_init");
+  return rc ? rc : wav_coeffs_to_rings(p, X, C, (hipStream_t)stream);
+}
+
+int pxm_wav_ring_preds(pxm_wav_plan_t p, void* preds, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, preds, preds, C, "pxm_wav_ring_preds");
+  if (rc) return rc;
+  PxOut out;
+  out.f = (double*)preds;
+  out.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  return launch_ring2px(p->dftL, p->ws + p->offGL, p->ncol, out, C, (hipStream_t)stream);
+}
+
+int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im, const double* T, double T_scalar,
+                      double delta, double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0,
+                      uint64_t iter, void* X_out, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, X, X_out, C, "pxm_wav_ring_step");
+  if (rc) return rc;
+  PXM_REQUIRE(p->have_data_rings, "pxm_wav_ring_step: call pxm_wav_ring_set_data first");
+  PXM_REQUIRE(X != X_out, "pxm_wav_ring_step: X_out must not alias X");
+  hipStream_t st = (hipStream_t)stream;
+  const int Cp = p->ncol / 2;
+  const int64_t total = (int64_t)(2 * p->L - 1) * p->Rp * Cp;
+  hipLaunchKernelGGL(k_ring_residual, dim3(2048), dim3(256), 0, st, reinterpret_cast<const double2*>(p->ws + p->offGL),
+                     reinterpret_cast<const double2*>(p->ws + p->offGD), reinterpret_cast<double2*>(p->ws + p->offGR), total,
+                     Cp, (double)(2 * p->L - 1), double2{w_re, w_im});
+  PXM_HIP(hipGetLastError());
+  if ((rc = run_tasks(p->adj_invadj_R, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;
+  PxOut out;
+  out.f = (double*)X_out;
+  out.X = (const double*)X;
+  out.T = T;
+  out.T_scalar = T_scalar;
+  out.delta = delta;
+  out.lmda = lmda;
+  out.noise = (const double*)noise;
+  out.noise_complex = noise_complex;
+  out.seed = seed;
+  out.chain0 = chain0;
+  out.iter = iter;
+  out.iter_dev = iter_counter();
+  if ((rc = wav_rings_to_blocks(p, out, C, st))) return rc;
+  return wav_coeffs_to_rings(p, X_out, C, st);
 }
 
 int pxm_wav_analysis(pxm_wav_plan_t p, const void* f, void* X, int C, pxm_stream_t stream) {

@@ -10,7 +10,8 @@ Extensions (all optional, defaults reproduce the reference's one-chain behaviour
   independent of how chains are spread over GPUs) or ``"numpy"`` (the reference's global
   ``np.random`` stream in the reference's draw order, for parity runs);
 * ``chain_offset`` -- global index of this process's first chain (multi-GPU sharding);
-* ``use_graph``    -- replay the fused iteration from a captured HIP graph (default on).
+* ``use_graph``    -- replay the fused iteration from a captured HIP graph (default on);
+* ``ring_shortcut`` -- with a scalar ``sig_d`` apply the residual on the ring transforms (default on).
 
 SKROCK (pxmcmc/mcmc.py:292-383) is out of scope.
 """
@@ -80,7 +81,7 @@ class PxMCMC:
     """
 
     def __init__(self, forward, prior, mcmcparams=PxMCMCParams(), nchains=1, rng="philox", seed=0, chain_offset=0,
-                 use_graph=True):
+                 use_graph=True, ring_shortcut=True):
         self.forward = forward
         self.prior = prior
         for attr in mcmcparams.__dict__.keys():
@@ -92,6 +93,7 @@ class PxMCMC:
         self.seed = int(seed)
         self.chain_offset = int(chain_offset)
         self.use_graph = bool(use_graph)
+        self.ring_shortcut = bool(ring_shortcut)
         self.nsamples = int(self.nsamples)
         for op in (getattr(forward, "transform", None), getattr(forward, "measurement", None)):
             if hasattr(op, "ensure_chains"):
@@ -276,11 +278,26 @@ class MYULA(PxMCMC):
         eng["side"] = "A"  # which buffer holds the current state
         args = (f.data_dev_c128, f.invcov.diag, self.prior.T_dev, float(self.delta), self.lmda)
         kw = dict(noise_complex=False, seed=self.seed, chain0=self.chain_offset, it=0)
+        # Uniform inverse covariance (scalar sig_d): the image-space residual is applied on the rings and the
+        # L-level iDFT/DFT pair between forward() and calc_gradg() drops out (pxm_wav_ring_step); preds is
+        # then materialised only when it is observed.
+        d = f.invcov.diag
+        eng["ring"] = bool(self.ring_shortcut and d.numel() > 0 and bool((d == d[0]).all()))
+        eng["P_valid"] = True
+        if eng["ring"]:
+            w = complex(d[0].item())
+            plan.ring_set_data(f.data_dev_c128)
+            plan.ring_init(eng["XA"])
 
-        def one(src, dst):
-            plan.gradg_step(src, eng["P"], *args, out=dst, **kw)   # calc_gradg + proxf + chain_step
-            eng["cnt"].add(1)
-            plan.synthesis(dst, out=eng["P"])                       # forward model of the new state
+            def one(src, dst):
+                plan.ring_step(src, w, self.prior.T_dev, float(self.delta), self.lmda, out=dst, **kw)
+                eng["cnt"].add(1)
+                eng["P_valid"] = False
+        else:
+            def one(src, dst):
+                plan.gradg_step(src, eng["P"], *args, out=dst, **kw)   # calc_gradg + proxf + chain_step
+                eng["cnt"].add(1)
+                plan.synthesis(dst, out=eng["P"])                       # forward model of the new state
 
         eng["one"] = one
         eng["graph"] = None
@@ -296,6 +313,8 @@ class MYULA(PxMCMC):
                 eng["XA"].copy_(X)
                 eng["P"].copy_(preds)
                 eng["cnt"].set(i0)
+                if eng["ring"]:
+                    plan.ring_init(eng["XA"])
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     one(eng["XA"], eng["XB"])
@@ -308,6 +327,8 @@ class MYULA(PxMCMC):
                 eng["XA"].copy_(X)
                 eng["P"].copy_(preds)
                 eng["cnt"].set(i0)
+                if eng["ring"]:
+                    plan.ring_init(eng["XA"])
         return eng
 
     def _engine_advance(self, k):
@@ -320,6 +341,7 @@ class MYULA(PxMCMC):
         if eng["graph"] is not None:
             while k >= 2:
                 eng["graph"].replay()
+                eng["P_valid"] = not eng["ring"]
                 k -= 2
         while k >= 2:
             eng["one"](eng["XA"], eng["XB"])
@@ -331,6 +353,9 @@ class MYULA(PxMCMC):
 
     def _engine_state(self):
         eng = self._eng
+        if eng["ring"] and not eng["P_valid"]:  # forward(X) of the carried rings, on demand
+            self.forward.transform._plan.ring_preds(eng["P"].shape[0], out=eng["P"])
+            eng["P_valid"] = True
         return (eng["XA"] if eng["side"] == "A" else eng["XB"]), eng["P"]
 
     def _engine_stop(self):

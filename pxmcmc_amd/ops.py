@@ -332,6 +332,46 @@ class WavPlan:
         )
         return out[0] if squeeze else out
 
+    # ---- ring-space MYULA step (identity measurement + uniform inverse covariance) ----
+    def ring_set_data(self, data):
+        d = as_device(data, _CPLX).reshape(-1)
+        if d.numel() != self.npix:
+            raise ValueError("data length mismatch")
+        check(lib.pxm_wav_ring_set_data(self._h, _p(d), _stream()))
+
+    def ring_init(self, X):
+        x, _ = _batched(as_device(X, _CPLX))
+        if x.shape[1] != self.ncoefs or x.shape[0] > self.max_chains:
+            raise AssertionError("ring_init: shape mismatch")
+        check(lib.pxm_wav_ring_init(self._h, _p(x), x.shape[0], _stream()))
+
+    def ring_step(self, X, w, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, out=None):
+        """calc_gradg + proxf + chain_step + forward for a uniform inverse covariance ``w``; the rings of the
+        new state stay inside the plan (``ring_preds`` materialises forward(X) when it is observed)."""
+        x, squeeze = _batched(as_device(X, _CPLX))
+        if x.shape[1] != self.ncoefs or x.shape[0] > self.max_chains:
+            raise AssertionError("ring_step: shape mismatch")
+        Tv, Ts = _vecT(T, self.ncoefs, x.device)
+        wn, wc = _noise_args(noise, x, noise_complex)
+        if out is None:
+            out = torch.empty_like(x)
+        elif out.shape != x.shape or out.dtype != _CPLX or not out.is_contiguous() or out.data_ptr() == x.data_ptr():
+            raise ValueError("out= buffer must be a distinct contiguous complex128 tensor of the state's shape")
+        w = complex(w)
+        check(
+            lib.pxm_wav_ring_step(
+                self._h, _p(x), w.real, w.imag, _p(Tv), Ts, float(delta), float(lmda), _p(wn), wc, seed, chain0, it,
+                _p(out), x.shape[0], _stream(),
+            )
+        )
+        return out[0] if squeeze else out
+
+    def ring_preds(self, C_, out=None):
+        if out is None:
+            out = torch.empty((C_, self.npix), dtype=_CPLX, device=device())
+        check(lib.pxm_wav_ring_preds(self._h, _p(out), C_, _stream()))
+        return out
+
     def table_bytes(self, op):
         return int(lib.pxm_wav_table_bytes(self._h, op))
 

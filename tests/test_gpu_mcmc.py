@@ -257,4 +257,40 @@ def test_graph_replay_equals_eager_stepping():
     for i in range(runs[0].niter):
         X = s._advance(X, preds, i)
         preds = op.forward(X)
-    np.testing.assert_allclose(X.cpu().numpy(), runs[0].X_curr.cpu().numpy(), rtol=0, atol=0)
+    # (the engine takes the ring-space step for this scalar sig_d, the loop above the image-space one:
+    # equal to round-off, not bit for bit)
+    ref = X.cpu().numpy()
+    assert np.abs(ref - runs[0].X_curr.cpu().numpy()).max() < 1e-10 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("cplx_data", [False, True])
+def test_ring_space_step_equals_image_space_step(cplx_data):
+    """Uniform inverse covariance: the ring-space step (no L-level iDFT/DFT pair) reproduces the general
+    image-space path -- incl. the complex-variance rule of forward.py:81-82 -- to round-off."""
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min, C = 24, 2, 2, 3
+    rng = np.random.default_rng(9)
+    P = L * (2 * L - 1)
+    data = rng.normal(size=P) + (1j * rng.normal(size=P) if cplx_data else 0)
+    op = SphericalWaveletTransformOperator(data, 0.3, "synthesis", L, B, J_min, max_chains=C)
+    reg = S2_Wavelets_L1("synthesis", None, None, 1e-3, L=L, B=B, J_min=J_min)
+    p = PxMCMCParams(lmda=1e-3, delta=5e-4, nsamples=4, nburn=2, ngap=3, verbosity=0,
+                     track=["logposterior", "L2", "prior", "chain", "predictions"])
+    runs = []
+    for ring in (True, False):
+        s = MYULA(op, reg, p, nchains=C, seed=11, ring_shortcut=ring)
+        _quiet(s.run, start_point=np.zeros(op.nparams))
+        assert s._eng["ring"] is ring
+        runs.append(s)
+    scale = np.abs(runs[1].chain).max()
+    assert np.abs(runs[0].chain - runs[1].chain).max() < 1e-11 * scale
+    np.testing.assert_allclose(runs[0].logPi, runs[1].logPi, rtol=1e-10)
+    np.testing.assert_allclose(runs[0].preds, runs[1].preds, rtol=1e-9, atol=1e-11)
+    # a vector sig_d is not uniform: the sampler must fall back to the image-space path by itself
+    op2 = SphericalWaveletTransformOperator(data, np.linspace(0.2, 0.4, P), "synthesis", L, B, J_min, max_chains=C)
+    s = MYULA(op2, reg, p, nchains=C, seed=11)
+    _quiet(s.run, start_point=np.zeros(op.nparams))
+    assert s._eng["ring"] is False and np.isfinite(s.chain).all()
