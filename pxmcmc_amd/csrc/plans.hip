@@ -16,6 +16,7 @@ struct TaskList {
   bool paired = false;
   std::vector<int> bls;  // bandlimits of the transforms grouped in this launch (roofline accounting)
   std::vector<int> los;  // their support cuts el_lo (0 = none)
+  bool gram = false;     // Gram launch: table sum_m (L-m)^2 entries, harmonic side read and written
 };
 
 static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std::vector<int> bls,
@@ -67,13 +68,18 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
 }
 
 // run a task list over all chain groups (16 chains = 32 columns per launch)
-static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, int C, hipStream_t st) {
+static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, int C, hipStream_t st,
+                     const GemmAffine& aff = GemmAffine()) {
   for (int col0 = 0; col0 < ncol; col0 += 32) {
     const int ct = (ncol - col0 >= 32) ? 2 : 1;
     const int cg = std::max(0, std::min(C - col0 / 2, 8 * ct));  // live chains in this column group
     double bytes = 0;
-    for (size_t i = 0; i < tl.bls.size(); ++i) bytes += gemm_alg_bytes(tl.bls[i], tl.paired, cg, tl.los[i]);
-    int rc = launch_gemm(tl.d, tl.n, tl.paired, X, Y, ncol, col0, ct, bytes, st);
+    for (size_t i = 0; i < tl.bls.size(); ++i) {
+      const double Ld = tl.bls[i];
+      if (tl.gram) bytes += 8.0 * Ld * (Ld + 1) * (2 * Ld + 1) / 6 + 2 * 16.0 * cg * Ld * Ld;
+      else bytes += gemm_alg_bytes(tl.bls[i], tl.paired, cg, tl.los[i]);
+    }
+    int rc = launch_gemm(tl.d, tl.n, tl.paired, X, Y, ncol, col0, ct, bytes, st, aff);
     if (rc) return rc;
   }
   return 0;
@@ -254,10 +260,13 @@ struct pxm_wav_plan_s {
   double* ws = nullptr;
   std::vector<int64_t> offG, offH;
   int64_t offGL = 0, offHL = 0, offS = 0;
-  int64_t offGR = 0, offGD = 0;  // ring-space residual buffer and the rings of the data (ring-space MYULA step)
+  int64_t offGR = 0, offGD = 0, offHD = 0;
+  TaskList gram, adj_invadj_D;   // Gram step of the ring-space MYULA iteration; B^T DFT(data)
+  bool use_gram = true;  // ring-space residual buffer and the rings of the data (ring-space MYULA step)
   bool have_data_rings = false;
   int64_t offHA = 0, offHB = 0;  // L-layout class buffers of the fused combine (disjoint l-supports per class)
   bool fused_combine = true;
+  static bool fused_combine_env_ok() { return !getenv("PXM_NO_FUSED_COMBINE") && !getenv("PXM_NO_GRAM"); }
   double* d_kc_syn = nullptr;  // [nsc][Rp]  c_s * kappa   (synthesis and its adjoint)
   double* d_kc_ana = nullptr;  // [nsc][Rp]  c_a * kappa   (analysis and its adjoint)
   TaskList syn_fwd, syn_inv, adj_invadj, adj_fwdadj;  // synthesis / synthesis-adjoint stages
@@ -321,6 +330,8 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   p->offHL = w; w += arr_size(L, p->ncol);
   p->offGR = w; w += arr_size(L, p->ncol);
   p->offGD = w; w += arr_size(L, p->ncol);
+  p->offHD = w; w += arr_size(L, p->ncol);
+  p->use_gram = p->fused_combine_env_ok();
   p->offHA = w; w += arr_size(L, p->ncol);
   p->offHB = w; w += arr_size(L, p->ncol);
   p->fused_combine = !getenv("PXM_NO_FUSED_COMBINE");
@@ -461,7 +472,7 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
     if (p->ev_join[i]) (void)hipEventDestroy(p->ev_join[i]);
   }
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-  TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj, &p->adj_invadj_R,
+  TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj, &p->adj_invadj_R, &p->gram, &p->adj_invadj_D,
                      &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj};
   for (TaskList* t : tls)
     if (t->d) (void)hipFree(t->d);
@@ -626,19 +637,36 @@ extern "C" {
 
 int pxm_wav_ring_set_data(pxm_wav_plan_t p, const void* data, pxm_stream_t stream) {
   PXM_REQUIRE(p && data, "pxm_wav_ring_set_data: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (p->use_gram && !p->gram.d) {  // first use: Gram tables + the two extra task lists
+    if ((rc = get_tables(p->L, 0, 1u << TAB_GRAM, &p->TL))) return rc;
+    std::vector<GemmTask> v;
+    GemmFuse fz;
+    fz.x2_base = p->offHB;
+    fz.hd_base = p->offHD;
+    append_gemm_tasks(*p->TL, TAB_GRAM, p->ncol, p->offHA, p->L, p->Rp, p->offHL, p->L, p->Rp, nullptr, p->offS, p->ws, v, 0, fz);
+    if ((rc = upload_tasks(v, true, &p->gram, {p->L}))) return rc;
+    p->gram.gram = true;
+    v.clear();
+    append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGD, p->L, p->Rp, p->offHD, p->L, p->Rp, nullptr, p->offS, p->ws, v);
+    if ((rc = upload_tasks(v, true, &p->adj_invadj_D, {p->L}))) return rc;
+  }
   PxIn in;
   in.f = (const double*)data;
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
-  int rc = launch_px2ring(p->dftL, in, p->ws + p->offGD, p->ncol, 1, (hipStream_t)stream);  // chain 0 of G_D
-  if (rc) return rc;
+  if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offGD, p->ncol, 1, st))) return rc;  // chain 0 of G_D
+  if (p->use_gram && (rc = run_tasks(p->adj_invadj_D, p->ws, p->ws, p->ncol, 1, st))) return rc;  // H_D = B^T DFT(data)
   p->have_data_rings = true;
   return 0;
 }
 
+// coefficient blocks -> harmonic class buffers (-> rings of S X when the Gram step is not used)
 static int wav_coeffs_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st) {
   int rc;
   if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
   if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if (p->use_gram) return 0;
   if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
   return run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st);
 }
@@ -651,10 +679,12 @@ int pxm_wav_ring_init(pxm_wav_plan_t p, const void* X, int C, pxm_stream_t strea
 int pxm_wav_ring_preds(pxm_wav_plan_t p, void* preds, int C, pxm_stream_t stream) {
   int rc = wav_check(p, preds, preds, C, "pxm_wav_ring_preds");
   if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->use_gram && (rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st))) return rc;  // rings on demand
   PxOut out;
   out.f = (double*)preds;
   out.chain_stride = (int64_t)p->L * (2 * p->L - 1);
-  return launch_ring2px(p->dftL, p->ws + p->offGL, p->ncol, out, C, (hipStream_t)stream);
+  return launch_ring2px(p->dftL, p->ws + p->offGL, p->ncol, out, C, st);
 }
 
 int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im, const double* T, double T_scalar,
@@ -665,13 +695,23 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
   PXM_REQUIRE(p->have_data_rings, "pxm_wav_ring_step: call pxm_wav_ring_set_data first");
   PXM_REQUIRE(X != X_out, "pxm_wav_ring_step: X_out must not alias X");
   hipStream_t st = (hipStream_t)stream;
-  const int Cp = p->ncol / 2;
-  const int64_t total = (int64_t)(2 * p->L - 1) * p->Rp * Cp;
-  hipLaunchKernelGGL(k_ring_residual, dim3(2048), dim3(256), 0, st, reinterpret_cast<const double2*>(p->ws + p->offGL),
-                     reinterpret_cast<const double2*>(p->ws + p->offGD), reinterpret_cast<double2*>(p->ws + p->offGR), total,
-                     Cp, (double)(2 * p->L - 1), double2{w_re, w_im});
-  PXM_HIP(hipGetLastError());
-  if ((rc = run_tasks(p->adj_invadj_R, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if (p->use_gram) {
+    // H' = w ((2L-1) B^T B H - B^T DFT(data)): inverse transform, ring residual and inverse-adjoint in one GEMM
+    GemmAffine aff;
+    aff.on = 1;
+    aff.ns = (double)(2 * p->L - 1);
+    aff.wr = w_re;
+    aff.wi = w_im;
+    if ((rc = run_tasks(p->gram, p->ws, p->ws, p->ncol, C, st, aff))) return rc;
+  } else {
+    const int Cp = p->ncol / 2;
+    const int64_t total = (int64_t)(2 * p->L - 1) * p->Rp * Cp;
+    hipLaunchKernelGGL(k_ring_residual, dim3(2048), dim3(256), 0, st, reinterpret_cast<const double2*>(p->ws + p->offGL),
+                       reinterpret_cast<const double2*>(p->ws + p->offGD), reinterpret_cast<double2*>(p->ws + p->offGR),
+                       total, Cp, (double)(2 * p->L - 1), double2{w_re, w_im});
+    PXM_HIP(hipGetLastError());
+    if ((rc = run_tasks(p->adj_invadj_R, p->ws, p->ws, p->ncol, C, st))) return rc;
+  }
   if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;
   PxOut out;
   out.f = (double*)X_out;

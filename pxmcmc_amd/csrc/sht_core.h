@@ -18,8 +18,12 @@
 
 namespace pxm {
 
-enum TableKind { TAB_INV = 0, TAB_FWD = 1, TAB_INV_ADJ = 2, TAB_FWD_ADJ = 3 };
+// TAB_GRAM: (B^m)^T B^m, el <- el: the inverse transform followed by its adjoint in one contraction
+// (normal equations of the ring-space MYULA step)
+enum TableKind { TAB_INV = 0, TAB_FWD = 1, TAB_INV_ADJ = 2, TAB_FWD_ADJ = 3, TAB_GRAM = 4, TAB_KINDS = 5 };
 inline bool kind_el_to_ring(int kind) { return kind == TAB_INV || kind == TAB_FWD_ADJ; }
+inline bool kind_rows_are_el(int kind) { return kind == TAB_FWD || kind == TAB_INV_ADJ || kind == TAB_GRAM; }
+inline bool kind_k_is_el(int kind) { return kind == TAB_INV || kind == TAB_FWD_ADJ || kind == TAB_GRAM; }
 
 // One workgroup's share of a per-m GEMM: up to 8 row tiles of 16 output rows (two per wave).
 struct GemmTask {
@@ -36,6 +40,13 @@ struct GemmTask {
   int64_t x2_off[2];   // optional second operand (same layout) added to the first while staging; 0 = none
   int64_t rs_off;      // optional per-output-row scale vector (absolute row) relative to the base; 0 = none
   int row_lo, row_hi;  // only output rows in [row_lo, row_hi) are written
+  int64_t hd_off[2];   // affine epilogue: per-row complex constant of each slab (columns 0,1 of an H-layout array)
+};
+
+// affine epilogue of the Gram launch: out = w * (ns * acc - hd[row]) as a complex product per chain
+struct GemmAffine {
+  double ns = 0, wr = 0, wi = 0;
+  int on = 0;
 };
 
 // extras of append_gemm_tasks for the fused wavelet combine
@@ -43,16 +54,17 @@ struct GemmFuse {
   int64_t x2_base = -1;           // second operand array (same L / Rp as x), -1 = none
   const double* rscale = nullptr;  // per-output-row scale
   int row_lo = 0, row_hi = 1 << 30;
+  int64_t hd_base = -1;            // H-layout array holding the affine constants (chain 0), -1 = none
 };
 
 struct ShtTables {
   int L = 0, spin = 0, Rp = 0;
   bool paired = false;           // spin 0: only m >= 0 stored, -m served with sign (-1)^m
   int n_m = 0;                   // stored m count
-  double* d_tab[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t bytes[4] = {0, 0, 0, 0};
-  std::vector<int64_t> m_off[4];  // per stored-m offset (doubles) into d_tab[kind]
-  std::vector<int> k_beg[4];      // per stored-m contraction start (el->ring kinds) / first row tile*16 (ring->el)
+  double* d_tab[TAB_KINDS] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t bytes[TAB_KINDS] = {0, 0, 0, 0, 0};
+  std::vector<int64_t> m_off[TAB_KINDS];  // per stored-m offset (doubles) into d_tab[kind]
+  std::vector<int> k_beg[TAB_KINDS];      // per stored-m contraction start (el->ring kinds) / first row tile*16 (ring->el)
   int m_of(int i) const { return paired ? i : i - (L - 1); }
 };
 
@@ -71,7 +83,7 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
 // tiles (1 or 2) of the group
 // alg_bytes: algorithmic bytes of this launch (table once + operand + result), for the live profiler
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double* X, double* Y, int ncol,
-                int col0, int ct, double alg_bytes, hipStream_t stream);
+                int col0, int ct, double alg_bytes, hipStream_t stream, const GemmAffine& aff = GemmAffine());
 
 // algorithmic bytes of one ring-GEMM stage at bandlimit L for C chains:
 // ring table 8*L*L*(L+1)/2 [paired] or 8*L*L*L [all m] read once, harmonic side 16*C*L*L,

@@ -35,7 +35,7 @@ constexpr int KC = 16;  // contraction rows per staged chunk
 template <int CT, int NSLAB, int NW, int RT>
 __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict__ tasks,
                                                       const double* __restrict__ X, double* __restrict__ Y,
-                                                      int ncol, int col0) {
+                                                      int ncol, int col0, GemmAffine aff) {
   constexpr int NCT = CT * NSLAB;
   constexpr int COLS = 16 * NCT;                          // staged operand columns
   constexpr int PITCH = COLS + (COLS == 16 ? 0 : 16);     // doubles; PITCH*8 = 128 (mod 256)
@@ -162,9 +162,19 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = rowb + 4 * q;
+        double v = acc[r][c][q];
+        if (aff.on) {  // out = w * (ns * acc - hd[row]), complex per chain: (re, im) sit in adjacent lanes
+          const double hdv = (X + (slab ? t.hd_off[1] : t.hd_off[0]))[(int64_t)row * ncol + (cl & 1)];
+          const double u = aff.ns * v - hdv;
+          int lo = __double2loint(u), hi = __double2hiint(u);
+          lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]: partner lane
+          hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
+          const double pu = __hiloint2double(hi, lo);
+          v = (cl & 1) ? (aff.wr * u + aff.wi * pu) : (aff.wr * u - aff.wi * pu);
+        }
         if (row >= t.row_lo && row < t.row_hi) {
           const double rs = t.rs_off ? (X + t.rs_off)[row] : 1.0;
-          yb[(int64_t)(4 * q) * ncol] = sg * rs * acc[r][c][q];
+          yb[(int64_t)(4 * q) * ncol] = sg * rs * v;
         }
       }
     }
@@ -230,14 +240,14 @@ int gemm_geom() {
 int gemm_rows_per_task() { return 8; }
 
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double* X, double* Y, int ncol,
-                int col0, int ct, double alg_bytes, hipStream_t stream) {
+                int col0, int ct, double alg_bytes, hipStream_t stream, const GemmAffine& aff) {
   if (n_tasks == 0) return 0;
   const int geom = gemm_geom();
   dim3 grid(n_tasks), block(geom == 81 ? 512 : 256);
   profile_gemm_begin(stream);
 #define PXM_GEMM_LAUNCH(A, B)                                                                                         \
-  if (geom == 81) hipLaunchKernelGGL((k_sht_gemm<A, B, 8, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);     \
-  else hipLaunchKernelGGL((k_sht_gemm<A, B, 4, 2>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0);
+  if (geom == 81) hipLaunchKernelGGL((k_sht_gemm<A, B, 8, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0, aff); \
+  else hipLaunchKernelGGL((k_sht_gemm<A, B, 4, 2>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0, aff);
   if (paired) {
     if (ct == 1) { PXM_GEMM_LAUNCH(1, 2) } else { PXM_GEMM_LAUNCH(2, 2) }
   } else {
@@ -257,29 +267,19 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
                        const double* ws_base, std::vector<GemmTask>& tasks, int el_lo, const GemmFuse& fuse) {
   // el_lo: harmonic degrees below it carry no signal for this transform (compact support of a wavelet
   // kernel): the rows (ring->el kinds) or contraction steps (el->ring kinds) below it are skipped.
-  const bool e2r = kind_el_to_ring(kind);
+  const bool rows_el = kind_rows_are_el(kind), k_el = kind_k_is_el(kind);
   const int Rp = T.Rp;
   const int lo16 = round_down(std::max(el_lo, 0), 16);
   const int rpt = gemm_rows_per_task();  // row tiles per task
   for (int i = 0; i < T.n_m; ++i) {
     const int m = T.m_of(i);
-    const int kb = T.k_beg[kind][i];  // table start of this m: multiple of 16
+    const int kb = T.k_beg[kind][i];  // table start of this m along its el dimension(s): multiple of 16
     const int start = std::max(kb, lo16);
     if (start >= Rp) continue;
-    int k_beg, k_end, row_beg;
-    int64_t tab_skip;  // doubles to skip inside the m-table (per row tile for el->ring, whole tiles otherwise)
-    const int64_t rt_stride = e2r ? (int64_t)((Rp - kb) / 8) * 128 : (int64_t)(Rp / 8) * 128;
-    if (e2r) {  // rows = rings (all), k = el from start
-      k_beg = start;
-      k_end = Rp;
-      row_beg = 0;
-      tab_skip = (int64_t)((start - kb) / 8) * 128;
-    } else {    // rows = el from start (multiple of 16), k = rings (all)
-      k_beg = 0;
-      k_end = Rp;
-      row_beg = start;
-      tab_skip = (int64_t)((start - kb) / 16) * rt_stride;
-    }
+    // table of this m: [row tiles from (rows_el ? kb : 0)][k chunks of 8 from (k_el ? kb : 0)]
+    const int64_t rt_stride = (int64_t)((k_el ? Rp - kb : Rp) / 8) * 128;
+    const int k_beg = k_el ? start : 0, k_end = Rp, row_beg = rows_el ? start : 0;
+    const int64_t tab_skip = (rows_el ? (int64_t)((start - kb) / 16) * rt_stride : 0) + (k_el ? (int64_t)((start - kb) / 8) * 128 : 0);
     const int n_rt_total = (Rp - row_beg) / 16;
     for (int rt = 0; rt < n_rt_total; rt += rpt) {
       GemmTask g;
@@ -312,7 +312,12 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
       g.k_end = k_end;
       g.row0 = row_beg + 16 * rt;
       g.n_rt = std::min(rpt, n_rt_total - rt);
-      g.sign1 = (m & 1) ? -1.0 : 1.0;
+      g.sign1 = (kind == TAB_GRAM) ? 1.0 : ((m & 1) ? -1.0 : 1.0);  // the Gram table is even in m
+      g.hd_off[0] = g.hd_off[1] = 0;
+      if (fuse.hd_base >= 0) {
+        g.hd_off[0] = fuse.hd_base + (int64_t)(m + y_L - 1) * y_Rp * ncol;
+        g.hd_off[1] = (T.paired && m != 0) ? fuse.hd_base + (int64_t)(-m + y_L - 1) * y_Rp * ncol : g.hd_off[0];
+      }
       tasks.push_back(g);
     }
   }
@@ -333,6 +338,16 @@ __global__ void k_build_fwd(const double* __restrict__ Bd, const double* __restr
   double acc = 0;
   for (int tp = 0; tp < L; ++tp) acc += B[(int64_t)tp * Rp + el] * Q[(int64_t)tp * Rp + t];
   Ad[(int64_t)i * Rp * Rp + (int64_t)el * Rp + t] = scale * acc;
+}
+
+// Gd[i][r][c] = sum_t Bd[i][t][r] * Bd[i][t][c]   (the per-m Gram matrix of the inverse transform)
+__global__ void k_build_gram(const double* __restrict__ Bd, double* __restrict__ Gd, int Rp, int L) {
+  const int i = blockIdx.z;
+  const int r = blockIdx.x * 16 + threadIdx.x, c = blockIdx.y * 16 + threadIdx.y;
+  const double* B = Bd + (int64_t)i * Rp * Rp;
+  double acc = 0;
+  for (int t = 0; t < L; ++t) acc += B[(int64_t)t * Rp + r] * B[(int64_t)t * Rp + c];
+  Gd[(int64_t)i * Rp * Rp + (int64_t)r * Rp + c] = acc;
 }
 
 // tiled[(rt, kk2, lane, h)] = D[row][k] (transposed = 0) or D[k][row] (transposed = 1), D = dense Rp x Rp
@@ -360,9 +375,9 @@ namespace pxm {
 static std::mutex g_tab_mutex;
 static std::map<std::pair<int, int>, ShtTables*> g_tab_cache;
 
-static int build_kind(ShtTables& T, int kind, const double* d_B, const double* d_A) {
-  const int Rp = T.Rp, L = T.L;
-  const bool e2r = kind_el_to_ring(kind);
+static int build_kind(ShtTables& T, int kind, const double* d_B, const double* d_A, const double* d_G) {
+  const int Rp = T.Rp;
+  const bool rows_el = kind_rows_are_el(kind), k_el = kind_k_is_el(kind);
   T.m_off[kind].resize(T.n_m);
   T.k_beg[kind].resize(T.n_m);
   int64_t total = 0;
@@ -371,8 +386,7 @@ static int build_kind(ShtTables& T, int kind, const double* d_B, const double* d
     const int kb = round_down(elmin, 16);  // contraction runs in 16-k chunks, output row tiles are 16 rows
     T.k_beg[kind][i] = kb;
     T.m_off[kind][i] = total;
-    if (e2r) total += (int64_t)(Rp / 16) * ((Rp - kb) / 8) * 128;
-    else total += (int64_t)((Rp - kb) / 16) * (Rp / 8) * 128;
+    total += (int64_t)((rows_el ? Rp - kb : Rp) / 16) * ((k_el ? Rp - kb : Rp) / 8) * 128;
   }
   T.bytes[kind] = (size_t)total * sizeof(double);
   PXM_HIP(hipMalloc(&T.d_tab[kind], T.bytes[kind]));
@@ -380,22 +394,20 @@ static int build_kind(ShtTables& T, int kind, const double* d_B, const double* d
     const int kb = T.k_beg[kind][i];
     const double* src;
     int transposed;
-    // dense arrays: B[t][el], A[el][t].  el->ring kinds want D[row = t][k = el].
+    // dense arrays: B[t][el], A[el][t], G[el][el].  el->ring kinds want D[row = t][k = el].
     if (kind == TAB_INV) { src = d_B; transposed = 0; }
     else if (kind == TAB_FWD_ADJ) { src = d_A; transposed = 1; }
     else if (kind == TAB_FWD) { src = d_A; transposed = 0; }
-    else { src = d_B; transposed = 1; }
+    else if (kind == TAB_INV_ADJ) { src = d_B; transposed = 1; }
+    else { src = d_G; transposed = 0; }
     src += (int64_t)i * Rp * Rp;
-    dim3 grid, block(128);
-    int row_beg, k_beg;
-    if (e2r) { row_beg = 0; k_beg = kb; grid = dim3((Rp - kb) / 8, Rp / 16); }
-    else { row_beg = kb; k_beg = 0; grid = dim3(Rp / 8, (Rp - kb) / 16); }
+    const int row_beg = rows_el ? kb : 0, k_beg = k_el ? kb : 0;
+    dim3 grid((Rp - k_beg) / 8, (Rp - row_beg) / 16), block(128);
     if (grid.x == 0 || grid.y == 0) continue;
     hipLaunchKernelGGL(k_tile_table, grid, block, 0, 0, src, T.d_tab[kind] + T.m_off[kind][i], Rp, row_beg, k_beg,
                        transposed);
   }
   PXM_HIP(hipGetLastError());
-  (void)L;
   return 0;
 }
 
@@ -417,7 +429,7 @@ int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out) {
     g_tab_cache[key] = T;
   }
   unsigned missing = 0;
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < TAB_KINDS; ++k)
     if ((kinds_mask >> k & 1u) && !T->d_tab[k]) missing |= 1u << k;
   if (missing) {
     const int Rp = T->Rp;
@@ -425,7 +437,7 @@ int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out) {
     std::vector<double> hB(dense, 0.0);
     const int m0 = T->paired ? 0 : -(L - 1);
     for (int i = 0; i < T->n_m; ++i) wigner_ring_table(L, spin, m0 + i, hB.data() + (size_t)i * Rp * Rp, Rp);
-    double *d_B = nullptr, *d_A = nullptr, *d_Q = nullptr;
+    double *d_B = nullptr, *d_A = nullptr, *d_Q = nullptr, *d_G = nullptr;
     PXM_HIP(hipMalloc(&d_B, dense * sizeof(double)));
     PXM_HIP(hipMemcpy(d_B, hB.data(), dense * sizeof(double), hipMemcpyHostToDevice));
     hB.clear();
@@ -441,15 +453,22 @@ int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out) {
       hipLaunchKernelGGL(k_build_fwd, grid, block, 0, 0, d_B, d_Q, d_A, Rp, L, 2.0 * M_PI / (2 * L - 1), m0, spin);
       PXM_HIP(hipGetLastError());
     }
-    for (int k = 0; k < 4; ++k)
+    if (missing & (1u << TAB_GRAM)) {
+      PXM_HIP(hipMalloc(&d_G, dense * sizeof(double)));
+      dim3 grid(Rp / 16, Rp / 16, T->n_m), block(16, 16);
+      hipLaunchKernelGGL(k_build_gram, grid, block, 0, 0, d_B, d_G, Rp, L);
+      PXM_HIP(hipGetLastError());
+    }
+    for (int k = 0; k < TAB_KINDS; ++k)
       if (missing >> k & 1u) {
-        int rc = build_kind(*T, k, d_B, d_A);
+        int rc = build_kind(*T, k, d_B, d_A, d_G);
         if (rc) return rc;
       }
     PXM_HIP(hipDeviceSynchronize());
     PXM_HIP(hipFree(d_B));
     if (d_A) PXM_HIP(hipFree(d_A));
     if (d_Q) PXM_HIP(hipFree(d_Q));
+    if (d_G) PXM_HIP(hipFree(d_G));
   }
   *out = T;
   return 0;
