@@ -63,6 +63,7 @@ __global__ void k_px2ring(DftArgs a, PxIn in, double* __restrict__ G, int ncol, 
   double2* buf = lds + (a.M >> 1);
   const int t = blockIdx.x, c0 = blockIdx.y * a.R;
   const int n = a.n, M = a.M, R = a.R;
+  if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
   for (int k = threadIdx.x; k < (M >> 1); k += blockDim.x) tw[k] = a.tw[k];
   for (int idx = threadIdx.x; idx < R * M; idx += blockDim.x) {
     const int r = idx / M, j = idx - r * M;

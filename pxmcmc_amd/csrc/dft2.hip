@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_px2ring2(Dft2Args a, PxIn in, double
   const int c = c0 + r;
   const bool live = r < R;
   double* mat = reinterpret_cast<double*>(lds2) + (live ? r : 0) * (M1 * PITCH);
+  if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
   double2 x[M1];
   if (live && l < M2) {
 #pragma unroll

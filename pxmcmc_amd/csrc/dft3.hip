@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_px2ring_w(Dft3Args a, PxIn in, doubl
   const int c = lane >> 1, h = lane & 1;
   const int t = blockIdx.x, c0 = blockIdx.y * R;
   const int ch = c0 + wave;
+  if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
   double* mat = reinterpret_cast<double*>(lds3) + wave * (32 * P33);
   double2 z[16];
 #pragma unroll

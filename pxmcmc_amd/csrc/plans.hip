@@ -529,7 +529,7 @@ static inline hipStream_t wav_stream(pxm_wav_plan_t p, int s, hipStream_t st) {
 }
 
 // coefficient blocks -> G_s (scales' px2ring) ; G_s -> coefficient blocks (ring2px with optional fused update)
-static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st) {
+static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st, uint64_t* bump = nullptr) {
   bool used[pxm_wav_plan_s::NSIDE];
   int rc = wav_fork(p, st, used);
   if (rc) return rc;
@@ -538,6 +538,7 @@ static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream
     in.f = (const double*)X;
     in.chain_stride = p->ncoefs;
     in.ring0 = p->coef_off[s];
+    if (s == p->nsc - 1) in.bump = bump;  // once per call, by a kernel that runs after every reader of the counter
     rc = launch_px2ring(p->dft[s], in, p->ws + p->offG[s], p->ncol, C, wav_stream(p, s, st));
     if (rc) return rc;
   }
@@ -662,9 +663,9 @@ int pxm_wav_ring_set_data(pxm_wav_plan_t p, const void* data, pxm_stream_t strea
 }
 
 // coefficient blocks -> harmonic class buffers (-> rings of S X when the Gram step is not used)
-static int wav_coeffs_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st) {
+static int wav_coeffs_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st, uint64_t* bump = nullptr) {
   int rc;
-  if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
+  if ((rc = wav_blocks_to_rings(p, X, C, st, bump))) return rc;
   if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
   if (p->use_gram) return 0;
   if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
@@ -727,7 +728,8 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
   out.iter = iter;
   out.iter_dev = iter_counter();
   if ((rc = wav_rings_to_blocks(p, out, C, st))) return rc;
-  return wav_coeffs_to_rings(p, X_out, C, st);
+  // the registered Philox iteration counter advances inside the step (no separate 1-thread launch)
+  return wav_coeffs_to_rings(p, X_out, C, st, const_cast<uint64_t*>(iter_counter()));
 }
 
 int pxm_wav_analysis(pxm_wav_plan_t p, const void* f, void* X, int C, pxm_stream_t stream) {

@@ -137,6 +137,7 @@ struct PxIn {  // px2ring input: plain image, or residual invcov .* (preds - dat
   const double* data = nullptr;    // [P] complex, shared (residual mode when non-null)
   const double* invcov = nullptr;  // [P] real or complex
   int invcov_complex = 0;
+  uint64_t* bump = nullptr;  // optional: workgroup 0 adds 1 to this counter (the Philox iteration counter)
 };
 struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a coefficient block
   double* f = nullptr;

@@ -290,8 +290,8 @@ class MYULA(PxMCMC):
             plan.ring_init(eng["XA"])
 
             def one(src, dst):
+                # (ring_step advances the registered iteration counter itself)
                 plan.ring_step(src, w, self.prior.T_dev, float(self.delta), self.lmda, out=dst, **kw)
-                eng["cnt"].add(1)
                 eng["P_valid"] = False
         else:
             def one(src, dst):
