@@ -115,7 +115,9 @@ int pxm_wav_gradg_step(pxm_wav_plan_t plan, const void* X, const void* preds, co
  * pxm_wav_synthesis to round-off.  The rings of the current state are carried inside the plan:
  *   pxm_wav_ring_set_data : rings of the data image (once per data set)
  *   pxm_wav_ring_init     : rings <- S X                           (start of a run)
- *   pxm_wav_ring_step     : X_out = MYULA update of X (as pxm_wav_gradg_step); rings <- S X_out
+ *   pxm_wav_ring_step     : X_out = MYULA update of X (as pxm_wav_gradg_step); rings <- S X_out.
+ *                           A registered iteration counter is advanced by 1 at the START of the step
+ *                           (the step's Philox iteration = iter + counter after the increment).
  *   pxm_wav_ring_preds    : preds = forward(X) of the carried state, [C][L(2L-1)] */
 int pxm_wav_ring_set_data(pxm_wav_plan_t plan, const void* data, pxm_stream_t stream);
 int pxm_wav_ring_init(pxm_wav_plan_t plan, const void* X, int C, pxm_stream_t stream);

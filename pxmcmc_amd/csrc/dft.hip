@@ -238,6 +238,12 @@ int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C,
   return 0;
 }
 
+int launch_ring2px2ring(const DftPlan& p, double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
+  if (p.use3) return dft3_ring2px(p, G, ncol, out, C, stream, true);
+  if (p.use2) return dft2_ring2px(p, G, ncol, out, C, stream, true);
+  return 1;
+}
+
 int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
   if (p.use3) return dft3_ring2px(p, G, ncol, out, C, stream);
   if (p.use2) return dft2_ring2px(p, G, ncol, out, C, stream);

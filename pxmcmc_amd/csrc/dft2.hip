@@ -202,8 +202,9 @@ __global__ __launch_bounds__(256, 2) void k_px2ring2(Dft2Args a, PxIn in, double
   }
 }
 
-template <int M1, int M2>
-__global__ __launch_bounds__(256, 2) void k_ring2px2(Dft2Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
+// RING_OUT: as in dft3.hip -- the updated ring is transformed again and written back in place over G
+template <int M1, int M2, bool RING_OUT>
+__global__ __launch_bounds__(256, 2) void k_ring2px2(Dft2Args a, double* __restrict__ G, int ncol, PxOut out, int C) {
   constexpr int TPR = M1 > M2 ? M1 : M2, PITCH = M2 + 1;
   extern __shared__ double2 lds2[];
   const int R = a.R, n = a.n;
@@ -253,11 +254,15 @@ __global__ __launch_bounds__(256, 2) void k_ring2px2(Dft2Args a, const double* _
   __syncthreads();
   double* mat = reinterpret_cast<double*>(lds2) + (live ? r : 0) * (M1 * PITCH);
   bluestein2<M1, M2>(x, mat, live ? l : TPR, a);
-  if (!(live && l < M2) || c >= C) return;
+  const bool act = live && l < M2 && c < C;
+  if (!RING_OUT && !act) return;
   constexpr int H = M1 / 2;
   const int64_t e0 = out.ring0 + (int64_t)t * n + l;  // element of j1 = 0; j1 advances by M2
   const int64_t ce0 = (int64_t)c * out.chain_stride + e0;
-  if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+  double2 xn[H];  // the ring as written to out.f (RING_OUT: input of the forward transform)
+#pragma unroll
+  for (int j1 = 0; j1 < H; ++j1) xn[j1] = double2{0.0, 0.0};
+  if (act && out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
     const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
     // in groups of EB elements: all loads of a group first (independent), then its arithmetic
     constexpr int EB = H < 4 ? H : 4;
@@ -295,19 +300,44 @@ __global__ __launch_bounds__(256, 2) void k_ring2px2(Dft2Args a, const double* _
             w = double2{philox_normal_real(out.seed, out.chain0 + c, (uint64_t)(e0 + off), it_eff), 0.0};
           }
         }
-        reinterpret_cast<double2*>(out.f)[ce0 + off] =
-            chain_step_cplx(xs[u], soft_cplx(xs[u], Ts[u]), y, w, out.delta, out.lmda);
+        xn[j1] = chain_step_cplx(xs[u], soft_cplx(xs[u], Ts[u]), y, w, out.delta, out.lmda);
+        reinterpret_cast<double2*>(out.f)[ce0 + off] = xn[j1];
       }
     }
-  } else {
+  } else if (act) {
 #pragma unroll
     for (int j1 = 0; j1 < H; ++j1) {
       const int p = j1 * M2 + l;
       if (p >= n) continue;
       double2 y = cmul(x[j1], a.chirp[p]);
       y.y = -y.y;
+      xn[j1] = y;
       reinterpret_cast<double2*>(out.f)[ce0 + (int64_t)j1 * M2] = y;
     }
+  }
+  if (!RING_OUT) return;
+  // ---- forward transform of the updated ring, rings written back in place
+  if (live && l < M2) {
+#pragma unroll
+    for (int j1 = 0; j1 < H; ++j1) {
+      const int j = j1 * M2 + l;
+      x[j1] = (j < n) ? cmul(xn[j1], a.chirp[j]) : double2{0.0, 0.0};
+    }
+  }
+  bluestein2<M1, M2>(x, mat, live ? l : TPR, a);
+  if (live && l < M2) {
+#pragma unroll
+    for (int j1 = 0; j1 < H; ++j1) {
+      const int j = j1 * M2 + l;
+      if (j < n) stage[j * (R + 1) + r] = cmul(x[j1], a.chirp[j]);
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < n * R; idx += blockDim.x) {
+    const int k = idx / R, rr = idx - k * R;
+    if (c0 + rr >= Cp) continue;
+    const int m = (k < a.L) ? k : k - n;
+    reinterpret_cast<double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + t) * Cp + c0 + rr] = stage[k * (R + 1) + rr];
   }
 }
 
@@ -367,7 +397,9 @@ static int set_attr_once() {
   if (!done) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring2<M1, M2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px2<M1, M2>),
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px2<M1, M2, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px2<M1, M2, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
@@ -399,13 +431,16 @@ int dft2_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, h
   return 0;
 }
 
-int dft2_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st) {
+int dft2_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
   Dft2Args a{p.L, p.n, p.Rp, p.R2, reinterpret_cast<const double2*>(p.d_chirp),
              reinterpret_cast<const double2*>(p.d_bhatn), reinterpret_cast<const double2*>(p.d_twm)};
-  dim3 grid(p.L, (C + p.R2 - 1) / p.R2), block(p.threads2);
+  // ring_out: every chain group must run (padded chains get zero rings written back)
+  dim3 grid(p.L, ((ring_out ? ncol / 2 : C) + p.R2 - 1) / p.R2), block(p.threads2);
+  double* Gw = const_cast<double*>(G);
 #define CALL(A, B)                                                                          \
   if (int rc = set_attr_once<A, B>()) return rc;                                            \
-  hipLaunchKernelGGL((k_ring2px2<A, B>), grid, block, p.lds2, st, a, G, ncol, out, C)
+  if (ring_out) hipLaunchKernelGGL((k_ring2px2<A, B, true>), grid, block, p.lds2, st, a, Gw, ncol, out, C);  \
+  else hipLaunchKernelGGL((k_ring2px2<A, B, false>), grid, block, p.lds2, st, a, Gw, ncol, out, C)
   DFT2_DISPATCH(p.M, CALL)
 #undef CALL
   PXM_HIP(hipGetLastError());

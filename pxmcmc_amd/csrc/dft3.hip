@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256, 2) void k_px2ring_w(Dft3Args a, PxIn in, doubl
   }
 }
 
-__global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
+// RING_OUT: after the (fused MYULA) epilogue the updated ring is transformed again and its rings are
+// written back IN PLACE over G -- rings of S X -> X' and rings of X' in one kernel (ring-space step).
+template <bool RING_OUT>
+__global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __restrict__ G, int ncol, PxOut out, int C) {
   extern __shared__ double2 lds3[];
   const int R = a.R, n = a.n;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -224,10 +227,14 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, const double* 
   __syncthreads();
   double* mat = reinterpret_cast<double*>(lds3) + wave * (32 * P33);
   bluestein_w(z, mat, c, h, a);
-  if (ch >= C) return;
+  if (!RING_OUT && ch >= C) return;
+  const bool act = ch < C;
   const int64_t e0 = out.ring0 + (int64_t)t * n + (8 * h) * 32 + c;  // element of q = 0; q advances by 32
   const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
-  if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+  double2 zn[8];  // the ring as written to out.f (RING_OUT: input of the forward transform)
+#pragma unroll
+  for (int q = 0; q < 8; ++q) zn[q] = double2{0.0, 0.0};
+  if (act && out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
     const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
 #pragma unroll
     for (int g0 = 0; g0 < 8; g0 += 4) {
@@ -263,19 +270,47 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, const double* 
             w = double2{philox_normal_real(out.seed, out.chain0 + ch, (uint64_t)(e0 + off), it_eff), 0.0};
           }
         }
-        reinterpret_cast<double2*>(out.f)[ce0 + off] =
-            chain_step_cplx(xs[u], soft_cplx(xs[u], Ts[u]), y, w, out.delta, out.lmda);
+        zn[q] = chain_step_cplx(xs[u], soft_cplx(xs[u], Ts[u]), y, w, out.delta, out.lmda);
+        reinterpret_cast<double2*>(out.f)[ce0 + off] = zn[q];
       }
     }
-  } else {
+  } else if (act) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int p = (q + 8 * h) * 32 + c;
       if (p >= n) continue;
       double2 y = cmul(z[q], a.chirp[p]);
       y.y = -y.y;
+      zn[q] = y;
       reinterpret_cast<double2*>(out.f)[ce0 + (int64_t)q * 32] = y;
     }
+  }
+  if (!RING_OUT) return;
+  // ---- forward transform of the updated ring: the column needs all 16 entries in both lanes of a pair
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double2 other = xchg2(zn[q]);
+    z[q] = sel(h, other, zn[q]);       // p = q      (owned by the h = 0 lane)
+    z[8 + q] = sel(h, zn[q], other);   // p = 8 + q  (owned by the h = 1 lane)
+  }
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int j = p * 32 + c;
+    z[p] = (j < n) ? cmul(z[p], a.chirp[j]) : double2{0.0, 0.0};
+  }
+  bluestein_w(z, mat, c, h, a);
+  __syncthreads();  // the planes are dead; reuse LDS as the [j][chain] layout-transpose stage
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int j = (q + 8 * h) * 32 + c;
+    if (j < n) stage[j * (R + 1) + wave] = cmul(z[q], a.chirp[j]);
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < n * R; idx += blockDim.x) {
+    const int k = idx / R, rr = idx - k * R;
+    if (c0 + rr >= Cp) continue;
+    const int m = (k < a.L) ? k : k - n;
+    reinterpret_cast<double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + t) * Cp + c0 + rr] = stage[k * (R + 1) + rr];
   }
 }
 
@@ -291,7 +326,9 @@ static int dft3_attr() {
   if (!done) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring_w), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w), hipFuncAttributeMaxDynamicSharedMemorySize,
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     done = true;
   }
@@ -309,12 +346,18 @@ int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, h
   return 0;
 }
 
-int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st) {
+int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
   if (int rc = dft3_attr()) return rc;
   Dft3Args a{p.L, p.n, p.Rp, p.R3, reinterpret_cast<const double2*>(p.d_chirp),
              reinterpret_cast<const double2*>(p.d_bhatn), reinterpret_cast<const double2*>(p.d_twm)};
   dim3 grid(p.L, (C + p.R3 - 1) / p.R3), block(p.threads3);
-  hipLaunchKernelGGL(k_ring2px_w, grid, block, p.lds3, st, a, G, ncol, out, C);
+  if (ring_out) {
+    // every chain group must run: padded chains get zero rings written back
+    grid = dim3(p.L, (ncol / 2 + p.R3 - 1) / p.R3);
+    hipLaunchKernelGGL(k_ring2px_w<true>, grid, block, p.lds3, st, a, const_cast<double*>(G), ncol, out, C);
+  } else {
+    hipLaunchKernelGGL(k_ring2px_w<false>, grid, block, p.lds3, st, a, const_cast<double*>(G), ncol, out, C);
+  }
   PXM_HIP(hipGetLastError());
   return 0;
 }

@@ -559,6 +559,29 @@ static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t
   return wav_join(p, st, used);
 }
 
+// G_s -> coefficient blocks (with out's epilogue) and, in the same kernels, the rings of the written blocks
+// back into G_s.  Only when every scale has a fused kernel (wav_can_fuse_dft).
+static bool wav_can_fuse_dft(pxm_wav_plan_t p) {
+  if (getenv("PXM_NO_FUSED_DFT")) return false;
+  for (int s = 0; s < p->nsc; ++s)
+    if (!dft_can_fuse(p->dft[s])) return false;
+  return true;
+}
+
+static int wav_rings_update_rings(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
+  bool used[pxm_wav_plan_s::NSIDE];
+  int rc = wav_fork(p, st, used);
+  if (rc) return rc;
+  for (int s = p->nsc - 1; s >= 0; --s) {
+    PxOut out = proto;
+    out.chain_stride = p->ncoefs;
+    out.ring0 = p->coef_off[s];
+    rc = launch_ring2px2ring(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, wav_stream(p, s, st));
+    if (rc) return rc < 0 ? rc : -1;
+  }
+  return wav_join(p, st, used);
+}
+
 int pxm_wav_synthesis(pxm_wav_plan_t p, const void* X, void* f, int C, pxm_stream_t stream) {
   int rc = wav_check(p, X, f, C, "pxm_wav_synthesis");
   if (rc) return rc;
@@ -703,8 +726,10 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
     aff.ns = (double)(2 * p->L - 1);
     aff.wr = w_re;
     aff.wi = w_im;
+    aff.bump = const_cast<uint64_t*>(iter_counter());  // the step's iteration number = counter after this bump
     if ((rc = run_tasks(p->gram, p->ws, p->ws, p->ncol, C, st, aff))) return rc;
   } else {
+    if (iter_counter() && (rc = pxm_iter_counter_add(1, stream))) return rc;
     const int Cp = p->ncol / 2;
     const int64_t total = (int64_t)(2 * p->L - 1) * p->Rp * Cp;
     hipLaunchKernelGGL(k_ring_residual, dim3(2048), dim3(256), 0, st, reinterpret_cast<const double2*>(p->ws + p->offGL),
@@ -727,9 +752,16 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
   out.chain0 = chain0;
   out.iter = iter;
   out.iter_dev = iter_counter();
+  if (wav_can_fuse_dft(p)) {
+    // rings -> X_out -> rings of X_out in one kernel per scale, then the per-scale forward GEMMs
+    if ((rc = wav_rings_update_rings(p, out, C, st))) return rc;
+    if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
+    if (p->use_gram) return 0;
+    if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
+    return run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st);
+  }
   if ((rc = wav_rings_to_blocks(p, out, C, st))) return rc;
-  // the registered Philox iteration counter advances inside the step (no separate 1-thread launch)
-  return wav_coeffs_to_rings(p, X_out, C, st, const_cast<uint64_t*>(iter_counter()));
+  return wav_coeffs_to_rings(p, X_out, C, st);
 }
 
 int pxm_wav_analysis(pxm_wav_plan_t p, const void* f, void* X, int C, pxm_stream_t stream) {

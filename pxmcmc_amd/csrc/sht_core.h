@@ -47,6 +47,7 @@ struct GemmTask {
 struct GemmAffine {
   double ns = 0, wr = 0, wi = 0;
   int on = 0;
+  uint64_t* bump = nullptr;  // optional: workgroup 0 adds 1 to this counter before anything of this step reads it
 };
 
 // extras of append_gemm_tasks for the fused wavelet combine
@@ -158,14 +159,18 @@ bool dft2_supported(int M);
 int dft2_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm);
 void dft2_geometry(int M, int n, int R, int* threads, size_t* lds);
 int dft2_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
-int dft2_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
+int dft2_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
 void dft3_geometry(int n, int R, int* threads, size_t* lds);
 int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
-int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
+int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
 
 // f(t,p) -> G[m][t][c]  (unnormalised, e^{-i m phi});  G -> f (e^{+i m phi})
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream);
 int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t stream);
+// fused: rings -> out.f (with out's epilogue) and the rings of what was written, in place over G.
+// Returns 1 (nothing launched) when the plan's DFT size has no fused kernel.
+int launch_ring2px2ring(const DftPlan& p, double* G, int ncol, const PxOut& out, int C, hipStream_t stream);
+inline bool dft_can_fuse(const DftPlan& p) { return p.use2 || p.use3; }
 
 // ---- layout repack (public harmonic layout el^2+el+m <-> internal [m][el][c]) ----------
 int launch_lm_to_mel(const double* flm, double* H, int L, int Rp, int ncol, int C, int spin, hipStream_t stream);

@@ -284,13 +284,16 @@ class MYULA(PxMCMC):
         d = f.invcov.diag
         eng["ring"] = bool(self.ring_shortcut and d.numel() > 0 and bool((d == d[0]).all()))
         eng["P_valid"] = True
+        eng["cnt0"] = lambda i: i  # counter value that makes the next step use Philox iteration i
         if eng["ring"]:
             w = complex(d[0].item())
             plan.ring_set_data(f.data_dev_c128)
             plan.ring_init(eng["XA"])
+            eng["cnt0"] = lambda i: i - 1  # ring_step increments the counter before using it
+            eng["cnt"].set(eng["cnt0"](i0))
 
             def one(src, dst):
-                # (ring_step advances the registered iteration counter itself)
+                # (ring_step advances the registered iteration counter itself, before using it)
                 plan.ring_step(src, w, self.prior.T_dev, float(self.delta), self.lmda, out=dst, **kw)
                 eng["P_valid"] = False
         else:
@@ -312,7 +315,7 @@ class MYULA(PxMCMC):
                 torch.cuda.synchronize()
                 eng["XA"].copy_(X)
                 eng["P"].copy_(preds)
-                eng["cnt"].set(i0)
+                eng["cnt"].set(eng["cnt0"](i0))
                 if eng["ring"]:
                     plan.ring_init(eng["XA"])
                 g = torch.cuda.CUDAGraph()
@@ -326,7 +329,7 @@ class MYULA(PxMCMC):
                 eng["graph_error"] = repr(exc)
                 eng["XA"].copy_(X)
                 eng["P"].copy_(preds)
-                eng["cnt"].set(i0)
+                eng["cnt"].set(eng["cnt0"](i0))
                 if eng["ring"]:
                     plan.ring_init(eng["XA"])
         return eng
