@@ -294,3 +294,33 @@ def test_ring_space_step_equals_image_space_step(cplx_data):
     s = MYULA(op2, reg, p, nchains=C, seed=11)
     _quiet(s.run, start_point=np.zeros(op.nparams))
     assert s._eng["ring"] is False and np.isfinite(s.chain).all()
+
+
+def test_analysis_setting_wavelet_prox_matches_oracle():
+    """analysis setting -- sample the image, prox = X + S(soft(S^H X, T) - S^H X)
+    (pxmcmc/prior.py:52-53, forward.py:60-69) -- through the generic (unfused) kernels, vs the oracle."""
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import L1
+
+    L, B, J_min = 12, 2, 2
+    rng = np.random.default_rng(10)
+    P = L * (2 * L - 1)
+    data = rng.normal(size=P)
+    lmda, delta, mu = 1e-2, 2e-3, 1.0
+    op = SphericalWaveletTransformOperator(data, 0.5, "analysis", L, B, J_min)
+    assert op.nparams == P
+    reg = L1("analysis", op.transform.inverse, op.transform.inverse_adjoint, lmda * mu)
+    p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=4, nburn=1, ngap=2, verbosity=0)
+    s = MYULA(op, reg, p, rng="numpy")
+    X0 = rng.normal(size=P) * 0.1
+    np.random.seed(3)
+    _quiet(s.run, start_point=X0)
+    T = ref.SphericalWaveletTransform(L, B, J_min)
+    oop = ref.ForwardOperator(data, 0.5, "analysis", T, ref.Identity(P, P), P)
+    oreg = ref.L1("analysis", T.inverse, T.inverse_adjoint, lmda * mu)
+    np.random.seed(3)
+    out = ref.myula_run(oop, oreg, lmda, delta, mu, 4, 1, 2, X0.astype(complex), lambda i: np.random.randn(P))
+    np.testing.assert_allclose(s.chain, out["chain"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(s.logPi, np.real(out["logPi"]), rtol=1e-9)
