@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=16)
+    ap.add_argument("--no-real-pairs", action="store_true", help="one complex128 slot per chain (reference layout)")
     args = ap.parse_args()
 
     import torch
@@ -107,7 +108,8 @@ def main():
     reg = S2_Wavelets_L1("synthesis", op.transform.inverse, op.transform.inverse_adjoint, LMDA * MU, L=L, B=B, J_min=J_MIN)
     params = PxMCMCParams(lmda=LMDA, delta=DELTA, mu=MU, nsamples=1, nburn=0, ngap=1, verbosity=0)
     first_chain, _ = D.shard_chains(world * C, rank, world)  # weak scaling: C chains per GPU
-    sampler = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain)
+    sampler = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain,
+                    real_pairs=not args.no_real_pairs)
     sampler._prepare()
     assert sampler._fused_wav, "the fused wavelet path must be the one benchmarked"
     with contextlib.redirect_stdout(io.StringIO()):
@@ -115,6 +117,8 @@ def main():
 
     # The timed region drives the sampler's own stepping engine (MYULA._engine_*): the fused iteration
     # replayed from a captured HIP graph (2 iterations per replay) when capture is available.
+    if sampler._pairs_ok(X):  # real data + real state: two real chains per complex128 slot (MYULA real_pairs)
+        sampler._pairs_start()
     eng = sampler._engine_start(X, preds, 0)
     barrier = D.barrier
 
@@ -162,11 +166,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "c128",
+            "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": "MYULA, spherical-wavelet synthesis L=256 B=2 J_min=2 (N=305060, P=130816), identity measurement, "
-                            "S2_Wavelets_L1 prox, complex128 state, real synthetic data, 16 chains batched per GPU",
+                            "S2_Wavelets_L1 prox, real synthetic data, 16 chains batched per GPU; state layout: "
+                            + ("two real chains per complex128 slot (real-signal symmetry, SURVEY 8d)" if eng["pairs"]
+                               else "one complex128 slot per chain (reference layout)"),
+                "real_pairs": bool(eng["pairs"]),
                 "chains_per_gpu": C,
                 "global_chains": world * C,
                 "parallelism": f"chains sharded over {world} GPU(s), no collective on the data path",

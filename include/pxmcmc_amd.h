@@ -98,11 +98,20 @@ int64_t pxm_wav_table_bytes(pxm_wav_plan_t plan, int op /*0 synthesis,1 synthesi
  * i.e. calc_gradg + proxf + chain_step in one pass over the coefficient vector, with the
  * residual folded into the transform's input read and the update into its output write.
  * data/invcov: [P] shared by all chains (invcov complex iff invcov_complex); T: [N] or NULL
- * (then T_scalar); noise: [C][N] injected N(0,1) (c128 iff noise_complex) or NULL for the
- * Philox stream keyed (seed, chain0 + c, iter). */
+ * (then T_scalar); noise: [C][N] injected N(0,1) or NULL for the Philox stream keyed
+ * (seed, chain0 + c, iter).  mode (how a complex128 slot of the state is read):
+ *   PXM_MODE_REAL_NOISE 0  complex state, real noise (float64 [C][N] when injected): params.complex = False
+ *   PXM_MODE_CPLX_NOISE 1  complex state, complex noise (c128 [C][N]):                params.complex = True
+ *   PXM_MODE_REAL_PAIRS 2  real data and real state: slot c carries the two REAL chains 2c (real part) and
+ *                          2c+1 (imaginary part) through the complex-linear transforms; soft threshold and
+ *                          noise are applied per component (injected noise: float64 [2C][N]; Philox keys
+ *                          chain0 + 2c and chain0 + 2c + 1); data must then be passed as d + i d. */
+#define PXM_MODE_REAL_NOISE 0
+#define PXM_MODE_CPLX_NOISE 1
+#define PXM_MODE_REAL_PAIRS 2
 int pxm_wav_gradg_step(pxm_wav_plan_t plan, const void* X, const void* preds, const void* data,
                        const void* invcov, int invcov_complex, const double* T, double T_scalar,
-                       double delta, double lmda, const void* noise, int noise_complex,
+                       double delta, double lmda, const void* noise, int mode,
                        uint64_t seed, uint64_t chain0, uint64_t iter, void* X_out, int C,
                        pxm_stream_t stream);
 
@@ -122,7 +131,7 @@ int pxm_wav_gradg_step(pxm_wav_plan_t plan, const void* X, const void* preds, co
 int pxm_wav_ring_set_data(pxm_wav_plan_t plan, const void* data, pxm_stream_t stream);
 int pxm_wav_ring_init(pxm_wav_plan_t plan, const void* X, int C, pxm_stream_t stream);
 int pxm_wav_ring_step(pxm_wav_plan_t plan, const void* X, double w_re, double w_im, const double* T,
-                      double T_scalar, double delta, double lmda, const void* noise, int noise_complex,
+                      double T_scalar, double delta, double lmda, const void* noise, int mode,
                       uint64_t seed, uint64_t chain0, uint64_t iter, void* X_out, int C, pxm_stream_t stream);
 int pxm_wav_ring_preds(pxm_wav_plan_t plan, void* preds, int C, pxm_stream_t stream);
 

@@ -6,6 +6,7 @@
 // (residual on read, prox + Langevin update on write).
 #include "elem.h"
 #include "sht_core.h"
+#include "update.h"
 
 #include <cstdlib>
 
@@ -135,18 +136,8 @@ __global__ void k_ring2px(DftArgs a, const double* __restrict__ G, int ncol, PxO
     const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
       const double2 x = reinterpret_cast<const double2*>(out.X)[ce];
       const double T = out.T ? out.T[e] : out.T_scalar;
-      const double2 px = soft_cplx(x, T);
-      double2 w;
-      if (out.noise) {
-        if (out.noise_complex) w = reinterpret_cast<const double2*>(out.noise)[ce];
-        else w = double2{out.noise[ce], 0.0};
-      } else if (out.noise_complex) {
-        NormalPair q = philox_normal_pair(out.seed, out.chain0 + c, (uint64_t)e, it_eff);
-        w = double2{q.z0, q.z1};
-      } else {
-        w = double2{philox_normal_real(out.seed, out.chain0 + c, (uint64_t)e, it_eff), 0.0};
-      }
-      y = chain_step_cplx(x, px, y, w, out.delta, out.lmda);
+      const double2 w = out.noise ? px_noise_load(out, c, e) : px_noise_philox(out, c, e, it_eff);
+      y = px_update(out, x, T, y, w);
     }
     reinterpret_cast<double2*>(out.f)[ce] = y;
   }

@@ -11,6 +11,7 @@
 //   step 1' (thread = column j2): DIT over k1 (only the n <= M/2 wanted outputs) -> times chirp
 #include "elem.h"
 #include "sht_core.h"
+#include "update.h"
 #include "tw32.h"
 
 namespace pxm {
@@ -277,11 +278,7 @@ __global__ __launch_bounds__(256, 2) void k_ring2px2(Dft2Args a, double* __restr
         const int64_t off = (int64_t)j1 * M2;
         xs[u] = ok ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
         Ts[u] = (ok && out.T) ? out.T[e0 + off] : out.T_scalar;
-        wn[u] = double2{0.0, 0.0};
-        if (ok && out.noise) {
-          if (out.noise_complex) wn[u] = reinterpret_cast<const double2*>(out.noise)[ce0 + off];
-          else wn[u].x = out.noise[ce0 + off];
-        }
+        wn[u] = (ok && out.noise) ? px_noise_load(out, c, e0 + off) : double2{0.0, 0.0};
       }
 #pragma unroll
       for (int u = 0; u < EB; ++u) {
@@ -292,15 +289,8 @@ __global__ __launch_bounds__(256, 2) void k_ring2px2(Dft2Args a, double* __restr
         double2 y = cmul(x[j1], a.chirp[p]);
         y.y = -y.y;
         double2 w = wn[u];
-        if (!out.noise) {
-          if (out.noise_complex) {
-            NormalPair q = philox_normal_pair(out.seed, out.chain0 + c, (uint64_t)(e0 + off), it_eff);
-            w = double2{q.z0, q.z1};
-          } else {
-            w = double2{philox_normal_real(out.seed, out.chain0 + c, (uint64_t)(e0 + off), it_eff), 0.0};
-          }
-        }
-        xn[j1] = chain_step_cplx(xs[u], soft_cplx(xs[u], Ts[u]), y, w, out.delta, out.lmda);
+        if (!out.noise) w = px_noise_philox(out, c, e0 + off, it_eff);
+        xn[j1] = px_update(out, xs[u], Ts[u], y, w);
         reinterpret_cast<double2*>(out.f)[ce0 + off] = xn[j1];
       }
     }

@@ -9,6 +9,7 @@
 //   lane = 2*c + h,  c = column j2 (steps 1, 1') or row k1 (step 2),  h = which half of the 32-point FFT
 #include "elem.h"
 #include "sht_core.h"
+#include "update.h"
 #include "tw32.h"
 
 namespace pxm {
@@ -247,11 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __rest
         const int64_t off = (int64_t)q * 32;
         xs[u] = ok ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
         Ts[u] = (ok && out.T) ? out.T[e0 + off] : out.T_scalar;
-        wn[u] = double2{0.0, 0.0};
-        if (ok && out.noise) {
-          if (out.noise_complex) wn[u] = reinterpret_cast<const double2*>(out.noise)[ce0 + off];
-          else wn[u].x = out.noise[ce0 + off];
-        }
+        wn[u] = (ok && out.noise) ? px_noise_load(out, ch, e0 + off) : double2{0.0, 0.0};
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -262,15 +259,8 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __rest
         double2 y = cmul(z[q], a.chirp[p]);
         y.y = -y.y;
         double2 w = wn[u];
-        if (!out.noise) {
-          if (out.noise_complex) {
-            NormalPair nq = philox_normal_pair(out.seed, out.chain0 + ch, (uint64_t)(e0 + off), it_eff);
-            w = double2{nq.z0, nq.z1};
-          } else {
-            w = double2{philox_normal_real(out.seed, out.chain0 + ch, (uint64_t)(e0 + off), it_eff), 0.0};
-          }
-        }
-        zn[q] = chain_step_cplx(xs[u], soft_cplx(xs[u], Ts[u]), y, w, out.delta, out.lmda);
+        if (!out.noise) w = px_noise_philox(out, ch, e0 + off, it_eff);
+        zn[q] = px_update(out, xs[u], Ts[u], y, w);
         reinterpret_cast<double2*>(out.f)[ce0 + off] = zn[q];
       }
     }

@@ -617,12 +617,13 @@ int pxm_wav_synthesis_adjoint(pxm_wav_plan_t p, const void* f, void* X, int C, p
 
 int pxm_wav_gradg_step(pxm_wav_plan_t p, const void* X, const void* preds, const void* data, const void* invcov,
                        int invcov_complex, const double* T, double T_scalar, double delta, double lmda,
-                       const void* noise, int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter,
+                       const void* noise, int mode, uint64_t seed, uint64_t chain0, uint64_t iter,
                        void* X_out, int C, pxm_stream_t stream) {
   int rc = wav_check(p, X, X_out, C, "pxm_wav_gradg_step");
   if (rc) return rc;
   PXM_REQUIRE(preds && data && invcov, "pxm_wav_gradg_step: null argument");
   PXM_REQUIRE(X != X_out, "pxm_wav_gradg_step: X_out must not alias X");
+  PXM_REQUIRE(mode >= 0 && mode <= 2, "pxm_wav_gradg_step: mode must be 0, 1 or 2");
   PxIn in;
   in.f = (const double*)preds;
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
@@ -637,7 +638,7 @@ int pxm_wav_gradg_step(pxm_wav_plan_t p, const void* X, const void* preds, const
   out.delta = delta;
   out.lmda = lmda;
   out.noise = (const double*)noise;
-  out.noise_complex = noise_complex;
+  out.mode = mode;
   out.seed = seed;
   out.chain0 = chain0;
   out.iter = iter;
@@ -712,12 +713,13 @@ int pxm_wav_ring_preds(pxm_wav_plan_t p, void* preds, int C, pxm_stream_t stream
 }
 
 int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im, const double* T, double T_scalar,
-                      double delta, double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0,
+                      double delta, double lmda, const void* noise, int mode, uint64_t seed, uint64_t chain0,
                       uint64_t iter, void* X_out, int C, pxm_stream_t stream) {
   int rc = wav_check(p, X, X_out, C, "pxm_wav_ring_step");
   if (rc) return rc;
   PXM_REQUIRE(p->have_data_rings, "pxm_wav_ring_step: call pxm_wav_ring_set_data first");
   PXM_REQUIRE(X != X_out, "pxm_wav_ring_step: X_out must not alias X");
+  PXM_REQUIRE(mode >= 0 && mode <= 2, "pxm_wav_ring_step: mode must be 0, 1 or 2");
   hipStream_t st = (hipStream_t)stream;
   if (p->use_gram) {
     // H' = w ((2L-1) B^T B H - B^T DFT(data)): inverse transform, ring residual and inverse-adjoint in one GEMM
@@ -747,7 +749,7 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
   out.delta = delta;
   out.lmda = lmda;
   out.noise = (const double*)noise;
-  out.noise_complex = noise_complex;
+  out.mode = mode;
   out.seed = seed;
   out.chain0 = chain0;
   out.iter = iter;

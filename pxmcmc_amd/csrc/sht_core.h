@@ -149,7 +149,7 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
   const double* T = nullptr;  // [N] thresholds (offset by ring0 like X) or null -> T_scalar
   double T_scalar = 0, delta = 0, lmda = 0;
   const double* noise = nullptr;  // injected noise or null -> Philox
-  int noise_complex = 0;
+  int mode = 0;  // update.h: 0 complex state + real noise, 1 + complex noise, 2 two real chains per slot
   uint64_t seed = 0, chain0 = 0, iter = 0;
   const uint64_t* iter_dev = nullptr;  // optional device-resident addend to iter (graph replay)
 };

@@ -1,0 +1,56 @@
+// Fused prox + MYULA update of one coefficient, shared by the epilogues of the DFT stage
+// (pxmcmc/mcmc.py:185-201 with prior.py:49-50 / utils.py:55-67).
+//
+// PxOut::mode selects how the complex128 slot of the state is interpreted:
+//   PXM_MODE_REAL_NOISE (0)  complex state, real noise        (params.complex = False, reference layout)
+//   PXM_MODE_CPLX_NOISE (1)  complex state, complex noise     (params.complex = True)
+//   PXM_MODE_REAL_PAIRS (2)  two REAL chains per slot: chain 2c in .x, chain 2c+1 in .y.  Every operator
+//                            of the path is complex-linear and maps real fields to real fields, so the
+//                            pair travels through the transforms as one complex array; only this update is
+//                            applied per component (real soft threshold, one noise draw per chain).
+#pragma once
+#include "elem.h"
+#include "sht_core.h"
+
+namespace pxm {
+
+enum { PXM_MODE_REAL_NOISE = 0, PXM_MODE_CPLX_NOISE = 1, PXM_MODE_REAL_PAIRS = 2 };
+
+// injected noise of (slot c, element e); real-pair noise is a real [2 * slots][chain_stride] array
+__device__ __forceinline__ double2 px_noise_load(const PxOut& o, int c, int64_t e) {
+  if (o.mode == PXM_MODE_CPLX_NOISE) return reinterpret_cast<const double2*>(o.noise)[(int64_t)c * o.chain_stride + e];
+  if (o.mode == PXM_MODE_REAL_PAIRS)
+    return double2{o.noise[(int64_t)(2 * c) * o.chain_stride + e], o.noise[(int64_t)(2 * c + 1) * o.chain_stride + e]};
+  return double2{o.noise[(int64_t)c * o.chain_stride + e], 0.0};
+}
+
+// Philox noise of (slot c, element e) at iteration it.  One Philox body for every mode (a rolled loop of
+// 1 or 2 trips) so the two-chain mode costs no extra registers in the DFT epilogues.
+__device__ __forceinline__ double2 px_noise_philox(const PxOut& o, int c, int64_t e, uint64_t it) {
+  const bool pairs = o.mode == PXM_MODE_REAL_PAIRS, cplx = o.mode == PXM_MODE_CPLX_NOISE;
+  const int nk = pairs ? 2 : 1;
+  const uint64_t idx = cplx ? (uint64_t)e : ((uint64_t)e >> 1);
+  double2 w{0.0, 0.0};
+#pragma nounroll
+  for (int k = 0; k < nk; ++k) {
+    const NormalPair q = philox_normal_pair(o.seed, o.chain0 + (pairs ? 2 * c + k : c), idx, it);
+    const double v = (cplx || !(e & 1)) ? q.z0 : q.z1;
+    if (k == 0) {
+      w.x = v;
+      w.y = cplx ? q.z1 : 0.0;
+    } else {
+      w.y = v;
+    }
+  }
+  return w;
+}
+
+// X' = (1 - d/l) X + (d/l) soft(X, T) - d g + sqrt(2 d) w
+__device__ __forceinline__ double2 px_update(const PxOut& o, double2 x, double T, double2 g, double2 w) {
+  double2 px;
+  if (o.mode == PXM_MODE_REAL_PAIRS) px = double2{soft_real(x.x, T), soft_real(x.y, T)};
+  else px = soft_cplx(x, T);
+  return chain_step_cplx(x, px, g, w, o.delta, o.lmda);
+}
+
+}  // namespace pxm

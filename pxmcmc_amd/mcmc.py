@@ -11,10 +11,18 @@ Extensions (all optional, defaults reproduce the reference's one-chain behaviour
   ``np.random`` stream in the reference's draw order, for parity runs);
 * ``chain_offset`` -- global index of this process's first chain (multi-GPU sharding);
 * ``use_graph``    -- replay the fused iteration from a captured HIP graph (default on);
-* ``ring_shortcut`` -- with a scalar ``sig_d`` apply the residual on the ring transforms (default on).
+* ``ring_shortcut`` -- with a scalar ``sig_d`` apply the residual on the ring transforms (default on);
+* ``real_pairs``   -- with REAL data, a real start point and ``params.complex == False`` the reference's
+  complex128 state has a zero imaginary part (every operator of the path maps real fields to real
+  fields); the fused wavelet path then carries two real chains per complex slot -- chain 2c in the real
+  part, chain 2c+1 in the imaginary part -- through the complex-linear transforms and applies prox and
+  noise per component (real-signal symmetry).  Same results, half the transform
+  work (default on; complex data, as in the reference-literal topography set-up, is never paired).
 
 SKROCK (pxmcmc/mcmc.py:292-383) is out of scope.
 """
+import gc
+
 import numpy as np
 import torch
 from scipy.stats import laplace
@@ -81,7 +89,7 @@ class PxMCMC:
     """
 
     def __init__(self, forward, prior, mcmcparams=PxMCMCParams(), nchains=1, rng="philox", seed=0, chain_offset=0,
-                 use_graph=True, ring_shortcut=True):
+                 use_graph=True, ring_shortcut=True, real_pairs=True):
         self.forward = forward
         self.prior = prior
         for attr in mcmcparams.__dict__.keys():
@@ -94,6 +102,8 @@ class PxMCMC:
         self.chain_offset = int(chain_offset)
         self.use_graph = bool(use_graph)
         self.ring_shortcut = bool(ring_shortcut)
+        self.real_pairs = bool(real_pairs)
+        self._pairs = False
         self.nsamples = int(self.nsamples)
         for op in (getattr(forward, "transform", None), getattr(forward, "measurement", None)):
             if hasattr(op, "ensure_chains"):
@@ -244,6 +254,12 @@ class MYULA(PxMCMC):
     def _advance(self, X, preds, i, delta=None):
         """one MYULA update X -> X_prop (pxmcmc/mcmc.py:158-160), fused where the operators allow"""
         delta = self.delta if delta is None else delta
+        if self._pairs:  # X, preds are pair-packed [ceil(C/2), .]
+            noise = self._host_noise_pairs(X) if self.rng == "numpy" else None
+            return self._pair_plan.gradg_step(
+                X, preds, self._pair_data, self.forward.invcov.diag, self.prior.T_dev, delta, self.lmda, noise=noise,
+                seed=self.seed, chain0=self.chain_offset, it=i, pairs=True,
+            )
         noise = self._host_noise(X) if self.rng == "numpy" else None
         kw = dict(noise=noise, noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=i)
         if self._fused_wav:
@@ -263,6 +279,48 @@ class MYULA(PxMCMC):
         self._fused_wav = self._fusable_wavelet() and isinstance(self.delta, float)
         self._fused_prox = _is_stock_l1(self.prior) and type(self).chain_step is MYULA.chain_step
         self._it = 0
+        self._pairs = False
+
+    # ---- two real chains per complex slot (real data, real state) ---------------------------------
+    def _pairs_ok(self, X):
+        """The reference's state is real-valued (stored as complex128 with a zero imaginary part) when the
+        data, the inverse covariance and the start point are real and params.complex is False."""
+        f = self.forward
+        return bool(
+            self._fused_wav and self.real_pairs and not self.complex
+            and not f.data_dev.is_complex() and not f.invcov.diag.is_complex()
+            and (not X.is_complex() or not bool((X.imag != 0).any()))
+        )
+
+    def _pairs_start(self):
+        tr = self.forward.transform
+        Cs = (self.nchains + 1) // 2
+        if getattr(self, "_pair_plan", None) is None or self._pair_plan.max_chains != Cs:
+            self._pair_plan = ops.WavPlan(tr.L, tr.B, tr.J_min, max_chains=Cs)  # tables are shared with tr._plan
+        d = self.forward.data_dev.to(torch.float64)
+        self._pair_data = torch.complex(d, d).contiguous()  # both chains of a slot see the same data
+        self._pairs = True
+
+    def _pack(self, X):
+        """[C, n] (real-valued) -> [ceil(C/2), n] complex128: chain 2c + i chain 2c+1"""
+        re = X.real if X.is_complex() else X
+        if re.shape[0] % 2:
+            re = torch.cat((re, re[-1:]))  # odd chain count: the last slot's partner is a discarded copy
+        return torch.complex(re[0::2].contiguous(), re[1::2].contiguous())
+
+    def _unpack(self, Xp):
+        """inverse of _pack, returned as complex128 [C, n] (the reference's state dtype)"""
+        Cs, n = Xp.shape
+        out = torch.stack((Xp.real, Xp.imag), dim=1).reshape(2 * Cs, n)[: self.nchains]
+        return out.to(torch.complex128)
+
+    def _host_noise_pairs(self, Xp):
+        """the reference's draw order (one randn(N) per chain, pxmcmc/mcmc.py:193) as a real [2 slots, N] array"""
+        Cs, N = Xp.shape
+        w = np.zeros((2 * Cs, N))
+        for c in range(self.nchains):
+            w[c] = np.random.randn(N)
+        return ops.as_device(w)
 
     # ---- HIP-graph engine for the fused wavelet path ----------------------------------------------
     def _graph_ok(self):
@@ -272,12 +330,18 @@ class MYULA(PxMCMC):
         """Static ping-pong state (XA, XB, P), a device iteration counter and a captured 2-iteration graph."""
         f = self.forward
         plan = f.transform._plan
+        data = f.data_dev_c128
         self._eng = eng = {}
+        eng["pairs"] = self._pairs
+        if self._pairs:  # two real chains per complex slot: X, preds are carried pair-packed
+            plan, data = self._pair_plan, self._pair_data
+            X, preds = self._pack(X), self._pack(preds)
+        eng["plan"] = plan
         eng["XA"], eng["XB"], eng["P"] = X.clone(), torch.empty_like(X), preds.clone()
         eng["cnt"] = ops.IterCounter(i0)
         eng["side"] = "A"  # which buffer holds the current state
-        args = (f.data_dev_c128, f.invcov.diag, self.prior.T_dev, float(self.delta), self.lmda)
-        kw = dict(noise_complex=False, seed=self.seed, chain0=self.chain_offset, it=0)
+        args = (data, f.invcov.diag, self.prior.T_dev, float(self.delta), self.lmda)
+        kw = dict(noise_complex=False, seed=self.seed, chain0=self.chain_offset, it=0, pairs=self._pairs)
         # Uniform inverse covariance (scalar sig_d): the image-space residual is applied on the rings and the
         # L-level iDFT/DFT pair between forward() and calc_gradg() drops out (pxm_wav_ring_step); preds is
         # then materialised only when it is observed.
@@ -287,7 +351,7 @@ class MYULA(PxMCMC):
         eng["cnt0"] = lambda i: i  # counter value that makes the next step use Philox iteration i
         if eng["ring"]:
             w = complex(d[0].item())
-            plan.ring_set_data(f.data_dev_c128)
+            plan.ring_set_data(data)
             plan.ring_init(eng["XA"])
             eng["cnt0"] = lambda i: i - 1  # ring_step increments the counter before using it
             eng["cnt"].set(eng["cnt0"](i0))
@@ -319,9 +383,18 @@ class MYULA(PxMCMC):
                 if eng["ring"]:
                     plan.ring_init(eng["XA"])
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    one(eng["XA"], eng["XB"])
-                    one(eng["XB"], eng["XA"])
+                # no garbage collection while capturing: a collected plan / graph of an earlier run would
+                # call hipFree / hipStreamDestroy in the middle of the capture
+                gc.collect()
+                gc_was_on = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g):
+                        one(eng["XA"], eng["XB"])
+                        one(eng["XB"], eng["XA"])
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 # capture does not execute: state is still (X, preds, i0)
                 eng["graph"] = g
             except Exception as exc:  # capture unsupported in this environment: eager stepping, same results
@@ -355,16 +428,25 @@ class MYULA(PxMCMC):
             eng["side"] = "B"
 
     def _engine_state(self):
+        """(X, preds) of the current state as [C, .] arrays (pair-packed engines unpack here: observation only)"""
         eng = self._eng
         if eng["ring"] and not eng["P_valid"]:  # forward(X) of the carried rings, on demand
-            self.forward.transform._plan.ring_preds(eng["P"].shape[0], out=eng["P"])
+            eng["plan"].ring_preds(eng["P"].shape[0], out=eng["P"])
             eng["P_valid"] = True
-        return (eng["XA"] if eng["side"] == "A" else eng["XB"]), eng["P"]
+        X = eng["XA"] if eng["side"] == "A" else eng["XB"]
+        if eng["pairs"]:
+            return self._unpack(X), self._unpack(eng["P"])
+        return X, eng["P"]
 
     def _engine_stop(self):
+        """unregister the iteration counter and drop the engine's buffers, graph and closures (the closures
+        reference the sampler: without this the plan would only be released by a later garbage collection)"""
         eng = getattr(self, "_eng", None)
-        if eng is not None:
+        if eng is not None and eng.get("cnt") is not None:
             eng["cnt"].close()
+            eng["graph"] = eng["graph"] is not None  # keep the flags (ring, pairs, graph) for inspection
+            for k in ("one", "XA", "XB", "P", "plan", "cnt", "cnt0"):
+                eng[k] = None
 
     def run(self, start_point=None):
         """Run the algorithm (pxmcmc/mcmc.py:150-183)."""
@@ -372,19 +454,27 @@ class MYULA(PxMCMC):
         i = 0  # total samples
         j = 0  # saved samples (excludes burn-in and thinned samples)
         X_curr, curr_preds = self._initial_sample(start_point)
+        if self._pairs_ok(X_curr):
+            self._pairs_start()
         if self._fused_wav and self.rng == "philox":
             return self._run_engine(X_curr, curr_preds)
+        if self._pairs:
+            X_curr, curr_preds = self._pack(X_curr), self._pack(curr_preds)
         while j < self.nsamples:
             X_prop = self._advance(X_curr, curr_preds, i)
-            prop_preds = ops.as_device(self.forward.forward(X_prop))
+            if self._pairs:  # identity measurement: forward = synthesis, on the pair-packed state
+                prop_preds = self._pair_plan.synthesis(X_prop)
+            else:
+                prop_preds = ops.as_device(self.forward.forward(X_prop))
 
             X_curr = X_prop
             curr_preds = prop_preds
 
             if i >= self.nburn:
                 if self.ngap == 0 or (i - self.nburn) % self.ngap == 0:
-                    logPi, L2, prior = self._logpi_dev(X_curr, curr_preds)
-                    self._tracking(j, X_curr, curr_preds, logPi, L2, prior)
+                    Xs, Ps = (self._unpack(X_curr), self._unpack(curr_preds)) if self._pairs else (X_curr, curr_preds)
+                    logPi, L2, prior = self._logpi_dev(Xs, Ps)
+                    self._tracking(j, Xs, Ps, logPi, L2, prior)
                     j += 1
                 if self.verbosity > 0 and (i + 1) % self.verbosity == 0:
                     first = (lambda a: a[j - 1] if self.nchains == 1 else a[0, j - 1])
@@ -393,6 +483,8 @@ class MYULA(PxMCMC):
                 if self.verbosity > 0 and (i + 1) % self.verbosity == 0:
                     print("Burning in...")
             i += 1
+        if self._pairs:
+            X_curr, curr_preds = self._unpack(X_curr), self._unpack(curr_preds)
         self.X_curr, self.curr_preds, self.niter = X_curr, curr_preds, i
         print("\nDONE")
 
@@ -433,6 +525,7 @@ class MYULA(PxMCMC):
             X_curr, curr_preds = self._engine_state()
             self.X_curr, self.curr_preds, self.niter = X_curr.clone(), curr_preds.clone(), i
             self.used_graph = self._eng["graph"] is not None
+            self.graph_error = self._eng.get("graph_error")
         finally:
             self._engine_stop()
         print("\nDONE")

@@ -106,6 +106,16 @@ def _delta_args(delta, C_, dev):
     return None, float(delta)
 
 
+def _pair_noise_args(noise, x):
+    """mode 2 (two real chains per complex slot): injected noise is a real [2 * slots, N] array"""
+    if noise is None:
+        return None, 2
+    w = as_device(noise, _REAL)
+    if w.dim() != 2 or w.shape != (2 * x.shape[0], x.shape[1]):
+        raise ValueError("real-pair noise must be a float64 [2 * slots, N] array")
+    return w, 2
+
+
 def _noise_args(noise, x, noise_complex):
     if noise is None:
         return None, int(bool(noise_complex))
@@ -308,8 +318,10 @@ class WavPlan:
     def analysis_adjoint(self, X):
         return self._run(lib.pxm_wav_analysis_adjoint, X, self.ncoefs, self.npix)
 
-    def gradg_step(self, X, preds, data, invcov, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, out=None):
-        """Fused calc_gradg + proxf + chain_step (pxmcmc/mcmc.py:158-160) for the synthesis setting."""
+    def gradg_step(self, X, preds, data, invcov, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, out=None,
+                   pairs=False):
+        """Fused calc_gradg + proxf + chain_step (pxmcmc/mcmc.py:158-160) for the synthesis setting.
+        ``pairs``: every complex slot of X carries two real chains (PXM_MODE_REAL_PAIRS)."""
         x, squeeze = _batched(as_device(X, _CPLX))
         p, _ = _batched(as_device(preds, _CPLX))
         if x.shape[1] != self.ncoefs or p.shape[1] != self.npix or p.shape[0] != x.shape[0]:
@@ -319,7 +331,7 @@ class WavPlan:
         if d.numel() != self.npix or ic.numel() != self.npix:
             raise ValueError("data / invcov length mismatch")
         Tv, Ts = _vecT(T, self.ncoefs, x.device)
-        w, wc = _noise_args(noise, x, noise_complex)
+        w, wc = _pair_noise_args(noise, x) if pairs else _noise_args(noise, x, noise_complex)
         if out is None:
             out = torch.empty_like(x)
         elif out.shape != x.shape or out.dtype != _CPLX or not out.is_contiguous() or out.data_ptr() == x.data_ptr():
@@ -345,14 +357,14 @@ class WavPlan:
             raise AssertionError("ring_init: shape mismatch")
         check(lib.pxm_wav_ring_init(self._h, _p(x), x.shape[0], _stream()))
 
-    def ring_step(self, X, w, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, out=None):
+    def ring_step(self, X, w, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, out=None, pairs=False):
         """calc_gradg + proxf + chain_step + forward for a uniform inverse covariance ``w``; the rings of the
         new state stay inside the plan (``ring_preds`` materialises forward(X) when it is observed)."""
         x, squeeze = _batched(as_device(X, _CPLX))
         if x.shape[1] != self.ncoefs or x.shape[0] > self.max_chains:
             raise AssertionError("ring_step: shape mismatch")
         Tv, Ts = _vecT(T, self.ncoefs, x.device)
-        wn, wc = _noise_args(noise, x, noise_complex)
+        wn, wc = _pair_noise_args(noise, x) if pairs else _noise_args(noise, x, noise_complex)
         if out is None:
             out = torch.empty_like(x)
         elif out.shape != x.shape or out.dtype != _CPLX or not out.is_contiguous() or out.data_ptr() == x.data_ptr():

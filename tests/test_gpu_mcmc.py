@@ -324,3 +324,53 @@ def test_analysis_setting_wavelet_prox_matches_oracle():
     out = ref.myula_run(oop, oreg, lmda, delta, mu, 4, 1, 2, X0.astype(complex), lambda i: np.random.randn(P))
     np.testing.assert_allclose(s.chain, out["chain"], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(s.logPi, np.real(out["logPi"]), rtol=1e-9)
+
+
+@pytest.mark.parametrize("C", [1, 4, 5])
+@pytest.mark.parametrize("sig", ["scalar", "vector"])
+def test_real_pairs_equal_complex_slots(C, sig):
+    """Real data + real start + params.complex False: two real chains per complex slot (PXM_MODE_REAL_PAIRS)
+    reproduce the reference layout (one complex128 slot per chain, zero imaginary part) to round-off, on the
+    ring-space path (scalar sig_d) and the image-space path (vector sig_d), for even and odd chain counts."""
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min = 20, 2, 2
+    rng = np.random.default_rng(12)
+    P = L * (2 * L - 1)
+    data = rng.normal(size=P)
+    sig_d = 0.2 if sig == "scalar" else np.linspace(0.15, 0.3, P)
+    op = SphericalWaveletTransformOperator(data, sig_d, "synthesis", L, B, J_min, max_chains=C)
+    reg = S2_Wavelets_L1("synthesis", None, None, 1e-3, L=L, B=B, J_min=J_min)
+    p = PxMCMCParams(lmda=1e-3, delta=5e-4, nsamples=4, nburn=2, ngap=3, verbosity=0,
+                     track=["logposterior", "L2", "prior", "chain", "predictions"])
+    X0 = rng.normal(size=(C, op.nparams)) * 0.05 if C > 1 else rng.normal(size=op.nparams) * 0.05
+    runs = []
+    for pairs in (True, False):
+        s = MYULA(op, reg, p, nchains=C, seed=13, real_pairs=pairs)
+        _quiet(s.run, start_point=X0)
+        assert s._eng["pairs"] is pairs and s._eng["ring"] is (sig == "scalar")
+        runs.append(s)
+    a, b = runs
+    scale = np.abs(b.chain).max()
+    assert np.abs(a.chain - b.chain).max() < 1e-12 * scale
+    np.testing.assert_allclose(a.logPi, b.logPi, rtol=1e-11)
+    np.testing.assert_allclose(a.priors, b.priors, rtol=1e-12)
+    np.testing.assert_allclose(a.preds, b.preds, rtol=1e-9, atol=1e-12 * np.abs(b.preds).max())
+    assert a.X_curr.shape == b.X_curr.shape and a.X_curr.dtype == b.X_curr.dtype
+    assert float(a.X_curr.imag.abs().max()) == 0.0
+    # complex data (reference-literal topography set-up, complex-variance rule): never paired
+    opc = SphericalWaveletTransformOperator(data.astype(complex), 0.2, "synthesis", L, B, J_min, max_chains=C)
+    s = MYULA(opc, reg, p, nchains=C, seed=13)
+    _quiet(s.run, start_point=X0)
+    assert s._eng["pairs"] is False
+    # injected (reference-order) noise: pairs vs complex slots
+    outs = []
+    for pairs in (True, False):
+        s = MYULA(op, reg, p, nchains=C, rng="numpy", real_pairs=pairs)
+        np.random.seed(21)
+        _quiet(s.run, start_point=X0)
+        assert s._pairs is pairs
+        outs.append(s.chain)
+    assert np.abs(outs[0] - outs[1]).max() < 1e-12 * scale
