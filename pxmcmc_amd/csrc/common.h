@@ -45,6 +45,6 @@ struct BluesteinTables {
   std::vector<double> bhat;   // [M][2]   FFT_M(conj chirp filter) / M, bit-reversed order
   std::vector<double> tw;     // [M/2][2] exp(-2 pi i k / M)
 };
-BluesteinTables make_bluestein(int n);
+BluesteinTables make_bluestein(int n, int M_force = 0);  // M_force: a power of two >= 2n-1, 0 = smallest
 
 }  // namespace pxm

@@ -176,14 +176,16 @@ int make_dft_plan(int L, DftPlan* p) {
       R2 >>= 1;
     }
     p->R2 = R2;
-    p->use3 = (b.M == 1024) && !getenv("PXM_DFT_NO_W");
-    if (p->use3) {
-      const char* e3 = getenv("PXM_DFT_R3");
-      int R3 = e3 ? atoi(e3) : 4;
-      if (R3 != 1 && R3 != 2 && R3 != 4 && R3 != 8) R3 = 4;
-      p->R3 = R3;
-      dft3_geometry(b.n, R3, &p->threads3, &p->lds3);
-    }
+  }
+  const int M3 = getenv("PXM_DFT_NO_W") ? 0 : dft3_size(b.n);
+  if (M3) {  // wave path: square size, its own filter transform and twiddle matrix
+    BluesteinTables b3 = (M3 == b.M) ? b : make_bluestein(b.n, M3);
+    int rc = dft2_make_tables(b3, &p->d_bhatn3, &p->d_twm3);
+    if (rc) return rc;
+    const char* e3 = getenv("PXM_DFT_R3");
+    p->M3 = M3;
+    dft3_geometry(M3, b.n, e3 ? atoi(e3) : 0, &p->R3, &p->TR3, &p->lds3);
+    p->use3 = true;
   }
   static bool attr_set = false;
   if (!attr_set) {
@@ -202,7 +204,9 @@ void free_dft_plan(DftPlan* p) {
   if (p->d_tw) (void)hipFree(p->d_tw);
   if (p->d_bhatn) (void)hipFree(p->d_bhatn);
   if (p->d_twm) (void)hipFree(p->d_twm);
-  p->d_chirp = p->d_bhat = p->d_tw = p->d_bhatn = p->d_twm = nullptr;
+  if (p->d_bhatn3) (void)hipFree(p->d_bhatn3);
+  if (p->d_twm3) (void)hipFree(p->d_twm3);
+  p->d_chirp = p->d_bhat = p->d_tw = p->d_bhatn = p->d_twm = p->d_bhatn3 = p->d_twm3 = nullptr;
 }
 
 static DftArgs make_args(const DftPlan& p) {

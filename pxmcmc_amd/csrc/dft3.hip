@@ -1,38 +1,51 @@
-// phi-DFT stage, M = 1024 (L in 129..256) fast path: ONE WAVE PER RING.
+// phi-DFT stage, wave path: Bluestein with a SQUARE power-of-two size M = N1 x N1, N1 = 2 P,
+// P in {2, 4, 8, 16}  (M = 16, 64, 256, 1024; every ring length n = 2L-1 with L <= 256 uses the
+// smallest such M >= 2n-1).  One ring occupies 2 N1 = 4 P lanes of a wave (a whole wave for M = 1024,
+// 2 / 4 / 8 rings per wave below), P complex points per lane:
 //
-// Same two-factor Bluestein as dft2.hip (1024 = 32 x 32), but every 32-point sub-FFT is shared by a
-// lane pair (h = lane & 1): the first (DIF) or last (DIT) radix-2 stage runs across the pair with a
-// DPP quad_perm exchange, the remaining 16-point FFT lives in each lane's registers.  Compared with
-// one-thread-per-column this halves the registers and the serial instruction stream per thread, and
-// since a ring is exactly one wave the column<->row transposes through LDS need only wave-local
-// ordering (LDS operations of a wave execute in order), no workgroup barrier.
-//   lane = 2*c + h,  c = column j2 (steps 1, 1') or row k1 (step 2),  h = which half of the 32-point FFT
+// every N1-point sub-FFT is shared by a lane pair (h = lane & 1): the first (DIF) or last (DIT)
+// radix-2 stage runs across the pair with a DPP quad_perm exchange, the remaining P-point FFT lives
+// in each lane's registers with compile-time twiddles.  Compared with one-thread-per-column this
+// halves the registers and the serial instruction stream per thread and keeps every lane busy in
+// both the column and the row phase; since a ring never leaves its wave, the column<->row
+// transposes through LDS need only wave-local ordering (LDS operations of a wave execute in order),
+// no workgroup barrier.
+//   lane-in-ring = 2*c + h,  c = column j2 (steps 1, 1') or row k1 (step 2),  h = which half of the sub-FFT
 #include "elem.h"
 #include "sht_core.h"
 #include "update.h"
 #include "tw32.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace pxm {
 
-// ---- shared with dft2.hip (kept local: templates) ------------------------------------------
 template <int SGN>
 __device__ __forceinline__ double2 w32(int k) {
   return double2{kCos32[k], SGN * kSin32[k]};
 }
 template <int SGN>
-__device__ __forceinline__ double2 mulw(double2 v, int k32) {
+__device__ __forceinline__ double2 mulw(double2 v, int k32) {  // v * exp(SGN 2 pi i k32 / 32)
   if (k32 == 0) return v;
   if (k32 == 8) return SGN < 0 ? double2{v.y, -v.x} : double2{-v.y, v.x};
   return cmul(v, w32<SGN>(k32));
 }
-__host__ __device__ constexpr int br16(int i) { return ((i & 1) << 3) | ((i & 2) << 1) | ((i & 4) >> 1) | ((i & 8) >> 3); }
+template <int P>
+__host__ __device__ constexpr int brp(int i) {  // bit reversal over log2(P) bits
+  int r = 0;
+  for (int b = 1, t = P >> 1; b < P; b <<= 1, t >>= 1)
+    if (i & b) r |= t;
+  return r;
+}
 
-template <int SGN>
-__device__ __forceinline__ void dif16(double2 (&x)[16]) {  // natural in, bit-reversed out
+// P-point FFTs in registers; W_{2s}^p = W_32^(16 p / s)
+template <int SGN, int P>
+__device__ __forceinline__ void difp(double2 (&x)[P]) {  // natural in, bit-reversed out
 #pragma unroll
-  for (int s = 8; s >= 1; s >>= 1)
+  for (int s = P / 2; s >= 1; s >>= 1)
 #pragma unroll
-    for (int g = 0; g < 16; g += 2 * s)
+    for (int g = 0; g < P; g += 2 * s)
 #pragma unroll
       for (int p = 0; p < s; ++p) {
         const double2 u = x[g + p], v = x[g + p + s];
@@ -40,12 +53,12 @@ __device__ __forceinline__ void dif16(double2 (&x)[16]) {  // natural in, bit-re
         x[g + p + s] = mulw<SGN>(csub(u, v), p * (16 / s));
       }
 }
-template <int SGN>
-__device__ __forceinline__ void dit16(double2 (&x)[16]) {  // bit-reversed in, natural out
+template <int SGN, int P>
+__device__ __forceinline__ void ditp(double2 (&x)[P]) {  // bit-reversed in, natural out
 #pragma unroll
-  for (int s = 1; s <= 8; s <<= 1)
+  for (int s = 1; s <= P / 2; s <<= 1)
 #pragma unroll
-    for (int g = 0; g < 16; g += 2 * s)
+    for (int g = 0; g < P; g += 2 * s)
 #pragma unroll
       for (int p = 0; p < s; ++p) {
         const double2 u = x[g + p], v = mulw<SGN>(x[g + p + s], p * (16 / s));
@@ -73,80 +86,111 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 struct Dft3Args {
-  int L, n, Rp, R;
+  int L, n, Rp;
+  int R, TR;             // chains x rings handled by one workgroup (R * TR = 256 / (4 P) ring slots)
   const double2* chirp;  // [n]
-  const double2* bhatn;  // [1024] FFT(filter)/M, natural order
-  const double2* twm;    // [32][32] W_1024^(k1 j2) at [j2*32 + k1]
+  const double2* bhatn;  // [M] FFT(filter)/M, natural order
+  const double2* twm;    // [N1][N1] W_M^(k1 j2) (symmetric)
 };
 
-constexpr int P33 = 33;  // LDS plane pitch (doubles)
+// geometry of the P-variant
+template <int P>
+struct G3 {
+  static constexpr int N1 = 2 * P, M = N1 * N1, LPR = 2 * N1, PITCH = N1 + 1, TS = 32 / N1;
+  static constexpr int UNITS = 256 / LPR;  // ring slots per 256-thread workgroup
+  static constexpr int H = P / 2;          // outputs per lane
+};
 
-// transpose one real plane through LDS: element (row ro[i], col co) written, (row ri, col ci[i]) read
-#define PXM_PLANE_XPOSE(SRC, FIELD, DST, WADDR, RADDR)        \
-  _Pragma("unroll") for (int i = 0; i < 16; ++i) mat[WADDR] = SRC[i].FIELD; \
-  wave_sync();                                                \
-  _Pragma("unroll") for (int i = 0; i < 16; ++i) DST[i].FIELD = mat[RADDR]; \
+// transpose one real plane through LDS: element written at WADDR, read at RADDR
+#define PXM_PLANE_XPOSE(SRC, FIELD, DST, WADDR, RADDR)                      \
+  _Pragma("unroll") for (int i = 0; i < P; ++i) mat[WADDR] = SRC[i].FIELD;  \
+  wave_sync();                                                              \
+  _Pragma("unroll") for (int i = 0; i < P; ++i) DST[i].FIELD = mat[RADDR];  \
   wave_sync();
 
-// Bluestein convolution core of one ring on one wave.  In: z[p] = a[p*32 + c] (p < 16; the upper half
-// of the column is Bluestein's zero padding), identical in both lanes of a pair.  Out: z[q] =
-// conv[(q + 8h)*32 + c], q < 8.
-__device__ __forceinline__ void bluestein_w(double2 (&z)[16], double* mat, int c, int h, const Dft3Args& a) {
+// Bluestein convolution core of one ring on its 4P lanes.  In: z[p] = a[p*N1 + c] (p < P; the upper
+// half of the column is Bluestein's zero padding), identical in both lanes of a pair.  Out: z[q] =
+// conv[(q + (P/2) h)*N1 + c], q < P/2.
+template <int P>
+__device__ __forceinline__ void bluestein_w(double2 (&z)[P], double* mat, int c, int h, const Dft3Args& a) {
+  constexpr int N1 = G3<P>::N1, PITCH = G3<P>::PITCH, TS = G3<P>::TS, H = G3<P>::H;
   // ---- step 1: column FFT over j1 (DIF, upper half zero): lane h takes the outputs k1 = 2q + h
 #pragma unroll
-  for (int p = 1; p < 16; ++p) z[p] = sel(h, mulw<-1>(z[p], p), z[p]);
-  dif16<-1>(z);  // z[i] = A[k1 = 2 br16(i) + h][c]
+  for (int p = 1; p < P; ++p) z[p] = sel(h, mulw<-1>(z[p], p * TS), z[p]);
+  difp<-1, P>(z);  // z[i] = A[k1 = 2 brp(i) + h][c]
 #pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = cmul(z[i], a.twm[c * 32 + 2 * br16(i) + h]);
-  double2 y[16];
-  PXM_PLANE_XPOSE(z, x, y, (2 * br16(i) + h) * P33 + c, c * P33 + i + 16 * h)
-  PXM_PLANE_XPOSE(z, y, y, (2 * br16(i) + h) * P33 + c, c * P33 + i + 16 * h)
+  for (int i = 0; i < P; ++i) z[i] = cmul(z[i], a.twm[(2 * brp<P>(i) + h) * N1 + c]);  // W^(k1 c): symmetric table
+  double2 y[P];
+  PXM_PLANE_XPOSE(z, x, y, (2 * brp<P>(i) + h) * PITCH + c, c * PITCH + i + P * h)
+  PXM_PLANE_XPOSE(z, y, y, (2 * brp<P>(i) + h) * PITCH + c, c * PITCH + i + P * h)
   // ---- step 2: row k1 = c.  Forward over j2: first DIF stage across the lane pair
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
+  for (int p = 0; p < P; ++p) {
     const double2 o = xchg2(y[p]);
-    y[p] = sel(h, mulw<-1>(csub(o, y[p]), p), cadd(y[p], o));
+    y[p] = sel(h, mulw<-1>(csub(o, y[p]), p * TS), cadd(y[p], o));
   }
-  dif16<-1>(y);  // y[i] = X[c + 32 k2], k2 = 2 br16(i) + h
+  difp<-1, P>(y);  // y[i] = X[c + N1 k2], k2 = 2 brp(i) + h
 #pragma unroll
-  for (int i = 0; i < 16; ++i) y[i] = cmul(y[i], a.bhatn[c + 32 * (2 * br16(i) + h)]);
-  dit16<+1>(y);  // inverse over k2: E[p] (h = 0) / O[p] (h = 1)
+  for (int i = 0; i < P; ++i) y[i] = cmul(y[i], a.bhatn[c + N1 * (2 * brp<P>(i) + h)]);
+  ditp<+1, P>(y);  // inverse over k2: E[p] (h = 0) / O[p] (h = 1)
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    const double2 v = sel(h, mulw<+1>(y[p], p), y[p]);
+  for (int p = 0; p < P; ++p) {
+    const double2 v = sel(h, mulw<+1>(y[p], p * TS), y[p]);
     const double2 o = xchg2(v);
-    const double2 r = sel(h, csub(o, v), cadd(v, o));  // C[c][j2 = p + 16 h]
-    y[p] = cmulc(r, a.twm[(p + 16 * h) * 32 + c]);
+    const double2 r = sel(h, csub(o, v), cadd(v, o));  // C[c][j2 = p + P h]
+    y[p] = cmulc(r, a.twm[(p + P * h) * N1 + c]);
   }
   // ---- step 1': column c, inverse over k1 (DIT), lane h takes the inputs k1 = 2q + h
-  PXM_PLANE_XPOSE(y, x, z, c * P33 + i + 16 * h, (2 * br16(i) + h) * P33 + c)
-  PXM_PLANE_XPOSE(y, y, z, c * P33 + i + 16 * h, (2 * br16(i) + h) * P33 + c)
-  dit16<+1>(z);  // E[p] / O[p]
+  PXM_PLANE_XPOSE(y, x, z, c * PITCH + i + P * h, (2 * brp<P>(i) + h) * PITCH + c)
+  PXM_PLANE_XPOSE(y, y, z, c * PITCH + i + P * h, (2 * brp<P>(i) + h) * PITCH + c)
+  ditp<+1, P>(z);  // E[p] / O[p]
 #pragma unroll
-  for (int p = 1; p < 16; ++p) z[p] = sel(h, mulw<+1>(z[p], p), z[p]);
-  // wanted outputs j1 = p < 16: y[p] = E[p] + t[p]; lane 0 of the pair produces p < 8, lane 1 p >= 8
+  for (int p = 1; p < P; ++p) z[p] = sel(h, mulw<+1>(z[p], p * TS), z[p]);
+  // wanted outputs j1 = p < P: E[p] + t[p]; lane 0 of the pair produces p < P/2, lane 1 p >= P/2
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const double2 recv = xchg2(sel(h, z[q], z[8 + q]));
-    z[q] = cadd(sel(h, z[8 + q], z[q]), recv);
+  for (int q = 0; q < H; ++q) {
+    const double2 recv = xchg2(sel(h, z[q], z[H + q]));
+    z[q] = cadd(sel(h, z[H + q], z[q]), recv);
   }
 }
 
+// thread -> (ring slot, lane in ring); ring slot -> (ring of the workgroup, chain of the workgroup)
+#define PXM_W_GEOMETRY                                                                \
+  constexpr int N1 = G3<P>::N1, LPR = G3<P>::LPR, PITCH = G3<P>::PITCH, H = G3<P>::H; \
+  const int R = a.R, TR = a.TR, n = a.n;                                              \
+  const int unit = threadIdx.x / LPR, lr = threadIdx.x % LPR;                         \
+  const int c = lr >> 1, h = lr & 1;                                                  \
+  const int tr = unit / R, r = unit - tr * R;                                         \
+  const int t = blockIdx.x * TR + tr, c0 = blockIdx.y * R;                            \
+  const int ch = c0 + r;                                                              \
+  const bool tv = t < a.L;                                                            \
+  const int Cp = ncol >> 1;                                                           \
+  double2* stage = lds3;                                                              \
+  double* mat = reinterpret_cast<double*>(lds3) + unit * (N1 * PITCH);
+
+// stage[(tr*n + k)*(R+1) + r] -> G rows of every ring of the workgroup (16-B x R segments per m)
+#define PXM_W_STORE_RINGS                                                                                      \
+  for (int idx = threadIdx.x; idx < TR * n * R; idx += blockDim.x) {                                           \
+    const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);                                            \
+    const int tt = blockIdx.x * TR + trr;                                                                      \
+    if (c0 + rr >= Cp || tt >= a.L) continue;                                                                  \
+    const int m = (k < a.L) ? k : k - n;                                                                       \
+    reinterpret_cast<double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + tt) * Cp + c0 + rr] =                      \
+        stage[(trr * n + k) * (R + 1) + rr];                                                                   \
+  }
+
+template <int P>
 __global__ __launch_bounds__(256, 2) void k_px2ring_w(Dft3Args a, PxIn in, double* __restrict__ G, int ncol, int C) {
   extern __shared__ double2 lds3[];
-  const int R = a.R, n = a.n;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c = lane >> 1, h = lane & 1;
-  const int t = blockIdx.x, c0 = blockIdx.y * R;
-  const int ch = c0 + wave;
+  PXM_W_GEOMETRY
+  (void)LPR;
   if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
-  double* mat = reinterpret_cast<double*>(lds3) + wave * (32 * P33);
-  double2 z[16];
+  double2 z[P];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    const int j = p * 32 + c;
+  for (int p = 0; p < P; ++p) {
+    const int j = p * N1 + c;
     double2 v{0.0, 0.0};
-    if (j < n && ch < C) {
+    if (j < n && ch < C && tv) {
       const int64_t e = in.ring0 + (int64_t)t * n + j;
       v = reinterpret_cast<const double2*>(in.f)[(int64_t)ch * in.chain_stride + e];
       if (in.data) {  // residual invcov .* (preds - data)   (pxmcmc/forward.py:66-69)
@@ -161,101 +205,90 @@ __global__ __launch_bounds__(256, 2) void k_px2ring_w(Dft3Args a, PxIn in, doubl
     }
     z[p] = v;
   }
-  bluestein_w(z, mat, c, h, a);
+  bluestein_w<P>(z, mat, c, h, a);
   __syncthreads();  // the planes are dead; reuse LDS as the [j][chain] layout-transpose stage
-  double2* stage = lds3;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int j = (q + 8 * h) * 32 + c;
-    if (j < n) stage[j * (R + 1) + wave] = cmul(z[q], a.chirp[j]);
+  for (int q = 0; q < H; ++q) {
+    const int j = (q + H * h) * N1 + c;
+    if (j < n) stage[(tr * n + j) * (R + 1) + r] = cmul(z[q], a.chirp[j]);
   }
   __syncthreads();
-  const int Cp = ncol >> 1;
-  for (int idx = threadIdx.x; idx < n * R; idx += blockDim.x) {
-    const int k = idx / R, rr = idx - k * R;
-    if (c0 + rr >= Cp) continue;
-    const int m = (k < a.L) ? k : k - n;
-    reinterpret_cast<double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + t) * Cp + c0 + rr] = stage[k * (R + 1) + rr];
-  }
+  PXM_W_STORE_RINGS
 }
 
 // RING_OUT: after the (fused MYULA) epilogue the updated ring is transformed again and its rings are
 // written back IN PLACE over G -- rings of S X -> X' and rings of X' in one kernel (ring-space step).
-template <bool RING_OUT>
+template <int P, bool RING_OUT>
 __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __restrict__ G, int ncol, PxOut out, int C) {
   extern __shared__ double2 lds3[];
-  const int R = a.R, n = a.n;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int c = lane >> 1, h = lane & 1;
-  const int t = blockIdx.x, c0 = blockIdx.y * R;
-  const int ch = c0 + wave;
-  const int Cp = ncol >> 1;
-  double2* stage = lds3;
+  PXM_W_GEOMETRY
+  (void)LPR;
   {
-    constexpr int U = 8;  // batches of independent loads: the memory latency is paid once per batch
-    const int total = n * R;
-    for (int base = threadIdx.x; base < total; base += U * blockDim.x) {
-      double2 v[U];
+    constexpr int NB = 8;  // batches of independent loads: the memory latency is paid once per batch
+    const int total = TR * n * R;
+    for (int base = threadIdx.x; base < total; base += NB * blockDim.x) {
+      double2 v[NB];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int idx = base + u * blockDim.x;
-        const int k = idx / R, rr = idx - k * R;
+        const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);
+        const int tt = blockIdx.x * TR + trr;
         v[u] = double2{0.0, 0.0};
-        if (idx < total && c0 + rr < Cp) {
+        if (idx < total && c0 + rr < Cp && tt < a.L) {
           const int m = (k < a.L) ? k : k - n;
-          v[u] = reinterpret_cast<const double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + t) * Cp + c0 + rr];
+          v[u] = reinterpret_cast<const double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + tt) * Cp + c0 + rr];
         }
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
+      for (int u = 0; u < NB; ++u) {
         const int idx = base + u * blockDim.x;
         if (idx < total) {
-          const int k = idx / R, rr = idx - k * R;
+          const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);
           double2 w = v[u];
           w.y = -w.y;  // inverse DFT by conjugation: y = conj(DFT(conj x))
-          stage[k * (R + 1) + rr] = cmul(w, a.chirp[k]);
+          stage[(trr * n + k) * (R + 1) + rr] = cmul(w, a.chirp[k]);
         }
       }
     }
   }
   __syncthreads();
-  double2 z[16];
+  double2 z[P];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    const int j = p * 32 + c;
-    z[p] = (j < n) ? stage[j * (R + 1) + wave] : double2{0.0, 0.0};
+  for (int p = 0; p < P; ++p) {
+    const int j = p * N1 + c;
+    z[p] = (j < n) ? stage[(tr * n + j) * (R + 1) + r] : double2{0.0, 0.0};
   }
   __syncthreads();
-  double* mat = reinterpret_cast<double*>(lds3) + wave * (32 * P33);
-  bluestein_w(z, mat, c, h, a);
-  if (!RING_OUT && ch >= C) return;
-  const bool act = ch < C;
-  const int64_t e0 = out.ring0 + (int64_t)t * n + (8 * h) * 32 + c;  // element of q = 0; q advances by 32
+  bluestein_w<P>(z, mat, c, h, a);
+  const bool act = ch < C && tv;
+  if (!RING_OUT && !act) return;
+  const int64_t e0 = out.ring0 + (int64_t)t * n + (H * h) * N1 + c;  // element of q = 0; q advances by N1
   const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
-  double2 zn[8];  // the ring as written to out.f (RING_OUT: input of the forward transform)
+  double2 zn[H];  // the ring as written to out.f (RING_OUT: input of the forward transform)
 #pragma unroll
-  for (int q = 0; q < 8; ++q) zn[q] = double2{0.0, 0.0};
+  for (int q = 0; q < H; ++q) zn[q] = double2{0.0, 0.0};
   if (act && out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
     const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
+    constexpr int EB = H < 4 ? H : 4;  // all loads of a group first (independent), then its arithmetic
 #pragma unroll
-    for (int g0 = 0; g0 < 8; g0 += 4) {
-      double2 xs[4], wn[4];
-      double Ts[4];
+    for (int g0 = 0; g0 < H; g0 += EB) {
+      double2 xs[EB], wn[EB];
+      double Ts[EB];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < EB; ++u) {
         const int q = g0 + u;
-        const bool ok = (q + 8 * h) * 32 + c < n;
-        const int64_t off = (int64_t)q * 32;
+        const bool ok = (q + H * h) * N1 + c < n;
+        const int64_t off = (int64_t)q * N1;
         xs[u] = ok ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
         Ts[u] = (ok && out.T) ? out.T[e0 + off] : out.T_scalar;
         wn[u] = (ok && out.noise) ? px_noise_load(out, ch, e0 + off) : double2{0.0, 0.0};
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < EB; ++u) {
         const int q = g0 + u;
-        const int p = (q + 8 * h) * 32 + c;
+        const int p = (q + H * h) * N1 + c;
         if (p >= n) continue;
-        const int64_t off = (int64_t)q * 32;
+        const int64_t off = (int64_t)q * N1;
         double2 y = cmul(z[q], a.chirp[p]);
         y.y = -y.y;
         double2 w = wn[u];
@@ -266,90 +299,119 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __rest
     }
   } else if (act) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int p = (q + 8 * h) * 32 + c;
+    for (int q = 0; q < H; ++q) {
+      const int p = (q + H * h) * N1 + c;
       if (p >= n) continue;
       double2 y = cmul(z[q], a.chirp[p]);
       y.y = -y.y;
       zn[q] = y;
-      reinterpret_cast<double2*>(out.f)[ce0 + (int64_t)q * 32] = y;
+      reinterpret_cast<double2*>(out.f)[ce0 + (int64_t)q * N1] = y;
     }
   }
   if (!RING_OUT) return;
-  // ---- forward transform of the updated ring: the column needs all 16 entries in both lanes of a pair
+  // ---- forward transform of the updated ring: the column needs all P entries in both lanes of a pair
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < H; ++q) {
     const double2 other = xchg2(zn[q]);
-    z[q] = sel(h, other, zn[q]);       // p = q      (owned by the h = 0 lane)
-    z[8 + q] = sel(h, zn[q], other);   // p = 8 + q  (owned by the h = 1 lane)
+    z[q] = sel(h, other, zn[q]);       // p = q        (owned by the h = 0 lane)
+    z[H + q] = sel(h, zn[q], other);   // p = P/2 + q  (owned by the h = 1 lane)
   }
 #pragma unroll
-  for (int p = 0; p < 16; ++p) {
-    const int j = p * 32 + c;
+  for (int p = 0; p < P; ++p) {
+    const int j = p * N1 + c;
     z[p] = (j < n) ? cmul(z[p], a.chirp[j]) : double2{0.0, 0.0};
   }
-  bluestein_w(z, mat, c, h, a);
+  bluestein_w<P>(z, mat, c, h, a);
   __syncthreads();  // the planes are dead; reuse LDS as the [j][chain] layout-transpose stage
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const int j = (q + 8 * h) * 32 + c;
-    if (j < n) stage[j * (R + 1) + wave] = cmul(z[q], a.chirp[j]);
+  for (int q = 0; q < H; ++q) {
+    const int j = (q + H * h) * N1 + c;
+    if (j < n) stage[(tr * n + j) * (R + 1) + r] = cmul(z[q], a.chirp[j]);
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < n * R; idx += blockDim.x) {
-    const int k = idx / R, rr = idx - k * R;
-    if (c0 + rr >= Cp) continue;
-    const int m = (k < a.L) ? k : k - n;
-    reinterpret_cast<double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + t) * Cp + c0 + rr] = stage[k * (R + 1) + rr];
-  }
+  PXM_W_STORE_RINGS
 }
 
 // ---- host side -----------------------------------------------------------------------------
-void dft3_geometry(int n, int R, int* threads, size_t* lds) {
-  *threads = 64 * R;
-  const size_t planes = (size_t)R * 32 * P33 * 8, stage = (size_t)n * (R + 1) * 16;
+// smallest square size (16, 64, 256, 1024) holding the Bluestein convolution of a length-n ring; 0 = none
+int dft3_size(int n) {
+  for (int M = 16; M <= 1024; M *= 4)
+    if (M >= 2 * n - 1) return M;
+  return 0;
+}
+static int dft3_P(int M) { return M == 1024 ? 16 : M == 256 ? 8 : M == 64 ? 4 : 2; }
+
+void dft3_geometry(int M, int n, int R_want, int* R, int* TR, size_t* lds) {
+  const int P = dft3_P(M), N1 = 2 * P, units = 256 / (4 * P);
+  int r = std::min(units, 8);
+  if (R_want > 0 && R_want <= r && units % R_want == 0) r = R_want;
+  *R = r;
+  *TR = units / r;
+  const size_t planes = (size_t)units * N1 * (N1 + 1) * 8, stage = (size_t)(*TR) * n * (r + 1) * 16;
   *lds = std::max(planes, stage);
 }
 
+template <int P>
 static int dft3_attr() {
   static bool done = false;
   if (!done) {
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring_w), hipFuncAttributeMaxDynamicSharedMemorySize,
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring_w<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<P, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<P, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
   return 0;
 }
 
-int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
-  if (int rc = dft3_attr()) return rc;
-  Dft3Args a{p.L, p.n, p.Rp, p.R3, reinterpret_cast<const double2*>(p.d_chirp),
-             reinterpret_cast<const double2*>(p.d_bhatn), reinterpret_cast<const double2*>(p.d_twm)};
+static Dft3Args dft3_args(const DftPlan& p) {
+  return Dft3Args{p.L, p.n, p.Rp, p.R3, p.TR3, reinterpret_cast<const double2*>(p.d_chirp),
+                  reinterpret_cast<const double2*>(p.d_bhatn3), reinterpret_cast<const double2*>(p.d_twm3)};
+}
+
+template <int P>
+static int px2ring_p(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
+  if (int rc = dft3_attr<P>()) return rc;
   const int Cp = ncol / 2;
-  dim3 grid(p.L, (Cp + p.R3 - 1) / p.R3), block(p.threads3);
-  hipLaunchKernelGGL(k_px2ring_w, grid, block, p.lds3, st, a, in, G, ncol, C);
+  dim3 grid((p.L + p.TR3 - 1) / p.TR3, (Cp + p.R3 - 1) / p.R3), block(256);
+  hipLaunchKernelGGL((k_px2ring_w<P>), grid, block, p.lds3, st, dft3_args(p), in, G, ncol, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
-int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
-  if (int rc = dft3_attr()) return rc;
-  Dft3Args a{p.L, p.n, p.Rp, p.R3, reinterpret_cast<const double2*>(p.d_chirp),
-             reinterpret_cast<const double2*>(p.d_bhatn), reinterpret_cast<const double2*>(p.d_twm)};
-  dim3 grid(p.L, (C + p.R3 - 1) / p.R3), block(p.threads3);
+template <int P>
+static int ring2px_p(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
+  if (int rc = dft3_attr<P>()) return rc;
+  dim3 grid((p.L + p.TR3 - 1) / p.TR3, (C + p.R3 - 1) / p.R3), block(256);
   if (ring_out) {
     // every chain group must run: padded chains get zero rings written back
-    grid = dim3(p.L, (ncol / 2 + p.R3 - 1) / p.R3);
-    hipLaunchKernelGGL(k_ring2px_w<true>, grid, block, p.lds3, st, a, const_cast<double*>(G), ncol, out, C);
+    grid.y = (ncol / 2 + p.R3 - 1) / p.R3;
+    hipLaunchKernelGGL((k_ring2px_w<P, true>), grid, block, p.lds3, st, dft3_args(p), const_cast<double*>(G), ncol, out, C);
   } else {
-    hipLaunchKernelGGL(k_ring2px_w<false>, grid, block, p.lds3, st, a, const_cast<double*>(G), ncol, out, C);
+    hipLaunchKernelGGL((k_ring2px_w<P, false>), grid, block, p.lds3, st, dft3_args(p), const_cast<double*>(G), ncol, out, C);
   }
   PXM_HIP(hipGetLastError());
   return 0;
+}
+
+int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
+  switch (dft3_P(p.M3)) {
+    case 16: return px2ring_p<16>(p, in, G, ncol, C, st);
+    case 8: return px2ring_p<8>(p, in, G, ncol, C, st);
+    case 4: return px2ring_p<4>(p, in, G, ncol, C, st);
+    default: return px2ring_p<2>(p, in, G, ncol, C, st);
+  }
+}
+
+int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
+  switch (dft3_P(p.M3)) {
+    case 16: return ring2px_p<16>(p, G, ncol, out, C, st, ring_out);
+    case 8: return ring2px_p<8>(p, G, ncol, out, C, st, ring_out);
+    case 4: return ring2px_p<4>(p, G, ncol, out, C, st, ring_out);
+    default: return ring2px_p<2>(p, G, ncol, out, C, st, ring_out);
+  }
 }
 
 }  // namespace pxm

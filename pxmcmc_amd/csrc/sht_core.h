@@ -121,10 +121,11 @@ struct DftPlan {
   int R2 = 0, threads2 = 0;
   size_t lds2 = 0;
   double *d_bhatn = nullptr, *d_twm = nullptr;
-  // wave-per-ring path (dft3.hip), used when M == 1024
+  // wave path (dft3.hip): square Bluestein size M3 in {16, 64, 256, 1024}, used for every L <= 256
   bool use3 = false;
-  int R3 = 0, threads3 = 0;
+  int M3 = 0, R3 = 0, TR3 = 0;  // R3 chains x TR3 rings per workgroup
   size_t lds3 = 0;
+  double *d_bhatn3 = nullptr, *d_twm3 = nullptr;
 };
 
 int make_dft_plan(int L, DftPlan* p);
@@ -160,7 +161,8 @@ int dft2_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm)
 void dft2_geometry(int M, int n, int R, int* threads, size_t* lds);
 int dft2_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft2_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
-void dft3_geometry(int n, int R, int* threads, size_t* lds);
+int dft3_size(int n);  // square Bluestein size of the wave path for ring length n, 0 = none
+void dft3_geometry(int M, int n, int R_want, int* R, int* TR, size_t* lds);
 int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
 

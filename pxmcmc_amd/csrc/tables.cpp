@@ -178,11 +178,12 @@ void quadrature_gram(int L, int par, double* Q, int ld) {
   }
 }
 
-BluesteinTables make_bluestein(int n) {
+BluesteinTables make_bluestein(int n, int M_force) {
   BluesteinTables b;
   b.n = n;
   int M = 16;
   while (M < 2 * n - 1) M <<= 1;
+  if (M_force > M) M = M_force;
   b.M = M;
   b.logM = 0;
   while ((1 << b.logM) < M) ++b.logM;
