@@ -190,6 +190,13 @@ int pxm_wl_mask_gather(const void* f, const int64_t* idx, const double* w, void*
 int pxm_wl_mask_scatter(const void* g, const int64_t* idx, const double* w, void* f, int64_t npix,
                         int64_t ndata, int C, pxm_stream_t stream);
 
+/* ---- sparse path-integral measurement (pxmcmc/measurements.py:59-83) ---------------------- */
+/* y[c][row] = sum_k vals[k] x[c][indices[k]], k in [indptr[row], indptr[row+1]): PathIntegral.forward with
+ * the CSR of path_matrix, PathIntegral.adjoint with the CSR of path_matrix.getH().  vals: float64, or
+ * complex128 iff vals_complex; x: [C][ncols], y: [C][nrows], float64 (dtype 0) or complex128 (dtype 1). */
+int pxm_csr_matvec(const int64_t* indptr, const int32_t* indices, const void* vals, int vals_complex,
+                   int64_t nrows, int64_t ncols, const void* x, void* y, int C, int dtype, pxm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,6 +202,60 @@ class S2_Wavelets_L1(L1):
         return np.sum(np.abs(self.map_weights * X))
 
 
+def power_weights(phi_l, psi_lm, bls, eta):
+    """S2_Wavelets_L1_Power_Weights._get_weights given the tiling (pxmcmc/prior.py:113-149): per scale
+    2 pi^2 peak_l^eta / (power nsamples) sin(theta) on that scale's MW grid (scaling: peak factor absent)."""
+    def grid(Le, value):
+        theta = np.pi * (2 * np.arange(Le) + 1) / (2 * Le - 1)          # pyssht.sample_positions [ext]
+        w = np.full((Le, 2 * Le - 1), value)                            # sample_shape / sample_length [ext]
+        return ((w.T * np.sin(theta)).T).flatten()
+
+    scaling_power = np.vdot(phi_l, phi_l).real
+    Ls = int(np.nonzero(phi_l)[0].max()) + 1
+    out = [grid(Ls, 2 * np.pi ** 2 / (scaling_power * Ls * (2 * Ls - 1)))]
+    L = len(phi_l)
+    powers = np.array([np.vdot(lm, lm).real for lm in psi_lm.T])
+    psi_l = np.array([[psi[el ** 2 + el] for el in range(L)] for psi in psi_lm.T])
+    peaks = np.array([np.argmax(r) for r in psi_l])
+    for Le, power, peak in zip(bls[1:], powers, peaks):
+        out.append(grid(Le, (2 * np.pi ** 2) * (peak ** eta) / (power * Le * (2 * Le - 1))))
+    return np.concatenate(out)
+
+
+class S2_Wavelets_L1_Power_Weights(S2_Wavelets_L1):
+    """pxmcmc/prior.py:87-149.  Note the reference's double application: T carries quadrature AND power
+    weights (:81,108) and prior() weights X twice with the power weights (:110-111 through :83-84)."""
+
+    def __init__(self, setting, fwd, adj, T, L, B, J_min, eta=1, tiling=None):
+        super().__init__(setting, fwd, adj, T, L, B, J_min)
+        phi_l, psi_lm = tiling if tiling is not None else s2let.wavelet_tiling(B, L, 1, J_min)
+        bls = s2let.bandlimits_from_support(B, L, J_min)
+        self.map_weights = power_weights(phi_l, psi_lm, bls, eta)
+        self.T = self.T * self.map_weights
+
+    def prior(self, X):
+        return np.sum(np.abs(self.map_weights * (self.map_weights * X)))
+
+
+class PathIntegral:
+    """pxmcmc/measurements.py:59-83"""
+
+    def __init__(self, path_matrix):
+        import scipy.sparse as sp
+
+        self.path_matrix = sp.csr_matrix(path_matrix)
+        self.path_matrix_adj = self.path_matrix.conj().T.tocsr()
+        self.ndata, self.npix = self.path_matrix.shape
+
+    def forward(self, X):
+        assert len(X) == self.npix
+        return self.path_matrix.dot(X)
+
+    def adjoint(self, Y):
+        assert len(Y) == self.ndata
+        return self.path_matrix_adj.dot(Y)
+
+
 # ---- pxmcmc/mcmc.py:71-82, 185-201, 277-289 ------------------------------------
 def logpi(X, preds, data, invcov, prior_fn, mu):
     diff = data - preds

@@ -82,6 +82,20 @@ def tiling_axisym(B, L, J_min):
     return kappa0, kappa
 
 
+def wavelet_tiling(B, L, N, J_min, spin=0):
+    """pys2let.wavelet_tiling [ext, parity unpinned]: phi_l[L] = sqrt((2l+1)/4pi) kappa0(l) and
+    psi_lm[L*L, nscales] with psi_{l0} = sqrt((2l+1)/8pi^2) kappa_j(l), one column per j = J_min..J_max
+    (consumers pxmcmc/utils.py:117, prior.py:121,132)."""
+    assert N == 1 and spin == 0
+    k0, k = tiling_axisym(B, L, J_min)
+    el = np.arange(L)
+    phi_l = np.sqrt((2 * el + 1) / (4 * np.pi)) * k0
+    psi_lm = np.zeros((L * L, k.shape[0] - J_min), dtype=complex)
+    for col, j in enumerate(range(J_min, k.shape[0])):
+        psi_lm[el * el + el, col] = np.sqrt((2 * el + 1) / (8 * np.pi ** 2)) * k[j]
+    return phi_l, psi_lm
+
+
 def bandlimits(B, L, J_min):
     """[scaling, j=J_min..J_max] multiresolution bandlimits (pxmcmc/utils.py:116-125)."""
     J = j_max(B, L, J_min)

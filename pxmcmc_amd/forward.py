@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .measurements import Identity
+from .measurements import Identity, PathIntegral
 from .transforms import SphericalWaveletTransform
 from .utils import mw_size, to_like
 
@@ -134,6 +134,19 @@ class SphericalWaveletTransformOperator(ForwardOperator):
     def __init__(self, data, sig_d, setting, L, B, J_min, dirs=1, spin=0, max_chains=1):
         transform = SphericalWaveletTransform(L, B, J_min, dirs=dirs, spin=spin, max_chains=max_chains)
         measurement = Identity(len(data), mw_size(L))
+        if setting == "analysis":
+            nparams = mw_size(L)
+        else:
+            nparams = transform.ncoefs
+        super().__init__(data, sig_d, setting, transform=transform, measurement=measurement, nparams=nparams)
+
+
+class PathIntegralOperator(ForwardOperator):
+    """Spherical wavelet transform + path-integral measurement (pxmcmc/forward.py:126-162)."""
+
+    def __init__(self, pathmatrix, data, sig_d, setting, L, B, J_min, dirs=1, spin=0, max_chains=1):
+        transform = SphericalWaveletTransform(L, B, J_min, dirs=dirs, spin=spin, max_chains=max_chains)
+        measurement = PathIntegral(pathmatrix)
         if setting == "analysis":
             nparams = mw_size(L)
         else:

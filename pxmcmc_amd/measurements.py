@@ -1,6 +1,6 @@
 """
 Measurement plugin API of the reference (pxmcmc/measurements.py) on the GPU:
-``Identity`` and the weak-lensing operators.  ``PathIntegral`` is a "next" row.
+``Identity``, ``PathIntegral`` (sparse matrix) and the weak-lensing operators.
 """
 from warnings import warn
 
@@ -51,6 +51,33 @@ class Identity(Measurement):
             out = np.zeros(Y.shape[:-1] + (self.npix,), dtype=np.asarray(Y).dtype)
         out[..., : self.ndata] = Y
         return out
+
+
+class PathIntegral(Measurement):
+    """
+    Path integration using a (sparse) matrix that describes a set of paths (pxmcmc/measurements.py:59-83).
+    The matrix and its Hermitian transpose (the reference's ``path_matrix.getH()``) are held on the GPU in
+    CSR form; both products are one HIP SpMV over the chain batch.
+
+    :param path_matrix: :math:`N_{\\mathrm{paths}}\\times N_{\\mathrm{pix}}` scipy.sparse (or dense) matrix
+    """
+
+    def __init__(self, path_matrix):
+        import scipy.sparse as sp
+
+        self.path_matrix = path_matrix if sp.issparse(path_matrix) else sp.csr_matrix(np.asarray(path_matrix))
+        self.path_matrix_adj = self.path_matrix.conj().T.tocsr()  # == getH()
+        self.ndata, self.npix = self.path_matrix.shape
+        self._A = ops.CsrMatrix(self.path_matrix)
+        self._AH = ops.CsrMatrix(self.path_matrix_adj)
+
+    def forward(self, X):
+        assert X.shape[-1] == self.npix
+        return to_like(self._A.matvec(X), X)
+
+    def adjoint(self, Y):
+        assert Y.shape[-1] == self.ndata
+        return to_like(self._AH.matvec(Y), Y)
 
 
 class WeakLensingHarmonic(Measurement):

@@ -229,6 +229,37 @@ def select_copy(flag, src, dst):
     return dst
 
 
+# ---- sparse measurement ----------------------------------------------------------------
+class CsrMatrix:
+    """A scipy.sparse matrix resident on the GPU in CSR form (int64 indptr, int32 indices, f64 / c128 values)."""
+
+    def __init__(self, mat):
+        import scipy.sparse as sp
+
+        m = sp.csr_matrix(mat)
+        m.sum_duplicates()
+        m.sort_indices()
+        self.shape = m.shape
+        self.is_complex = np.iscomplexobj(m.data)
+        dev = device()
+        self.indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(dev)
+        self.indices = torch.from_numpy(m.indices.astype(np.int32)).to(dev)
+        self.vals = torch.from_numpy(np.ascontiguousarray(m.data.astype(np.complex128 if self.is_complex else np.float64))).to(dev)
+        self.nnz = int(m.nnz)
+
+    def matvec(self, X):
+        """[ncols] or [C, ncols] -> [nrows] or [C, nrows] (float64 stays float64 under a real matrix)"""
+        x, squeeze = _batched(as_device(X))
+        if self.is_complex and not x.is_complex():
+            x = x.to(_CPLX)
+        if x.shape[1] != self.shape[1]:
+            raise AssertionError(f"expected length {self.shape[1]}, got {x.shape[1]}")
+        out = torch.empty((x.shape[0], self.shape[0]), dtype=x.dtype, device=x.device)
+        check(lib.pxm_csr_matvec(_p(self.indptr), _p(self.indices), _p(self.vals), int(self.is_complex), self.shape[0],
+                                 self.shape[1], _p(x), _p(out), x.shape[0], _dt(x), _stream()))
+        return out[0] if squeeze else out
+
+
 # ---- transform plans -------------------------------------------------------------------
 class ShtPlan:
     """MW spin spherical-harmonic transforms at bandlimit L (replaces the pyssht calls)."""

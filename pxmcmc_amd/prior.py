@@ -1,12 +1,12 @@
 """
-Prior plugin API of the reference (pxmcmc/prior.py:8-84) on the GPU: L1 norm and its
-soft-thresholding prox, with MW quadrature weighting for wavelets on the sphere.
+Prior plugin API of the reference (pxmcmc/prior.py:8-149) on the GPU: L1 norm and its
+soft-thresholding prox, with MW quadrature weighting (and optional wavelet-power weighting) on the sphere.
 """
 import numpy as np
 import torch
 
 from . import ops
-from .utils import _multires_bandlimits, mw_map_weights, to_like
+from .utils import _multires_bandlimits, mw_map_weights, mw_size, sample_positions, to_like, wavelet_tiling
 
 
 class L1:
@@ -81,3 +81,53 @@ class S2_Wavelets_L1(L1):
             raise NotImplementedError
         self.T = self.T * self.map_weights
         self._weights_dev = ops.as_device(self.map_weights, torch.float64)
+
+
+class S2_Wavelets_L1_Power_Weights(S2_Wavelets_L1):
+    """
+    L1 regulariser for wavelets on S2 with pixel-area, wavelet-power and wavelet-decay weighting
+    (pxmcmc/prior.py:87-149; eqns 33 & 34 of Wallis et al 2017).
+
+    As in the reference the threshold ends up weighted by the quadrature weights AND the power weights
+    (prior.py:81,108), and ``prior`` applies the power weights twice (prior.py:110-111 through :83-84).
+
+    :param float eta: wavelet decay tuning parameter
+    """
+
+    def __init__(self, setting, fwd, adj, T, L, B, J_min, dirs=1, spin=0, eta=1):
+        super().__init__(setting, fwd, adj, T, L, B, J_min, dirs, spin)
+        self.eta = eta
+        if setting == "synthesis":
+            self._get_weights()
+        else:
+            raise NotImplementedError
+        self.T = self.T * self.map_weights
+        self._weights_dev = ops.as_device(self.map_weights * self.map_weights, torch.float64)
+
+    def _get_weights(self):
+        s = self._calculate_scaling_weights().flatten()
+        w = np.concatenate([w.flatten() for w in self._calculate_wavelet_weights()])
+        self.map_weights = np.concatenate([s, w])
+
+    @staticmethod
+    def _grid_weights(effective_L, value):
+        weights = np.full((effective_L, 2 * effective_L - 1), value)
+        thetas, _ = sample_positions(effective_L)
+        return (weights.T * np.sin(thetas)).T
+
+    def _calculate_scaling_weights(self):
+        phi_l, _ = wavelet_tiling(self.B, self.L, self.dirs, self.J_min, self.spin)
+        scaling_power = np.vdot(phi_l, phi_l).real
+        effective_L = int(np.nonzero(phi_l)[0].max()) + 1
+        return self._grid_weights(effective_L, 2 * np.pi ** 2 / (scaling_power * mw_size(effective_L)))
+
+    def _calculate_wavelet_weights(self):
+        bls = _multires_bandlimits(self.L, self.B, self.J_min)
+        _, psi_lm = wavelet_tiling(self.B, self.L, self.dirs, self.J_min, self.spin)
+        wavelet_powers = np.array([np.vdot(lm, lm).real for lm in psi_lm.T])
+        el = np.arange(self.L)
+        peak_ls = np.array([np.argmax(psi[el * el + el]) for psi in psi_lm.T])
+        return [
+            self._grid_weights(int(Le), (2 * np.pi ** 2) * (peak_l ** self.eta) / (power * mw_size(int(Le))))
+            for Le, power, peak_l in zip(bls[1:], wavelet_powers, peak_ls)
+        ]

@@ -60,6 +60,28 @@ def _multires_bandlimits(L, B, J_min, dirs=1, spin=0):
     return np.array([int(np.nonzero(r)[0].max()) + 1 for r in rows], dtype=int)
 
 
+def wavelet_tiling(B, L, N=1, J_min=0, spin=0):
+    """[ext] pys2let.wavelet_tiling (pxmcmc/utils.py:117, prior.py:121,132) for axisymmetric spin-0 wavelets:
+    ``phi_l[L] = sqrt((2l+1)/4pi) kappa0(l)`` and ``psi_lm[L*L, nscales]`` with
+    ``psi_{l0} = sqrt((2l+1)/8pi^2) kappa_j(l)``, one column per scale j = J_min..J_max.  The harmonic
+    normalisation is parity-unpinned; only supports, ``sum |.|^2`` and peak degrees
+    are consumed by the callers."""
+    if N != 1 or spin != 0:
+        raise NotImplementedError("only axisymmetric (N=1), spin-0 wavelets are on the hot path")
+    k0, k = ops.tiling_axisym(L, B, J_min)
+    el = np.arange(L)
+    phi_l = np.sqrt((2 * el + 1) / (4 * np.pi)) * k0
+    psi_lm = np.zeros((L * L, k.shape[0] - J_min), dtype=complex)
+    for col, j in enumerate(range(J_min, k.shape[0])):
+        psi_lm[el * el + el, col] = np.sqrt((2 * el + 1) / (8 * np.pi ** 2)) * k[j]
+    return phi_l, psi_lm
+
+
+def sample_positions(L):
+    """[ext] pyssht.sample_positions for MW sampling: theta_t = pi (2t+1)/(2L-1), phi_p = 2 pi p/(2L-1)."""
+    return np.pi * (2 * np.arange(L) + 1) / (2 * L - 1), 2 * np.pi * np.arange(2 * L - 1) / (2 * L - 1)
+
+
 def mw_weights(m):
     """pxmcmc/utils.py:249-259."""
     if m == 1:

@@ -131,3 +131,50 @@ def test_g8_layouts():
     assert np.array_equal(ref.flatten_mlm(g["wav1d"], g["scal1"]), g["flat1d"])
     w, s = ref.expand_mlm(g["flat1d"], 6)
     assert np.array_equal(w, g["exp_wav"]) and np.array_equal(s, g["exp_scal"])
+
+
+def test_g9_pathintegral():
+    """PathIntegral forward / adjoint (pxmcmc/measurements.py:59-83), real and complex matrix"""
+    import scipy.sparse as sp
+
+    g = golden("g9_pathintegral.npz")
+    shape = tuple(g["A_shape"])
+    A = sp.csr_matrix((g["A_data"], g["A_indices"], g["A_indptr"]), shape=shape)
+    pi = ref.PathIntegral(A)
+    assert (pi.ndata, pi.npix) == tuple(g["ndata_npix"])
+    for x, y, tag in ((g["xr"], g["yr"], "r"), (g["xc"], g["yc"], "c")):
+        np.testing.assert_allclose(pi.forward(x), g[f"fwd_{tag}"], rtol=1e-14, atol=1e-15)
+        np.testing.assert_allclose(pi.adjoint(y), g[f"adj_{tag}"], rtol=1e-14, atol=1e-15)
+    Ac = sp.csr_matrix((g["Ac_data"], g["A_indices"], g["A_indptr"]), shape=shape)
+    pic = ref.PathIntegral(Ac)
+    np.testing.assert_allclose(pic.forward(g["xc"]), g["cfwd_c"], rtol=1e-14, atol=1e-15)
+    np.testing.assert_allclose(pic.adjoint(g["yc"]), g["cadj_c"], rtol=1e-14, atol=1e-15)
+    with np.testing.assert_raises(AssertionError):
+        pi.forward(g["xr"][:5])
+
+
+def test_g10_power_weights():
+    """S2_Wavelets_L1 / S2_Wavelets_L1_Power_Weights weights, thresholds and priors
+    (pxmcmc/prior.py:56-149) for the tiling arrays stored in the fixture."""
+    from oracle import s2let
+
+    g = golden("g10_power_weights.npz")
+    T0 = float(g["T0"])
+    for i, (L, B, J_min, eta) in enumerate(g["cases"]):
+        L, J_min = int(L), int(J_min)
+        tiling = (g[f"phi_l_{i}"], g[f"psi_lm_{i}"])
+        # the oracle's own tiling is the one the fixture was generated with (its normalisation is parity-unpinned)
+        phi_l, psi_lm = s2let.wavelet_tiling(B, L, 1, J_min)
+        np.testing.assert_allclose(phi_l, tiling[0], rtol=1e-14)
+        np.testing.assert_allclose(psi_lm, tiling[1], rtol=1e-14)
+        assert list(s2let.bandlimits_from_support(B, L, J_min)) == list(g[f"bls_{i}"])
+        X = g[f"X_{i}"]
+        s2 = ref.S2_Wavelets_L1("synthesis", None, None, T0, L, B, J_min)
+        np.testing.assert_allclose(s2.map_weights, g[f"s2_map_weights_{i}"], rtol=1e-13, atol=1e-18)
+        np.testing.assert_allclose(s2.T, g[f"s2_T_{i}"], rtol=1e-13, atol=1e-20)
+        np.testing.assert_allclose(s2.prior(X), g[f"s2_prior_{i}"], rtol=1e-13)
+        pw = ref.S2_Wavelets_L1_Power_Weights("synthesis", None, None, T0, L, B, J_min, eta=eta, tiling=tiling)
+        np.testing.assert_allclose(pw.map_weights, g[f"pw_map_weights_{i}"], rtol=1e-13, atol=1e-18)
+        np.testing.assert_allclose(pw.T, g[f"pw_T_{i}"], rtol=1e-12, atol=1e-22)
+        np.testing.assert_allclose(pw.prior(X), g[f"pw_prior_{i}"], rtol=1e-13)
+        np.testing.assert_allclose(pw.proxf(X), g[f"pw_prox_{i}"], rtol=1e-13, atol=1e-18)
