@@ -3,7 +3,8 @@ numpy restatement of the device noise stream (pxmcmc_amd/csrc/philox.h) -- oracl
 infrastructure.  The reference draws from numpy's global MT19937 (pxmcmc/mcmc.py:193-195),
 which a counter-based device generator cannot reproduce; parity runs inject noise, and this
 file pins the device stream itself: Philox4x32-10 (Salmon et al. 2011) keyed by
-(seed, chain), counter (index, iteration), Box-Muller to N(0,1) (float32 transcendentals,
+(seed, chain) [real stream: (seed + tweak, chain >> 1), one deviate of the pair per chain], counter
+(index, iteration), Box-Muller to N(0,1) (float32 transcendentals,
 exact exponent handling so the tail reaches 8.5 sigma).
 """
 import numpy as np
@@ -63,11 +64,16 @@ def normal_pairs(seed, chain, index, it):
     return (rad * np.cos(ang)).astype(np.float64), (rad * np.sin(ang)).astype(np.float64)
 
 
+REAL_TWEAK = 0xD1B54A32D192ED03
+
+
 def randn_real(n, seed, chain, it):
-    """real stream: element e takes draw (e & 1) of pair (e >> 1)."""
+    """real stream: chain ch takes draw (ch & 1) of the pair keyed (seed + tweak, ch >> 1) at counter (e, it)."""
     e = np.arange(n, dtype=np.uint64)
-    z0, z1 = normal_pairs(seed, chain, e >> np.uint64(1), it)
-    return np.where(e & np.uint64(1), z1, z0)
+    with np.errstate(over="ignore"):
+        s = np.uint64(seed) + np.uint64(REAL_TWEAK)
+    z0, z1 = normal_pairs(s, int(chain) >> 1, e, it)
+    return z1 if (int(chain) & 1) else z0
 
 
 def randn_complex(n, seed, chain, it):

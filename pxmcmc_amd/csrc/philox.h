@@ -55,10 +55,17 @@ __device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, u
   return box_muller_fast(u1, u2);
 }
 
-// real stream: element e takes draw (e & 1) of pair (e >> 1); complex stream: element e takes pair e
+// Real stream: chains come in pairs -- chain ch takes draw (ch & 1) of the Philox pair keyed by
+// (seed, ch >> 1) [tweaked key: disjoint from the complex stream] at counter (element, iteration) -- so
+// a kernel that advances chains 2k and 2k+1 together (two real chains per complex slot, update.h) pays
+// one Philox + Box-Muller evaluation per two deviates.  Complex stream: element e of chain ch takes
+// the whole pair keyed (seed, ch).
+__device__ inline NormalPair philox_normal_chainpair(uint64_t seed, uint64_t pair, uint64_t e, uint64_t iter) {
+  return philox_normal_pair(seed + 0xD1B54A32D192ED03ull, pair, e, iter);
+}
 __device__ inline double philox_normal_real(uint64_t seed, uint64_t chain, uint64_t e, uint64_t iter) {
-  NormalPair p = philox_normal_pair(seed, chain, e >> 1, iter);
-  return (e & 1) ? p.z1 : p.z0;
+  const NormalPair p = philox_normal_chainpair(seed, chain >> 1, e, iter);
+  return (chain & 1) ? p.z1 : p.z0;
 }
 
 // one uniform in (0,1) for the PxMALA accept test: counter index 2^63 + 0 keeps it off the noise stream

@@ -105,7 +105,7 @@ inline double gemm_alg_bytes(int L, bool paired, int C, int el_lo = 0) {
   return 8.0 * L * tab_entries + 16.0 * C * (lm_entries + (double)L * (2 * L - 1));
 }
 
-int gemm_rows_per_task();
+int gemm_rows_per_task(int ncol);
 void profile_gemm_begin(hipStream_t st);
 void profile_gemm_end(hipStream_t st, double alg_bytes);
 

@@ -227,27 +227,35 @@ int profile_read(double* ms, int64_t* launches, double* bytes) {
   return 0;
 }
 
-// GEMM workgroup geometry: NW waves x RT row tiles per wave (a task covers NW*RT row tiles).
-// Default 8 x 1: same operand staging traffic as 4 x 2, twice the waves to hide latency, <= 128 VGPR.
-// PXM_GEMM_GEOM=42 selects 4 waves x 2 row tiles.
-int gemm_geom() {
-  static int g = 0;
-  if (!g) {
+// GEMM workgroup geometry: NW waves x RT row tiles per wave (a task covers NW*RT row tiles), chosen per
+// plan from its column count:
+//   81  8 waves x 1 row tile  -- default for >= 32 columns: same operand staging traffic as 4 x 2, twice
+//                                the waves to hide latency, <= 128 VGPR
+//   41  4 waves x 1 row tile  -- default for 16 columns (8 complex slots, e.g. 16 real chains in pairs):
+//                                half-size tasks balance the tail of the launch better (+2 %)
+//   42  4 waves x 2 row tiles -- kept for A/B runs
+// PXM_GEMM_GEOM=81|41|42 forces one.
+int gemm_geom(int ncol) {
+  static int forced = -1;
+  if (forced < 0) {
     const char* e = getenv("PXM_GEMM_GEOM");
-    g = (e && atoi(e) == 42) ? 42 : 81;
+    const int v = e ? atoi(e) : 0;
+    forced = (v == 81 || v == 41 || v == 42) ? v : 0;
   }
-  return g;
+  if (forced) return forced;
+  return ncol <= 16 ? 41 : 81;
 }
-int gemm_rows_per_task() { return 8; }
+int gemm_rows_per_task(int ncol) { return gemm_geom(ncol) == 41 ? 4 : 8; }
 
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double* X, double* Y, int ncol,
                 int col0, int ct, double alg_bytes, hipStream_t stream, const GemmAffine& aff) {
   if (n_tasks == 0) return 0;
-  const int geom = gemm_geom();
-  dim3 grid(n_tasks), block(geom == 81 ? 512 : 256);
+  const int geom = gemm_geom(ncol);
+  dim3 grid(n_tasks), block(geom == 81 ? 512 : 256);  // 41: 4 waves x 1 row tile (tasks of 4 row tiles)
   profile_gemm_begin(stream);
 #define PXM_GEMM_LAUNCH(A, B)                                                                                         \
   if (geom == 81) hipLaunchKernelGGL((k_sht_gemm<A, B, 8, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0, aff); \
+  else if (geom == 41) hipLaunchKernelGGL((k_sht_gemm<A, B, 4, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0, aff); \
   else hipLaunchKernelGGL((k_sht_gemm<A, B, 4, 2>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0, aff);
   if (paired) {
     if (ct == 1) { PXM_GEMM_LAUNCH(1, 2) } else { PXM_GEMM_LAUNCH(2, 2) }
@@ -271,7 +279,7 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
   const bool rows_el = kind_rows_are_el(kind), k_el = kind_k_is_el(kind);
   const int Rp = T.Rp;
   const int lo16 = round_down(std::max(el_lo, 0), 16);
-  const int rpt = gemm_rows_per_task();  // row tiles per task
+  const int rpt = gemm_rows_per_task(ncol);  // row tiles per task
   for (int i = 0; i < T.n_m; ++i) {
     const int m = T.m_of(i);
     const int kb = T.k_beg[kind][i];  // table start of this m along its el dimension(s): multiple of 16

@@ -24,17 +24,24 @@ __device__ __forceinline__ double2 px_noise_load(const PxOut& o, int c, int64_t 
   return double2{o.noise[(int64_t)c * o.chain_stride + e], 0.0};
 }
 
-// Philox noise of (slot c, element e) at iteration it.  One Philox body for every mode (a rolled loop of
-// 1 or 2 trips) so the two-chain mode costs no extra registers in the DFT epilogues.
+// Philox noise of (slot c, element e) at iteration it.  Two real chains per slot whose first chain id is
+// even are exactly one chain pair of the real stream (philox.h): one Philox + Box-Muller evaluation
+// yields both deviates.  Every other case runs a rolled loop of 1 or 2 trips over one Philox body (no
+// extra registers in the DFT epilogues).
 __device__ __forceinline__ double2 px_noise_philox(const PxOut& o, int c, int64_t e, uint64_t it) {
   const bool pairs = o.mode == PXM_MODE_REAL_PAIRS, cplx = o.mode == PXM_MODE_CPLX_NOISE;
+  if (pairs && !(o.chain0 & 1)) {
+    const NormalPair q = philox_normal_chainpair(o.seed, (o.chain0 >> 1) + c, (uint64_t)e, it);
+    return double2{q.z0, q.z1};
+  }
   const int nk = pairs ? 2 : 1;
-  const uint64_t idx = cplx ? (uint64_t)e : ((uint64_t)e >> 1);
   double2 w{0.0, 0.0};
 #pragma nounroll
   for (int k = 0; k < nk; ++k) {
-    const NormalPair q = philox_normal_pair(o.seed, o.chain0 + (pairs ? 2 * c + k : c), idx, it);
-    const double v = (cplx || !(e & 1)) ? q.z0 : q.z1;
+    const uint64_t chain = o.chain0 + (pairs ? 2 * c + k : c);
+    const NormalPair q = cplx ? philox_normal_pair(o.seed, chain, (uint64_t)e, it)
+                              : philox_normal_chainpair(o.seed, chain >> 1, (uint64_t)e, it);
+    const double v = (cplx || !(chain & 1)) ? q.z0 : q.z1;
     if (k == 0) {
       w.x = v;
       w.y = cplx ? q.z1 : 0.0;

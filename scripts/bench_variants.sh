@@ -1,3 +1,3 @@
-for v in "PXM_X=0" "PXM_GEMM_GEOM=42" "PXM_GEMM_PLAIN_ORDER=1" "PXM_NO_SUPPORT_CUT=1"; do
+for v in "PXM_X=0" "PXM_GEMM_GEOM=81"; do
   echo "== $v"; env $v python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],4), round(d['roofline']['avg_launch_us'],1), round(d['roofline']['frac'],3))"
 done
