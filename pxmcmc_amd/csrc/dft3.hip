@@ -11,6 +11,13 @@
 // transposes through LDS need only wave-local ordering (LDS operations of a wave execute in order),
 // no workgroup barrier.
 //   lane-in-ring = 2*c + h,  c = column j2 (steps 1, 1') or row k1 (step 2),  h = which half of the sub-FFT
+//
+// DUAL: when n <= M/4 (the ring lengths whose 2n-1 falls just above a square size: L = 8, 32, 128) one
+// Bluestein convolution carries TWO rings of the same scale, the second one offset by M/2: their
+// filtered outputs [0, n) and [M/2, M/2 + n) do not overlap (2n-2 < M/2), the chirp filter is shared.
+// Ring A enters the column FFTs as rows p < P/2, ring B as rows p + P, i.e. exactly the two inputs of the
+// cross-pair first DIF stage: lane h of a pair owns ring h, and the last DIT stage hands E + t to lane 0
+// (ring A) and E - t to lane 1 (ring B).  The squaring-up then costs nothing.
 #include "elem.h"
 #include "sht_core.h"
 #include "update.h"
@@ -18,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace pxm {
 
@@ -93,6 +101,15 @@ struct Dft3Args {
   const double2* twm;    // [N1][N1] W_M^(k1 j2) (symmetric)
 };
 
+// one scale of a grouped launch (k_ring2px_group)
+struct Dft3Group {
+  Dft3Args a;
+  int64_t g_off;  // this scale's ring array inside the workspace (doubles)
+  int64_t ring0;  // offset of its coefficient block inside a chain (complex elements)
+  int P, dual;
+  int b0, nbx, nby;  // first block of the scale in the grid, its blocks along rings / chain groups
+};
+
 // geometry of the P-variant
 template <int P>
 struct G3 {
@@ -111,12 +128,23 @@ struct G3 {
 // Bluestein convolution core of one ring on its 4P lanes.  In: z[p] = a[p*N1 + c] (p < P; the upper
 // half of the column is Bluestein's zero padding), identical in both lanes of a pair.  Out: z[q] =
 // conv[(q + (P/2) h)*N1 + c], q < P/2.
-template <int P>
+// DUAL: in z[q] (q < P/2) = the lane's OWN ring (ring h of the pair); out z[q] = conv of the own ring at q*N1 + c.
+template <int P, bool DUAL>
 __device__ __forceinline__ void bluestein_w(double2 (&z)[P], double* mat, int c, int h, const Dft3Args& a) {
   constexpr int N1 = G3<P>::N1, PITCH = G3<P>::PITCH, TS = G3<P>::TS, H = G3<P>::H;
-  // ---- step 1: column FFT over j1 (DIF, upper half zero): lane h takes the outputs k1 = 2q + h
+  // ---- step 1: column FFT over j1 (DIF): lane h takes the outputs k1 = 2q + h
+  if (DUAL) {  // rows p (ring A, lane 0) and p + P (ring B, lane 1): a full first stage across the pair
 #pragma unroll
-  for (int p = 1; p < P; ++p) z[p] = sel(h, mulw<-1>(z[p], p * TS), z[p]);
+    for (int q = 0; q < H; ++q) {
+      const double2 o = xchg2(z[q]);
+      z[q] = sel(h, mulw<-1>(csub(o, z[q]), q * TS), cadd(z[q], o));
+    }
+#pragma unroll
+    for (int q = H; q < P; ++q) z[q] = double2{0.0, 0.0};
+  } else {  // upper half of the column is zero padding: both lanes hold the same inputs
+#pragma unroll
+    for (int p = 1; p < P; ++p) z[p] = sel(h, mulw<-1>(z[p], p * TS), z[p]);
+  }
   difp<-1, P>(z);  // z[i] = A[k1 = 2 brp(i) + h][c]
 #pragma unroll
   for (int i = 0; i < P; ++i) z[i] = cmul(z[i], a.twm[(2 * brp<P>(i) + h) * N1 + c]);  // W^(k1 c): symmetric table
@@ -146,11 +174,18 @@ __device__ __forceinline__ void bluestein_w(double2 (&z)[P], double* mat, int c,
   ditp<+1, P>(z);  // E[p] / O[p]
 #pragma unroll
   for (int p = 1; p < P; ++p) z[p] = sel(h, mulw<+1>(z[p], p * TS), z[p]);
-  // wanted outputs j1 = p < P: E[p] + t[p]; lane 0 of the pair produces p < P/2, lane 1 p >= P/2
+  if (DUAL) {  // outputs j1 = q (ring A) = E[q] + t[q] on lane 0, j1 = q + P (ring B) = E[q] - t[q] on lane 1
 #pragma unroll
-  for (int q = 0; q < H; ++q) {
-    const double2 recv = xchg2(sel(h, z[q], z[H + q]));
-    z[q] = cadd(sel(h, z[H + q], z[q]), recv);
+    for (int q = 0; q < H; ++q) {
+      const double2 recv = xchg2(z[q]);
+      z[q] = sel(h, csub(recv, z[q]), cadd(z[q], recv));
+    }
+  } else {  // wanted outputs j1 = p < P: E[p] + t[p]; lane 0 of the pair produces p < P/2, lane 1 p >= P/2
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      const double2 recv = xchg2(sel(h, z[q], z[H + q]));
+      z[q] = cadd(sel(h, z[H + q], z[q]), recv);
+    }
   }
 }
 
@@ -161,33 +196,39 @@ __device__ __forceinline__ void bluestein_w(double2 (&z)[P], double* mat, int c,
   const int unit = threadIdx.x / LPR, lr = threadIdx.x % LPR;                         \
   const int c = lr >> 1, h = lr & 1;                                                  \
   const int tr = unit / R, r = unit - tr * R;                                         \
-  const int t = blockIdx.x * TR + tr, c0 = blockIdx.y * R;                            \
-  const int ch = c0 + r;                                                              \
+  constexpr int NRG = DUAL ? 2 : 1; /* rings per ring slot */                         \
+  const int TRS = TR * NRG;         /* rings per workgroup */                         \
+  const int c0 = by * R, ch = c0 + r;                                                 \
+  const int trs = DUAL ? 2 * tr + h : tr;          /* own ring within the workgroup */ \
+  const int t = bx * TRS + trs;                    /* own ring */                      \
+  const int rowb = DUAL ? 0 : H * h;               /* first output row of the lane */ \
   const bool tv = t < a.L;                                                            \
   const int Cp = ncol >> 1;                                                           \
   double2* stage = lds3;                                                              \
   double* mat = reinterpret_cast<double*>(lds3) + unit * (N1 * PITCH);
 
-// stage[(tr*n + k)*(R+1) + r] -> G rows of every ring of the workgroup (16-B x R segments per m)
+// stage[(ring*n + k)*(R+1) + r] -> G rows of every ring of the workgroup (16-B x R segments per m)
 #define PXM_W_STORE_RINGS                                                                                      \
-  for (int idx = threadIdx.x; idx < TR * n * R; idx += blockDim.x) {                                           \
+  for (int idx = threadIdx.x; idx < TRS * n * R; idx += blockDim.x) {                                          \
     const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);                                            \
-    const int tt = blockIdx.x * TR + trr;                                                                      \
+    const int tt = bx * TRS + trr;                                                                             \
     if (c0 + rr >= Cp || tt >= a.L) continue;                                                                  \
     const int m = (k < a.L) ? k : k - n;                                                                       \
     reinterpret_cast<double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + tt) * Cp + c0 + rr] =                      \
         stage[(trr * n + k) * (R + 1) + rr];                                                                   \
   }
 
-template <int P>
-__global__ __launch_bounds__(256, 2) void k_px2ring_w(Dft3Args a, PxIn in, double* __restrict__ G, int ncol, int C) {
-  extern __shared__ double2 lds3[];
+template <int P, bool DUAL>
+__device__ __forceinline__ void px2ring_body(const Dft3Args& a, const PxIn& in, double* __restrict__ G, int ncol, int C,
+                                             int bx, int by, double2* lds3) {
   PXM_W_GEOMETRY
   (void)LPR;
-  if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
+  constexpr int NIN = DUAL ? H : P;  // input rows a lane loads (DUAL: its own ring only)
   double2 z[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
+  for (int p = 0; p < P; ++p) z[p] = double2{0.0, 0.0};
+#pragma unroll
+  for (int p = 0; p < NIN; ++p) {
     const int j = p * N1 + c;
     double2 v{0.0, 0.0};
     if (j < n && ch < C && tv) {
@@ -205,34 +246,41 @@ __global__ __launch_bounds__(256, 2) void k_px2ring_w(Dft3Args a, PxIn in, doubl
     }
     z[p] = v;
   }
-  bluestein_w<P>(z, mat, c, h, a);
+  bluestein_w<P, DUAL>(z, mat, c, h, a);
   __syncthreads();  // the planes are dead; reuse LDS as the [j][chain] layout-transpose stage
 #pragma unroll
   for (int q = 0; q < H; ++q) {
-    const int j = (q + H * h) * N1 + c;
-    if (j < n) stage[(tr * n + j) * (R + 1) + r] = cmul(z[q], a.chirp[j]);
+    const int j = (q + rowb) * N1 + c;
+    if (j < n) stage[(trs * n + j) * (R + 1) + r] = cmul(z[q], a.chirp[j]);
   }
   __syncthreads();
   PXM_W_STORE_RINGS
 }
 
+template <int P, bool DUAL>
+__global__ __launch_bounds__(256, 2) void k_px2ring_w(Dft3Args a, PxIn in, double* __restrict__ G, int ncol, int C) {
+  extern __shared__ double2 lds3[];
+  if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
+  px2ring_body<P, DUAL>(a, in, G, ncol, C, blockIdx.x, blockIdx.y, lds3);
+}
+
 // RING_OUT: after the (fused MYULA) epilogue the updated ring is transformed again and its rings are
 // written back IN PLACE over G -- rings of S X -> X' and rings of X' in one kernel (ring-space step).
-template <int P, bool RING_OUT>
-__global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __restrict__ G, int ncol, PxOut out, int C) {
-  extern __shared__ double2 lds3[];
+template <int P, bool DUAL, bool RING_OUT>
+__device__ __forceinline__ void ring2px_body(const Dft3Args& a, double* __restrict__ G, int ncol, const PxOut& out, int C,
+                                             int bx, int by, double2* lds3) {
   PXM_W_GEOMETRY
   (void)LPR;
   {
     constexpr int NB = 8;  // batches of independent loads: the memory latency is paid once per batch
-    const int total = TR * n * R;
+    const int total = TRS * n * R;
     for (int base = threadIdx.x; base < total; base += NB * blockDim.x) {
       double2 v[NB];
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
         const int idx = base + u * blockDim.x;
         const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);
-        const int tt = blockIdx.x * TR + trr;
+        const int tt = bx * TRS + trr;
         v[u] = double2{0.0, 0.0};
         if (idx < total && c0 + rr < Cp && tt < a.L) {
           const int m = (k < a.L) ? k : k - n;
@@ -252,17 +300,20 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __rest
     }
   }
   __syncthreads();
+  constexpr int NIN = DUAL ? H : P;  // input rows a lane holds (DUAL: its own ring only)
   double2 z[P];
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
+  for (int p = 0; p < P; ++p) z[p] = double2{0.0, 0.0};
+#pragma unroll
+  for (int p = 0; p < NIN; ++p) {
     const int j = p * N1 + c;
-    z[p] = (j < n) ? stage[(tr * n + j) * (R + 1) + r] : double2{0.0, 0.0};
+    if (j < n) z[p] = stage[(trs * n + j) * (R + 1) + r];
   }
   __syncthreads();
-  bluestein_w<P>(z, mat, c, h, a);
+  bluestein_w<P, DUAL>(z, mat, c, h, a);
   const bool act = ch < C && tv;
   if (!RING_OUT && !act) return;
-  const int64_t e0 = out.ring0 + (int64_t)t * n + (H * h) * N1 + c;  // element of q = 0; q advances by N1
+  const int64_t e0 = out.ring0 + (int64_t)t * n + rowb * N1 + c;  // element of q = 0; q advances by N1
   const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
   double2 zn[H];  // the ring as written to out.f (RING_OUT: input of the forward transform)
 #pragma unroll
@@ -277,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __rest
 #pragma unroll
       for (int u = 0; u < EB; ++u) {
         const int q = g0 + u;
-        const bool ok = (q + H * h) * N1 + c < n;
+        const bool ok = (q + rowb) * N1 + c < n;
         const int64_t off = (int64_t)q * N1;
         xs[u] = ok ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
         Ts[u] = (ok && out.T) ? out.T[e0 + off] : out.T_scalar;
@@ -286,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __rest
 #pragma unroll
       for (int u = 0; u < EB; ++u) {
         const int q = g0 + u;
-        const int p = (q + H * h) * N1 + c;
+        const int p = (q + rowb) * N1 + c;
         if (p >= n) continue;
         const int64_t off = (int64_t)q * N1;
         double2 y = cmul(z[q], a.chirp[p]);
@@ -300,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __rest
   } else if (act) {
 #pragma unroll
     for (int q = 0; q < H; ++q) {
-      const int p = (q + H * h) * N1 + c;
+      const int p = (q + rowb) * N1 + c;
       if (p >= n) continue;
       double2 y = cmul(z[q], a.chirp[p]);
       y.y = -y.y;
@@ -309,27 +360,70 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __rest
     }
   }
   if (!RING_OUT) return;
-  // ---- forward transform of the updated ring: the column needs all P entries in both lanes of a pair
+  // ---- forward transform of the updated ring
+  if (DUAL) {  // the lane keeps its own ring; the pair exchange happens inside the transform's first stage
 #pragma unroll
-  for (int q = 0; q < H; ++q) {
-    const double2 other = xchg2(zn[q]);
-    z[q] = sel(h, other, zn[q]);       // p = q        (owned by the h = 0 lane)
-    z[H + q] = sel(h, zn[q], other);   // p = P/2 + q  (owned by the h = 1 lane)
+    for (int q = 0; q < H; ++q) z[q] = zn[q];
+#pragma unroll
+    for (int q = H; q < P; ++q) z[q] = double2{0.0, 0.0};
+  } else {  // the column needs all P entries in both lanes of a pair
+#pragma unroll
+    for (int q = 0; q < H; ++q) {
+      const double2 other = xchg2(zn[q]);
+      z[q] = sel(h, other, zn[q]);       // p = q        (owned by the h = 0 lane)
+      z[H + q] = sel(h, zn[q], other);   // p = P/2 + q  (owned by the h = 1 lane)
+    }
   }
 #pragma unroll
-  for (int p = 0; p < P; ++p) {
+  for (int p = 0; p < NIN; ++p) {
     const int j = p * N1 + c;
     z[p] = (j < n) ? cmul(z[p], a.chirp[j]) : double2{0.0, 0.0};
   }
-  bluestein_w<P>(z, mat, c, h, a);
+  bluestein_w<P, DUAL>(z, mat, c, h, a);
   __syncthreads();  // the planes are dead; reuse LDS as the [j][chain] layout-transpose stage
 #pragma unroll
   for (int q = 0; q < H; ++q) {
-    const int j = (q + H * h) * N1 + c;
-    if (j < n) stage[(tr * n + j) * (R + 1) + r] = cmul(z[q], a.chirp[j]);
+    const int j = (q + rowb) * N1 + c;
+    if (j < n) stage[(trs * n + j) * (R + 1) + r] = cmul(z[q], a.chirp[j]);
   }
   __syncthreads();
   PXM_W_STORE_RINGS
+}
+
+template <int P, bool DUAL, bool RING_OUT>
+__global__ __launch_bounds__(256, 2) void k_ring2px_w(Dft3Args a, double* __restrict__ G, int ncol, PxOut out, int C) {
+  extern __shared__ double2 lds3[];
+  ring2px_body<P, DUAL, RING_OUT>(a, G, ncol, out, C, blockIdx.x, blockIdx.y, lds3);
+}
+
+// Grouped launch of the ring-space step: the rings -> X' -> rings kernels of EVERY scale of a wavelet plan in
+// one grid.  A full-size scale alone fills every wave slot of the chip (2 waves per SIMD by registers), so
+// separate launches of the small scales on side streams only ran in its tail; here the small scales'
+// workgroups come first in the grid and the large scales' fill in behind them.
+__global__ __launch_bounds__(256, 2) void k_ring2px_group(const Dft3Group* __restrict__ ents, int nent, double* __restrict__ ws,
+                                                          int ncol, PxOut out, int C) {
+  extern __shared__ double2 lds3[];
+  int e = 0;
+  while (e + 1 < nent && (int)blockIdx.x >= ents[e + 1].b0) ++e;
+  const Dft3Group g = ents[e];
+  const int local = blockIdx.x - g.b0;
+  const int bx = local % g.nbx, by = local / g.nbx;
+  out.ring0 = g.ring0;
+  double* G = ws + g.g_off;
+  const Dft3Args a = g.a;
+#define PXM_GROUP_CASE(PP, DD) \
+  case 2 * PP + DD: ring2px_body<PP, DD != 0, true>(a, G, ncol, out, C, bx, by, lds3); break;
+  switch (2 * g.P + g.dual) {
+    PXM_GROUP_CASE(16, 0)
+    PXM_GROUP_CASE(16, 1)
+    PXM_GROUP_CASE(8, 0)
+    PXM_GROUP_CASE(8, 1)
+    PXM_GROUP_CASE(4, 0)
+    PXM_GROUP_CASE(4, 1)
+    PXM_GROUP_CASE(2, 0)
+    default: ring2px_body<2, true, true>(a, G, ncol, out, C, bx, by, lds3); break;
+  }
+#undef PXM_GROUP_CASE
 }
 
 // ---- host side -----------------------------------------------------------------------------
@@ -341,25 +435,28 @@ int dft3_size(int n) {
 }
 static int dft3_P(int M) { return M == 1024 ? 16 : M == 256 ? 8 : M == 64 ? 4 : 2; }
 
+bool dft3_dual(int M, int n) { return 4 * n <= M && !getenv("PXM_DFT_NO_DUAL"); }
+
 void dft3_geometry(int M, int n, int R_want, int* R, int* TR, size_t* lds) {
   const int P = dft3_P(M), N1 = 2 * P, units = 256 / (4 * P);
   int r = std::min(units, 8);
   if (R_want > 0 && R_want <= r && units % R_want == 0) r = R_want;
   *R = r;
   *TR = units / r;
-  const size_t planes = (size_t)units * N1 * (N1 + 1) * 8, stage = (size_t)(*TR) * n * (r + 1) * 16;
+  const int rings = (*TR) * (dft3_dual(M, n) ? 2 : 1);
+  const size_t planes = (size_t)units * N1 * (N1 + 1) * 8, stage = (size_t)rings * n * (r + 1) * 16;
   *lds = std::max(planes, stage);
 }
 
-template <int P>
+template <int P, bool DUAL>
 static int dft3_attr() {
   static bool done = false;
   if (!done) {
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring_w<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<P, false>),
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring_w<P, DUAL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<P, true>),
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<P, DUAL, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_w<P, DUAL, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
@@ -371,47 +468,107 @@ static Dft3Args dft3_args(const DftPlan& p) {
                   reinterpret_cast<const double2*>(p.d_bhatn3), reinterpret_cast<const double2*>(p.d_twm3)};
 }
 
-template <int P>
+template <int P, bool DUAL>
 static int px2ring_p(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
-  if (int rc = dft3_attr<P>()) return rc;
-  const int Cp = ncol / 2;
-  dim3 grid((p.L + p.TR3 - 1) / p.TR3, (Cp + p.R3 - 1) / p.R3), block(256);
-  hipLaunchKernelGGL((k_px2ring_w<P>), grid, block, p.lds3, st, dft3_args(p), in, G, ncol, C);
+  if (int rc = dft3_attr<P, DUAL>()) return rc;
+  const int Cp = ncol / 2, rings = p.TR3 * (DUAL ? 2 : 1);
+  dim3 grid((p.L + rings - 1) / rings, (Cp + p.R3 - 1) / p.R3), block(256);
+  hipLaunchKernelGGL((k_px2ring_w<P, DUAL>), grid, block, p.lds3, st, dft3_args(p), in, G, ncol, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
-template <int P>
+template <int P, bool DUAL>
 static int ring2px_p(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
-  if (int rc = dft3_attr<P>()) return rc;
-  dim3 grid((p.L + p.TR3 - 1) / p.TR3, (C + p.R3 - 1) / p.R3), block(256);
+  if (int rc = dft3_attr<P, DUAL>()) return rc;
+  const int rings = p.TR3 * (DUAL ? 2 : 1);
+  dim3 grid((p.L + rings - 1) / rings, (C + p.R3 - 1) / p.R3), block(256);
   if (ring_out) {
     // every chain group must run: padded chains get zero rings written back
     grid.y = (ncol / 2 + p.R3 - 1) / p.R3;
-    hipLaunchKernelGGL((k_ring2px_w<P, true>), grid, block, p.lds3, st, dft3_args(p), const_cast<double*>(G), ncol, out, C);
+    hipLaunchKernelGGL((k_ring2px_w<P, DUAL, true>), grid, block, p.lds3, st, dft3_args(p), const_cast<double*>(G), ncol, out, C);
   } else {
-    hipLaunchKernelGGL((k_ring2px_w<P, false>), grid, block, p.lds3, st, dft3_args(p), const_cast<double*>(G), ncol, out, C);
+    hipLaunchKernelGGL((k_ring2px_w<P, DUAL, false>), grid, block, p.lds3, st, dft3_args(p), const_cast<double*>(G), ncol, out, C);
   }
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
-int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
-  switch (dft3_P(p.M3)) {
-    case 16: return px2ring_p<16>(p, in, G, ncol, C, st);
-    case 8: return px2ring_p<8>(p, in, G, ncol, C, st);
-    case 4: return px2ring_p<4>(p, in, G, ncol, C, st);
-    default: return px2ring_p<2>(p, in, G, ncol, C, st);
+// ---- grouped launch (wavelet plan: every scale in one grid) ------------------------------------
+int dft3_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
+                      const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out) {
+  // small scales first (descending size among them), then the full-size scales
+  std::vector<int> order;
+  int Lmax = 0;
+  for (const DftPlan* d : plans) Lmax = std::max(Lmax, d->L);
+  const bool top_first = getenv("PXM_DFT_TOP_FIRST") != nullptr;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int s = (int)plans.size() - 1; s >= 0; --s)
+      if ((plans[s]->L == Lmax) == (top_first ? pass == 0 : pass == 1)) order.push_back(s);
+  std::vector<Dft3Group> v;
+  int b0 = 0;
+  size_t lds = 0;
+  for (int s : order) {
+    const DftPlan& p = *plans[s];
+    if (!p.use3) return 1;
+    Dft3Group g;
+    g.a = dft3_args(p);
+    g.g_off = g_off[s];
+    g.ring0 = ring0[s];
+    g.P = dft3_P(p.M3);
+    g.dual = dft3_dual(p.M3, p.n) ? 1 : 0;
+    const int rings = p.TR3 * (g.dual ? 2 : 1);
+    g.nbx = (p.L + rings - 1) / rings;
+    g.nby = (ncol / 2 + p.R3 - 1) / p.R3;
+    g.b0 = b0;
+    b0 += g.nbx * g.nby;
+    lds = std::max(lds, p.lds3);
+    v.push_back(g);
   }
+  out->n = (int)v.size();
+  out->blocks = b0;
+  out->lds = lds;
+  PXM_HIP(hipMalloc(&out->d, v.size() * sizeof(Dft3Group)));
+  PXM_HIP(hipMemcpy(out->d, v.data(), v.size() * sizeof(Dft3Group), hipMemcpyHostToDevice));
+  static bool attr = false;
+  if (!attr) {
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr = true;
+  }
+  return 0;
+}
+
+void dft3_group_destroy(Dft3GroupList* g) {
+  if (g->d) (void)hipFree(g->d);
+  g->d = nullptr;
+  g->n = 0;
+}
+
+int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_ring2px_group, dim3(g.blocks), dim3(256), g.lds, st, reinterpret_cast<const Dft3Group*>(g.d), g.n, ws,
+                     ncol, out, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+#define PXM_W_DISPATCH(FN, ...)                                                   \
+  {                                                                               \
+    const bool dual = dft3_dual(p.M3, p.n);                                       \
+    switch (dft3_P(p.M3)) {                                                       \
+      case 16: return dual ? FN<16, true>(__VA_ARGS__) : FN<16, false>(__VA_ARGS__); \
+      case 8: return dual ? FN<8, true>(__VA_ARGS__) : FN<8, false>(__VA_ARGS__);   \
+      case 4: return dual ? FN<4, true>(__VA_ARGS__) : FN<4, false>(__VA_ARGS__);   \
+      default: return dual ? FN<2, true>(__VA_ARGS__) : FN<2, false>(__VA_ARGS__);  \
+    }                                                                             \
+  }
+
+int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
+  PXM_W_DISPATCH(px2ring_p, p, in, G, ncol, C, st)
 }
 
 int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
-  switch (dft3_P(p.M3)) {
-    case 16: return ring2px_p<16>(p, G, ncol, out, C, st, ring_out);
-    case 8: return ring2px_p<8>(p, G, ncol, out, C, st, ring_out);
-    case 4: return ring2px_p<4>(p, G, ncol, out, C, st, ring_out);
-    default: return ring2px_p<2>(p, G, ncol, out, C, st, ring_out);
-  }
+  PXM_W_DISPATCH(ring2px_p, p, G, ncol, out, C, st, ring_out)
 }
 
 }  // namespace pxm

@@ -281,6 +281,7 @@ struct pxm_wav_plan_s {
   hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
   int nside = 2;
   std::vector<int> lane_of;  // per scale: -1 = caller's stream, else side stream index
+  Dft3GroupList dft_group;   // every scale's rings -> X' -> rings kernel in one grid (ring-space step)
 };
 
 extern "C" {
@@ -456,12 +457,19 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
     for (int s = p->nsc - 1; s >= 0; --s)
       if (p->bl[s] < L) p->lane_of[s] = (k++) % p->nside;
   }
+  if (!getenv("PXM_NO_DFT_GROUP")) {
+    std::vector<const DftPlan*> dp;
+    for (int s = 0; s < p->nsc; ++s) dp.push_back(&p->dft[s]);
+    rc = dft3_group_create(dp, p->offG, p->coef_off, p->ncol, &p->dft_group);
+    if (rc < 0) return rc;  // rc == 1: some scale has no wave path -> per-scale launches
+  }
   *plan = p;
   return 0;
 }
 
 int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   if (!p) return 0;
+  dft3_group_destroy(&p->dft_group);
   for (auto& d : p->dft) free_dft_plan(&d);
   free_dft_plan(&p->dftL);
   if (p->ws) (void)hipFree(p->ws);
@@ -569,16 +577,26 @@ static bool wav_can_fuse_dft(pxm_wav_plan_t p) {
 }
 
 static int wav_rings_update_rings(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
+  if (p->dft_group.d) {  // one grid for every scale, small scales first
+    proto.chain_stride = p->ncoefs;
+    return dft3_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st);
+  }
   bool used[pxm_wav_plan_s::NSIDE];
   int rc = wav_fork(p, st, used);
   if (rc) return rc;
-  for (int s = p->nsc - 1; s >= 0; --s) {
-    PxOut out = proto;
-    out.chain_stride = p->ncoefs;
-    out.ring0 = p->coef_off[s];
-    rc = launch_ring2px2ring(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, wav_stream(p, s, st));
-    if (rc) return rc < 0 ? rc : -1;
-  }
+  // side-stream (small) scales are enqueued first: the full-size kernels fill every wave slot of the chip
+  // (2 waves per SIMD by registers), so whatever is enqueued behind them only runs in their tail
+  const bool small_first = !getenv("PXM_DFT_TOP_FIRST");
+  for (int pass = 0; pass < 2; ++pass)
+    for (int s = p->nsc - 1; s >= 0; --s) {
+      const bool side = p->lane_of[s] >= 0;
+      if (side != (small_first ? pass == 0 : pass == 1)) continue;
+      PxOut out = proto;
+      out.chain_stride = p->ncoefs;
+      out.ring0 = p->coef_off[s];
+      rc = launch_ring2px2ring(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, wav_stream(p, s, st));
+      if (rc) return rc < 0 ? rc : -1;
+    }
   return wav_join(p, st, used);
 }
 

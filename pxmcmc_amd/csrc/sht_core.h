@@ -161,6 +161,16 @@ int dft2_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm)
 void dft2_geometry(int M, int n, int R, int* threads, size_t* lds);
 int dft2_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft2_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
+// grouped launch of every scale's rings -> X' -> rings kernel (dft3.hip)
+struct Dft3GroupList {
+  void* d = nullptr;  // device array of per-scale descriptors
+  int n = 0, blocks = 0;
+  size_t lds = 0;
+};
+int dft3_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
+                      const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available
+void dft3_group_destroy(Dft3GroupList* g);
+int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st);
 int dft3_size(int n);  // square Bluestein size of the wave path for ring length n, 0 = none
 void dft3_geometry(int M, int n, int R_want, int* R, int* TR, size_t* lds);
 int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
