@@ -106,8 +106,6 @@ inline double gemm_alg_bytes(int L, bool paired, int C, int el_lo = 0) {
 }
 
 int gemm_rows_per_task(int ncol);
-void profile_gemm_begin(hipStream_t st);
-void profile_gemm_end(hipStream_t st, double alg_bytes);
 
 // ---- DFT stage ---------------------------------------------------------------
 struct DftPlan {

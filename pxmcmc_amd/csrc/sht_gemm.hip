@@ -9,6 +9,8 @@
 #include "../../include/pxmcmc_amd.h"
 #include "sht_core.h"
 
+#include <hip/hip_ext.h>
+
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -188,13 +190,13 @@ static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 static size_t g_prof_used = 0;
 static double g_prof_bytes = 0;
 
-void profile_gemm_begin(hipStream_t st) {
+// next event pair of the pool (or nulls when profiling is off): passed to hipExtLaunchKernelGGL, which
+// stamps them with the kernel's own start / end (what rocprofv3's kernel trace reports)
+static void profile_gemm_events(hipEvent_t* start, hipEvent_t* stop, double alg_bytes) {
+  *start = *stop = nullptr;
   if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return;
-  (void)hipEventRecord(g_prof_pool[g_prof_used].first, st);
-}
-void profile_gemm_end(hipStream_t st, double alg_bytes) {
-  if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return;
-  (void)hipEventRecord(g_prof_pool[g_prof_used].second, st);
+  *start = g_prof_pool[g_prof_used].first;
+  *stop = g_prof_pool[g_prof_used].second;
   g_prof_bytes += alg_bytes;
   ++g_prof_used;
 }
@@ -227,23 +229,23 @@ int profile_read(double* ms, int64_t* launches, double* bytes) {
   return 0;
 }
 
-// GEMM workgroup geometry: NW waves x RT row tiles per wave (a task covers NW*RT row tiles), chosen per
-// plan from its column count:
-//   81  8 waves x 1 row tile  -- default for >= 32 columns: same operand staging traffic as 4 x 2, twice
-//                                the waves to hide latency, <= 128 VGPR
-//   41  4 waves x 1 row tile  -- default for 16 columns (8 complex slots, e.g. 16 real chains in pairs):
-//                                half-size tasks balance the tail of the launch better (+2 %)
+// GEMM workgroup geometry: NW waves x RT row tiles per wave (a task covers NW*RT row tiles):
+//   81  8 waves x 1 row tile  -- default: same operand staging traffic as 4 x 2, twice the waves to hide
+//                                latency, <= 128 VGPR
+//   41  4 waves x 1 row tile  -- half-size tasks: 2 % faster at 16 columns (better tail balance) but the
+//                                operand is staged twice as often (PMC: 1.14x the algorithmic bytes instead
+//                                of 0.90x), so it is not the default
 //   42  4 waves x 2 row tiles -- kept for A/B runs
-// PXM_GEMM_GEOM=81|41|42 forces one.
+// PXM_GEMM_GEOM=81|41|42 selects one.
 int gemm_geom(int ncol) {
+  (void)ncol;
   static int forced = -1;
   if (forced < 0) {
     const char* e = getenv("PXM_GEMM_GEOM");
     const int v = e ? atoi(e) : 0;
     forced = (v == 81 || v == 41 || v == 42) ? v : 0;
   }
-  if (forced) return forced;
-  return ncol <= 16 ? 41 : 81;
+  return forced ? forced : 81;
 }
 int gemm_rows_per_task(int ncol) { return gemm_geom(ncol) == 41 ? 4 : 8; }
 
@@ -252,18 +254,18 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double*
   if (n_tasks == 0) return 0;
   const int geom = gemm_geom(ncol);
   dim3 grid(n_tasks), block(geom == 81 ? 512 : 256);  // 41: 4 waves x 1 row tile (tasks of 4 row tiles)
-  profile_gemm_begin(stream);
+  hipEvent_t ev0, ev1;
+  profile_gemm_events(&ev0, &ev1, alg_bytes);
 #define PXM_GEMM_LAUNCH(A, B)                                                                                         \
-  if (geom == 81) hipLaunchKernelGGL((k_sht_gemm<A, B, 8, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0, aff); \
-  else if (geom == 41) hipLaunchKernelGGL((k_sht_gemm<A, B, 4, 1>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0, aff); \
-  else hipLaunchKernelGGL((k_sht_gemm<A, B, 4, 2>), grid, block, 0, stream, d_tasks, X, Y, ncol, col0, aff);
+  if (geom == 81) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 8, 1>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
+  else if (geom == 41) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 1>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
+  else hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
   if (paired) {
     if (ct == 1) { PXM_GEMM_LAUNCH(1, 2) } else { PXM_GEMM_LAUNCH(2, 2) }
   } else {
     if (ct == 1) { PXM_GEMM_LAUNCH(1, 1) } else { PXM_GEMM_LAUNCH(2, 1) }
   }
 #undef PXM_GEMM_LAUNCH
-  profile_gemm_end(stream, alg_bytes);
   PXM_HIP(hipGetLastError());
   return 0;
 }

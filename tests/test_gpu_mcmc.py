@@ -374,3 +374,49 @@ def test_real_pairs_equal_complex_slots(C, sig):
         assert s._pairs is pairs
         outs.append(s.chain)
     assert np.abs(outs[0] - outs[1]).max() < 1e-12 * scale
+
+
+def test_full_size_step_properties_L256():
+    """BASELINE.json configs[2] at full size (L=256, B=2, J_min=2, 16 chains).  Size-independent checks of the
+    benchmarked iteration: (i) the real-pair / Gram / ring-space engine equals the general image-space step
+    (pxm_wav_gradg_step + pxm_wav_synthesis, one complex slot per chain) after several iterations; (ii) the
+    step is the reference formula: X' - (1-d/l) X - (d/l) soft(X,T) + d S^H(w (S X - data)) = sqrt(2d) noise,
+    with the noise recovered that way distributed N(0,1) and different in every chain."""
+    import torch
+
+    from pxmcmc_amd import ops
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min, C = 256, 2.0, 2, 16
+    rng = np.random.default_rng(2)
+    P = L * (2 * L - 1)
+    data = rng.normal(size=P)
+    lmda, delta, sig = 1e-6, 5e-7, 0.05
+    op = SphericalWaveletTransformOperator(data, sig, "synthesis", L, B, J_min, max_chains=C)
+    reg = S2_Wavelets_L1("synthesis", None, None, lmda, L=L, B=B, J_min=J_min)
+    p = PxMCMCParams(lmda=lmda, delta=delta, nsamples=1, nburn=5, ngap=1, verbosity=0, track=["chain"])
+    fast = MYULA(op, reg, p, nchains=C, seed=3)
+    _quiet(fast.run, start_point=np.zeros(op.nparams))
+    assert fast._eng["pairs"] and fast._eng["ring"] and fast.niter == 6
+    slow = MYULA(op, reg, p, nchains=C, seed=3, real_pairs=False, ring_shortcut=False, use_graph=False)
+    _quiet(slow.run, start_point=np.zeros(op.nparams))
+    assert not slow._eng["pairs"] and not slow._eng["ring"]
+    a, b = fast.X_curr, slow.X_curr
+    assert float((a - b).abs().max()) < 1e-10 * float(b.abs().max())
+    # one more step from the common state, checked against the formula with the unfused operators
+    X = b.clone()
+    preds = ops.as_device(op.forward(X))
+    s2 = MYULA(op, reg, p, nchains=C, seed=3)
+    s2._prepare()
+    Xn = s2._advance(X, preds, 17)  # Philox iteration 17
+    gradg = ops.as_device(op.calc_gradg(preds))
+    det = (1 - delta / lmda) * X + (delta / lmda) * ops.soft(X, reg.T_dev) - delta * gradg
+    w = ((Xn - det) / np.sqrt(2 * delta)).real.cpu().numpy()
+    assert abs(w.mean()) < 5e-3 and abs(w.std() - 1) < 5e-3
+    assert np.abs(((Xn - det).imag).cpu().numpy()).max() < 1e-9 * np.sqrt(2 * delta)
+    assert np.abs(w[0] - w[1]).max() > 1 and abs(np.corrcoef(w[0], w[1])[0, 1]) < 0.02
+    # ... and that noise is the documented Philox stream of each chain
+    ref = ops.randn(op.nparams, C, seed=3, chain0=0, it=17).cpu().numpy()
+    assert np.abs(w - ref).max() < 1e-6
