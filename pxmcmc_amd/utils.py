@@ -119,3 +119,30 @@ def s2_integrate(f, L):
 def mw_size(L):
     """[ext] pys2let.mw_size (pxmcmc/forward.py:1,109)."""
     return L * (2 * L - 1)
+
+
+# J2000 north galactic pole and the ICRS -> Galactic rotation astropy applies (its Galactic frame is defined
+# through FK5 J2000; the ICRS / FK5 frame bias of ~20 mas is far below any pixel of a mask)
+_NGP_RA, _NGP_DEC = np.radians(192.8594812065348), np.radians(27.12825118085622)
+
+
+def galactic_latitude(lon_deg, lat_deg):
+    """galactic latitude b (degrees) of ICRS (lon, lat) in degrees"""
+    ra, dec = np.radians(lon_deg), np.radians(lat_deg)
+    sinb = np.sin(dec) * np.sin(_NGP_DEC) + np.cos(dec) * np.cos(_NGP_DEC) * np.cos(ra - _NGP_RA)
+    return np.degrees(np.arcsin(np.clip(sinb, -1.0, 1.0)))
+
+
+def build_mask(L, size=20):
+    """
+    Mask for the galactic plane and the equatorial band, MW format, 0 at masked positions
+    (pxmcmc/utils.py:320-349).  The reference builds the coordinates as lon = phi - 180, lat = theta - 90 degrees
+    (:337-339) and masks |galactic latitude| < size through astropy; the same rotation is applied here directly
+    (parity unpinned against astropy, which is absent from this image).
+    """
+    thetas, phis = sample_positions(L)
+    mask = np.ones((L, 2 * L - 1))
+    mask[np.abs(90 - np.degrees(thetas)) < size, :] = 0
+    thetaarray, phiarray = np.meshgrid(np.degrees(thetas) - 90, np.degrees(phis) - 180, indexing="ij")
+    mask[np.abs(galactic_latitude(phiarray, thetaarray)) < size] = 0
+    return mask

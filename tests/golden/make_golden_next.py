@@ -1,6 +1,6 @@
 """
-Golden fixtures G9-G10 for the SURVEY.md section 8f rows (PathIntegral measurement, power-weighted S2
-prior), captured by importing the REFERENCE's own classes from /root/reference -- same procedure and
+Golden fixtures G9-G11 for the SURVEY.md section 8f rows (PathIntegral measurement, power-weighted S2
+prior, uncertainty summaries), captured by importing the REFERENCE's own classes from /root/reference -- same procedure and
 same stub modules as make_golden.py (build container only; only the *.npz data files are committed).
 
 G9  pxmcmc.measurements.PathIntegral forward / adjoint on random sparse path matrices (real and complex).
@@ -78,9 +78,28 @@ def main():
         g10[f"s2_map_weights_{i}"], g10[f"s2_T_{i}"], g10[f"s2_prior_{i}"] = s2.map_weights, s2.T, s2.prior(X)
         g10[f"pw_map_weights_{i}"], g10[f"pw_T_{i}"], g10[f"pw_prior_{i}"] = pw.map_weights, pw.T, pw.prior(X)
         g10[f"pw_prox_{i}"] = pw.proxf(X)
+    # ---- G11: uncertainty summaries (pxmcmc/uncertainty.py), tiling of case 0 ----------------
+    import pxmcmc.uncertainty as uncertainty
+
+    L, B, J_min = 10, 2.0, 2
+    t0 = (g10["phi_l_0"], g10["psi_lm_0"])
+    sys.modules["pys2let"].wavelet_tiling = lambda B_, L_, N_, J_, s_, _t=t0: _t
+    uncertainty.pyssht = sys.modules["pyssht"]
+    g11 = {}
+    chain = rng.normal(size=(60, int(g10["s2_map_weights_0"].size))) * rng.random(int(g10["s2_map_weights_0"].size))
+    g11["chain"] = chain
+    g11["ci"] = uncertainty.credible_interval_range(chain, 0.05)
+    g11["ci10"] = uncertainty.credible_interval_range(chain, 0.1)
+    for i, w in enumerate(uncertainty.wavelet_credible_interval_range(chain, L, B, J_min, 0.05)):
+        g11[f"wav_ci_{i}"] = w
+    logpis = rng.normal(size=200)
+    g11["logpis"] = logpis
+    g11["thr"] = np.array(uncertainty.credible_region_threshold(logpis, 0.05))
+    np.savez_compressed(os.path.join(HERE, "g11_uncertainty.npz"), **g11)
+
     g10["T0"] = np.array(3e-4)
     np.savez_compressed(os.path.join(HERE, "g10_power_weights.npz"), **g10)
-    print("wrote g9_pathintegral.npz, g10_power_weights.npz")
+    print("wrote g9_pathintegral.npz, g10_power_weights.npz, g11_uncertainty.npz")
 
 
 if __name__ == "__main__":
