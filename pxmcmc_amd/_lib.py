@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpxmcmc_amd.so")
+LIB_PATH = os.environ.get("PXM_LIB_PATH") or os.path.join(_HERE, "lib", "libpxmcmc_amd.so")  # override: A/B builds
 
 c_i64, c_u64, c_int, c_dbl, c_vp = C.c_int64, C.c_uint64, C.c_int, C.c_double, C.c_void_p
 

@@ -32,6 +32,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // * one barrier per 16-k chunk (32 MFMAs per wave between barriers).
 // ---------------------------------------------------------------------------------------
 constexpr int KC = 16;  // contraction rows per staged chunk
+#ifndef PXM_GEMM_NSET
+#define PXM_GEMM_NSET 3  // table register sets: the table stream runs NSET-1 chunks (of 16 k) ahead
+#endif
 
 // NW waves per workgroup, RT row tiles of 16 rows per wave: a task covers NW*RT row tiles.
 template <int CT, int NSLAB, int NW, int RT>
@@ -100,9 +103,10 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   for (int r = 0; r < RT; ++r)
     tab[r] = reinterpret_cast<const double2*>(X + t.tab_off + (int64_t)(n_my > r ? RT * wave + r : 0) * t.rt_stride) + lane;
   const bool v0 = n_my > 0;
-  // three register sets used round-robin with compile-time indices (no register rotation: a copy
-  // of an in-flight load would force a full vmcnt(0) drain every chunk)
-  double2 A[3][RT][2];
+  // NSET register sets used round-robin with compile-time indices (no register rotation: a copy of an
+  // in-flight load would force a full vmcnt(0) drain every chunk); the table runs NSET-1 chunks ahead
+  constexpr int NSET = PXM_GEMM_NSET;
+  double2 A[NSET][RT][2];
 #define PXM_TAB_LOAD(SET, CH)                                                 \
   {                                                                           \
     const int cc = min((CH), nch - 1);                                        \
@@ -119,17 +123,17 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     for (int c = 0; c < NCT; ++c) acc[r][c] = d4{0, 0, 0, 0};
 
   PXM_STAGE_LOAD(0)
-  PXM_TAB_LOAD(0, 0)
-  PXM_TAB_LOAD(1, 1)
-  for (int ch0 = 0; ch0 < nch; ch0 += 3) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+  for (int u = 0; u < NSET - 1; ++u) PXM_TAB_LOAD(u, u)
+  for (int ch0 = 0; ch0 < nch; ch0 += NSET) {
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
       const int ch = ch0 + u;
       if (ch < nch) {
         const int buf = ch & 1;
         PXM_STAGE_STORE(ch, buf)
         if (ch + 1 < nch) { PXM_STAGE_LOAD(ch + 1) }
-        PXM_TAB_LOAD((u + 2) % 3, ch + 2)
+        PXM_TAB_LOAD((u + NSET - 1) % NSET, ch + NSET - 1)
         __syncthreads();
         if (v0) {
 #pragma unroll
