@@ -187,6 +187,23 @@ int make_dft_plan(int L, DftPlan* p) {
     dft3_geometry(M3, b.n, e3 ? atoi(e3) : 0, &p->R3, &p->TR3, &p->lds3);
     p->use3 = true;
   }
+  if (!M3 && b.M == 2048 && !getenv("PXM_DFT_NO_W") && !getenv("PXM_DFT_NO_W2")) {  // two waves per ring
+    std::vector<double> bn(2 * (size_t)b.M);
+    for (int i = 0; i < b.M; ++i) {  // b.bhat is in bit-reversed order
+      int r = 0;
+      for (int bit = 0; bit < b.logM; ++bit) r |= ((i >> bit) & 1) << (b.logM - 1 - bit);
+      bn[2 * (size_t)r] = b.bhat[2 * (size_t)i];
+      bn[2 * (size_t)r + 1] = b.bhat[2 * (size_t)i + 1];
+    }
+    PXM_HIP(hipMalloc(&p->d_bhatn4, bn.size() * sizeof(double)));
+    PXM_HIP(hipMemcpy(p->d_bhatn4, bn.data(), bn.size() * sizeof(double), hipMemcpyHostToDevice));
+    BluesteinTables b1k = make_bluestein(2, 1024);  // only its size matters: the 32 x 32 W_1024 twiddle matrix
+    double* unused = nullptr;
+    int rc = dft2_make_tables(b1k, &unused, &p->d_twm4);
+    if (rc) return rc;
+    (void)hipFree(unused);
+    p->use4 = true;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -206,6 +223,9 @@ void free_dft_plan(DftPlan* p) {
   if (p->d_twm) (void)hipFree(p->d_twm);
   if (p->d_bhatn3) (void)hipFree(p->d_bhatn3);
   if (p->d_twm3) (void)hipFree(p->d_twm3);
+  if (p->d_bhatn4) (void)hipFree(p->d_bhatn4);
+  if (p->d_twm4) (void)hipFree(p->d_twm4);
+  p->d_bhatn4 = p->d_twm4 = nullptr;
   p->d_chirp = p->d_bhat = p->d_tw = p->d_bhatn = p->d_twm = p->d_bhatn3 = p->d_twm3 = nullptr;
 }
 
@@ -225,6 +245,7 @@ static DftArgs make_args(const DftPlan& p) {
 
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream) {
   if (p.use3) return dft3_px2ring(p, in, G, ncol, C, stream);
+  if (p.use4) return dft4_px2ring(p, in, G, ncol, C, stream);
   if (p.use2) return dft2_px2ring(p, in, G, ncol, C, stream);
   const int Cp = ncol / 2;
   dim3 grid(p.L, (Cp + p.R - 1) / p.R), block(p.threads);
@@ -241,6 +262,7 @@ int launch_ring2px2ring(const DftPlan& p, double* G, int ncol, const PxOut& out,
 
 int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
   if (p.use3) return dft3_ring2px(p, G, ncol, out, C, stream);
+  if (p.use4) return dft4_ring2px(p, G, ncol, out, C, stream);
   if (p.use2) return dft2_ring2px(p, G, ncol, out, C, stream);
   dim3 grid(p.L, (C + p.R - 1) / p.R), block(p.threads);
   hipLaunchKernelGGL(k_ring2px, grid, block, p.lds, stream, make_args(p), G, ncol, out, C);

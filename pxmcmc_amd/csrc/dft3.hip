@@ -129,18 +129,23 @@ struct G3 {
 // half of the column is Bluestein's zero padding), identical in both lanes of a pair.  Out: z[q] =
 // conv[(q + (P/2) h)*N1 + c], q < P/2.
 // DUAL: in z[q] (q < P/2) = the lane's OWN ring (ring h of the pair); out z[q] = conv of the own ring at q*N1 + c.
-template <int P, bool DUAL>
-__device__ __forceinline__ void bluestein_w(double2 (&z)[P], double* mat, int c, int h, const Dft3Args& a) {
+// FULL (two-wave path, k_*4 below): a complete M-point transform pair with no pruning: in z[p] = a[(p + P h)*N1 + c],
+// out z[p] = the filtered sequence at the same index; the filter spectrum is read at stride BS, offset BO.
+enum { BW_HALF = 0, BW_DUAL = 1, BW_FULL = 2 };
+template <int P, int MODE, int BS = 1>
+__device__ __forceinline__ void bluestein_w(double2 (&z)[P], double* mat, int c, int h, const Dft3Args& a, int BO = 0) {
   constexpr int N1 = G3<P>::N1, PITCH = G3<P>::PITCH, TS = G3<P>::TS, H = G3<P>::H;
+  constexpr bool DUAL = MODE == BW_DUAL;
+  constexpr int NQ = MODE == BW_FULL ? P : H;  // rows a lane owns when both halves of the column are live
   // ---- step 1: column FFT over j1 (DIF): lane h takes the outputs k1 = 2q + h
-  if (DUAL) {  // rows p (ring A, lane 0) and p + P (ring B, lane 1): a full first stage across the pair
+  if (MODE != BW_HALF) {  // rows p (lane 0) and p + P (lane 1): a full first stage across the pair
 #pragma unroll
-    for (int q = 0; q < H; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const double2 o = xchg2(z[q]);
       z[q] = sel(h, mulw<-1>(csub(o, z[q]), q * TS), cadd(z[q], o));
     }
 #pragma unroll
-    for (int q = H; q < P; ++q) z[q] = double2{0.0, 0.0};
+    for (int q = NQ; q < P; ++q) z[q] = double2{0.0, 0.0};
   } else {  // upper half of the column is zero padding: both lanes hold the same inputs
 #pragma unroll
     for (int p = 1; p < P; ++p) z[p] = sel(h, mulw<-1>(z[p], p * TS), z[p]);
@@ -159,7 +164,7 @@ __device__ __forceinline__ void bluestein_w(double2 (&z)[P], double* mat, int c,
   }
   difp<-1, P>(y);  // y[i] = X[c + N1 k2], k2 = 2 brp(i) + h
 #pragma unroll
-  for (int i = 0; i < P; ++i) y[i] = cmul(y[i], a.bhatn[c + N1 * (2 * brp<P>(i) + h)]);
+  for (int i = 0; i < P; ++i) y[i] = cmul(y[i], a.bhatn[(c + N1 * (2 * brp<P>(i) + h)) * BS + BO]);
   ditp<+1, P>(y);  // inverse over k2: E[p] (h = 0) / O[p] (h = 1)
 #pragma unroll
   for (int p = 0; p < P; ++p) {
@@ -174,9 +179,10 @@ __device__ __forceinline__ void bluestein_w(double2 (&z)[P], double* mat, int c,
   ditp<+1, P>(z);  // E[p] / O[p]
 #pragma unroll
   for (int p = 1; p < P; ++p) z[p] = sel(h, mulw<+1>(z[p], p * TS), z[p]);
-  if (DUAL) {  // outputs j1 = q (ring A) = E[q] + t[q] on lane 0, j1 = q + P (ring B) = E[q] - t[q] on lane 1
+  (void)DUAL;
+  if (MODE != BW_HALF) {  // outputs j1 = q = E[q] + t[q] on lane 0, j1 = q + P = E[q] - t[q] on lane 1
 #pragma unroll
-    for (int q = 0; q < H; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const double2 recv = xchg2(z[q]);
       z[q] = sel(h, csub(recv, z[q]), cadd(z[q], recv));
     }
@@ -246,7 +252,7 @@ __device__ __forceinline__ void px2ring_body(const Dft3Args& a, const PxIn& in, 
     }
     z[p] = v;
   }
-  bluestein_w<P, DUAL>(z, mat, c, h, a);
+  bluestein_w<P, DUAL ? BW_DUAL : BW_HALF>(z, mat, c, h, a);
   __syncthreads();  // the planes are dead; reuse LDS as the [j][chain] layout-transpose stage
 #pragma unroll
   for (int q = 0; q < H; ++q) {
@@ -310,7 +316,7 @@ __device__ __forceinline__ void ring2px_body(const Dft3Args& a, double* __restri
     if (j < n) z[p] = stage[(trs * n + j) * (R + 1) + r];
   }
   __syncthreads();
-  bluestein_w<P, DUAL>(z, mat, c, h, a);
+  bluestein_w<P, DUAL ? BW_DUAL : BW_HALF>(z, mat, c, h, a);
   const bool act = ch < C && tv;
   if (!RING_OUT && !act) return;
   const int64_t e0 = out.ring0 + (int64_t)t * n + rowb * N1 + c;  // element of q = 0; q advances by N1
@@ -379,7 +385,7 @@ __device__ __forceinline__ void ring2px_body(const Dft3Args& a, double* __restri
     const int j = p * N1 + c;
     z[p] = (j < n) ? cmul(z[p], a.chirp[j]) : double2{0.0, 0.0};
   }
-  bluestein_w<P, DUAL>(z, mat, c, h, a);
+  bluestein_w<P, DUAL ? BW_DUAL : BW_HALF>(z, mat, c, h, a);
   __syncthreads();  // the planes are dead; reuse LDS as the [j][chain] layout-transpose stage
 #pragma unroll
   for (int q = 0; q < H; ++q) {
@@ -424,6 +430,151 @@ __global__ __launch_bounds__(256, 2) void k_ring2px_group(const Dft3Group* __res
     default: ring2px_body<2, true, true>(a, G, ncol, out, C, bx, by, lds3); break;
   }
 #undef PXM_GROUP_CASE
+}
+
+// =============================================================================================
+// Two waves per ring: M = 2048 = 2 x 1024 for 256 < L <= 512 (n = 2L-1 <= 1023).
+// Radix-2 split of the Bluestein FFT across the two waves of a ring: the input is zero above n <= 1024, so
+// wave w takes the bins k = 2k' + w as the 1024-point transform of a[j] W_2048^(w j); after the filter the
+// two unnormalised inverse transforms recombine as conv[j] = y_0[j] + W_2048^(-j) y_1[j], j < 1024, through
+// LDS.  Each wave runs the complete (unpruned) 32 x 32 lane-pair transform pair above (BW_FULL).
+// Workgroup = 2 chains of one ring x 2 waves.
+// =============================================================================================
+struct Dft4Args {
+  Dft3Args a;          // chirp [n]; bhatn = FFT_2048(filter)/2048 in natural order; twm = 32 x 32 W_1024 table
+  const double2* tw2;  // W_2048^j = exp(-2 pi i j / 2048), j < 1024
+};
+constexpr int W4_PITCH = 3;  // stage pitch (2 chains + 1)
+
+#define PXM_W4_GEOMETRY                                                  \
+  const Dft3Args& a = a4.a;                                              \
+  const int n = a.n;                                                     \
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;            \
+  const int u = wave >> 1, w = wave & 1; /* chain of the group, bin parity */ \
+  const int c = lane >> 1, h = lane & 1;                                 \
+  const int t = blockIdx.x, c0 = blockIdx.y * 2, ch = c0 + u;            \
+  const int Cp = ncol >> 1;                                              \
+  double2* stage = lds4;                       /* [n][3]: ring <-> chain transpose */ \
+  double2* comb = lds4 + u * 1024;             /* [2][1024]: wave 1 -> wave 0 (aliases the stage) */ \
+  double* mat = reinterpret_cast<double*>(lds4) + wave * (32 * 33);
+
+// conv[j] for the lane's 16 rows: wave 1 hands W^(-j) y_1[j] to wave 0 through LDS (two barriers)
+#define PXM_W4_COMBINE                                                                   \
+  __syncthreads(); /* every plane / stage read is done */                                \
+  if (w) {                                                                               \
+    _Pragma("unroll") for (int p = 0; p < 16; ++p) {                                     \
+      const int j = (p + 16 * h) * 32 + c;                                               \
+      comb[j] = cmulc(z[p], a4.tw2[j]);                                                  \
+    }                                                                                    \
+  }                                                                                      \
+  __syncthreads();                                                                       \
+  if (!w) {                                                                              \
+    _Pragma("unroll") for (int p = 0; p < 16; ++p) z[p] = cadd(z[p], comb[(p + 16 * h) * 32 + c]); \
+  }                                                                                      \
+  __syncthreads(); /* comb is dead: the stage may be written */
+
+__global__ __launch_bounds__(256, 2) void k_px2ring4(Dft4Args a4, PxIn in, double* __restrict__ G, int ncol, int C) {
+  extern __shared__ double2 lds4[];
+  PXM_W4_GEOMETRY
+  if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
+  double2 z[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int j = (p + 16 * h) * 32 + c;
+    double2 v{0.0, 0.0};
+    if (j < n && ch < C) {
+      const int64_t e = in.ring0 + (int64_t)t * n + j;
+      v = reinterpret_cast<const double2*>(in.f)[(int64_t)ch * in.chain_stride + e];
+      if (in.data) {  // residual invcov .* (preds - data)   (pxmcmc/forward.py:66-69)
+        v = csub(v, reinterpret_cast<const double2*>(in.data)[e]);
+        if (in.invcov_complex) v = cmul(reinterpret_cast<const double2*>(in.invcov)[e], v);
+        else {
+          const double wt = in.invcov[e];
+          v = double2{wt * v.x, wt * v.y};
+        }
+      }
+      v = cmul(v, a.chirp[j]);
+      if (w) v = cmul(v, a4.tw2[j]);
+    }
+    z[p] = v;
+  }
+  bluestein_w<16, BW_FULL, 2>(z, mat, c, h, a, w);
+  PXM_W4_COMBINE
+  if (!w) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int j = (p + 16 * h) * 32 + c;
+      if (j < n) stage[j * W4_PITCH + u] = cmul(z[p], a.chirp[j]);
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < n * 2; idx += blockDim.x) {
+    const int k = idx >> 1, rr = idx & 1;
+    if (c0 + rr >= Cp) continue;
+    const int m = (k < a.L) ? k : k - n;
+    reinterpret_cast<double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + t) * Cp + c0 + rr] = stage[k * W4_PITCH + rr];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_ring2px4(Dft4Args a4, const double* __restrict__ G, int ncol, PxOut out, int C) {
+  extern __shared__ double2 lds4[];
+  PXM_W4_GEOMETRY
+  for (int idx = threadIdx.x; idx < n * 2; idx += blockDim.x) {
+    const int k = idx >> 1, rr = idx & 1;
+    double2 v{0.0, 0.0};
+    if (c0 + rr < Cp) {
+      const int m = (k < a.L) ? k : k - n;
+      v = reinterpret_cast<const double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + t) * Cp + c0 + rr];
+      v.y = -v.y;  // inverse DFT by conjugation: y = conj(DFT(conj x))
+      v = cmul(v, a.chirp[k]);
+    }
+    stage[k * W4_PITCH + rr] = v;
+  }
+  __syncthreads();
+  double2 z[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const int j = (p + 16 * h) * 32 + c;
+    double2 v = (j < n) ? stage[j * W4_PITCH + u] : double2{0.0, 0.0};
+    if (w && j < n) v = cmul(v, a4.tw2[j]);
+    z[p] = v;
+  }
+  __syncthreads();
+  bluestein_w<16, BW_FULL, 2>(z, mat, c, h, a, w);
+  PXM_W4_COMBINE
+  if (w || ch >= C) return;
+  const int64_t e0 = out.ring0 + (int64_t)t * n + (16 * h) * 32 + c;  // element of p = 0; p advances by 32
+  const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
+  const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
+#pragma unroll
+  for (int g0 = 0; g0 < 16; g0 += 4) {
+    double2 xs[4], wn[4];
+    double Ts[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = g0 + q;
+      const bool ok = (p + 16 * h) * 32 + c < n;
+      const int64_t off = (int64_t)p * 32;
+      xs[q] = (ok && out.X) ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
+      Ts[q] = (ok && out.X && out.T) ? out.T[e0 + off] : out.T_scalar;
+      wn[q] = (ok && out.X && out.noise) ? px_noise_load(out, ch, e0 + off) : double2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = g0 + q;
+      const int j = (p + 16 * h) * 32 + c;
+      if (j >= n) continue;
+      const int64_t off = (int64_t)p * 32;
+      double2 y = cmul(z[p], a.chirp[j]);
+      y.y = -y.y;
+      if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+        double2 wv = wn[q];
+        if (!out.noise) wv = px_noise_philox(out, ch, e0 + off, it_eff);
+        y = px_update(out, xs[q], Ts[q], y, wv);
+      }
+      reinterpret_cast<double2*>(out.f)[ce0 + off] = y;
+    }
+  }
 }
 
 // ---- host side -----------------------------------------------------------------------------
@@ -562,6 +713,39 @@ int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut&
       default: return dual ? FN<2, true>(__VA_ARGS__) : FN<2, false>(__VA_ARGS__);  \
     }                                                                             \
   }
+
+// ---- two-wave path (M = 2048) ---------------------------------------------------------------------
+static Dft4Args dft4_args(const DftPlan& p) {
+  Dft4Args a4;
+  a4.a = Dft3Args{p.L, p.n, p.Rp, 2, 1, reinterpret_cast<const double2*>(p.d_chirp),
+                  reinterpret_cast<const double2*>(p.d_bhatn4), reinterpret_cast<const double2*>(p.d_twm4)};
+  a4.tw2 = reinterpret_cast<const double2*>(p.d_tw);
+  return a4;
+}
+static size_t dft4_lds(int n) { return std::max((size_t)n * W4_PITCH * 16, (size_t)std::max(4 * 32 * 33 * 8, 2 * 1024 * 16)); }
+static int dft4_attr() {
+  static bool done = false;
+  if (!done) {
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  return 0;
+}
+int dft4_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
+  if (int rc = dft4_attr()) return rc;
+  dim3 grid(p.L, (ncol / 2 + 1) / 2), block(256);
+  hipLaunchKernelGGL(k_px2ring4, grid, block, dft4_lds(p.n), st, dft4_args(p), in, G, ncol, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+int dft4_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st) {
+  if (int rc = dft4_attr()) return rc;
+  dim3 grid(p.L, (C + 1) / 2), block(256);
+  hipLaunchKernelGGL(k_ring2px4, grid, block, dft4_lds(p.n), st, dft4_args(p), G, ncol, out, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
 
 int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
   PXM_W_DISPATCH(px2ring_p, p, in, G, ncol, C, st)

@@ -124,6 +124,9 @@ struct DftPlan {
   int M3 = 0, R3 = 0, TR3 = 0;  // R3 chains x TR3 rings per workgroup
   size_t lds3 = 0;
   double *d_bhatn3 = nullptr, *d_twm3 = nullptr;
+  // two-wave path (dft3.hip, k_*4): M = 2048 for 256 < L <= 512
+  bool use4 = false;
+  double *d_bhatn4 = nullptr, *d_twm4 = nullptr;  // FFT_2048(filter)/2048 natural order; 32 x 32 W_1024 table
 };
 
 int make_dft_plan(int L, DftPlan* p);
@@ -169,6 +172,8 @@ int dft3_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
                       const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available
 void dft3_group_destroy(Dft3GroupList* g);
 int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st);
+int dft4_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
+int dft4_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
 int dft3_size(int n);  // square Bluestein size of the wave path for ring length n, 0 = none
 void dft3_geometry(int M, int n, int R_want, int* R, int* TR, size_t* lds);
 int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);

@@ -109,3 +109,43 @@ def test_full_size_properties_L256():
     # linearity across the chain batch: chain c of a batch == the same chain run alone
     one = wav.synthesis(X[3])
     assert (one - wav.synthesis(X)[3]).abs().max() == 0
+
+
+def test_two_wave_dft_path_L_above_256(monkeypatch):
+    """256 < L <= 512: the phi-DFT runs as two waves per ring (M = 2048 = 2 x 1024).  Same results as the radix-2
+    in-LDS fallback kernel, exact round trip, adjoint dot tests, and the fused residual / MYULA epilogues."""
+    import torch
+
+    from pxmcmc_amd import ops
+
+    L, C = 260, 3
+    g = torch.Generator(device="cpu").manual_seed(1)
+    flm = torch.randn(C, L * L, dtype=torch.complex128, generator=g)
+    x = torch.randn(C, L * (2 * L - 1), dtype=torch.complex128, generator=g)
+    fast = ops.ShtPlan(L, 0, max_chains=C)
+    monkeypatch.setenv("PXM_DFT_NO_W2", "1")
+    slow = ops.ShtPlan(L, 0, max_chains=C)
+    monkeypatch.delenv("PXM_DFT_NO_W2")
+    for name, arg in (("inverse", flm), ("forward_adjoint", flm), ("forward", x), ("inverse_adjoint", x)):
+        a, b = getattr(fast, name)(arg), getattr(slow, name)(arg)
+        assert float((a - b).abs().max()) < 1e-11 * float(b.abs().max()), name
+    f = fast.inverse(flm)
+    assert float((fast.forward(f).cpu() - flm).abs().max()) < 1e-10 * float(flm.abs().max())
+    for fwd, adj, a, b in ((fast.inverse, fast.inverse_adjoint, flm, x), (fast.forward, fast.forward_adjoint, x, flm)):
+        lhs = torch.sum(torch.conj(b.cuda()) * fwd(a), dim=1)
+        rhs = torch.sum(torch.conj(adj(b)) * a.cuda(), dim=1)
+        assert float(((lhs - rhs).abs() / lhs.abs()).max()) < 1e-10
+    # a wavelet plan at L = 260 exercises the fused epilogues of the two-wave kernels (residual on input,
+    # prox + update on output) against the unfused kernels
+    wav = ops.WavPlan(L, 2.0, 2, max_chains=2)
+    X = torch.randn(2, wav.ncoefs, dtype=torch.complex128, generator=g).cuda() * 0.1
+    preds = wav.synthesis(X)
+    data = torch.randn(wav.npix, dtype=torch.complex128, generator=g).cuda()
+    invcov = torch.rand(wav.npix, dtype=torch.float64, generator=g).cuda() + 0.5
+    T = torch.rand(wav.ncoefs, dtype=torch.float64, generator=g).cuda() * 0.05
+    noise = torch.randn(2, wav.ncoefs, dtype=torch.float64, generator=g).cuda()
+    delta, lmda = 1e-3, 2e-3
+    got = wav.gradg_step(X, preds, data, invcov, T, delta, lmda, noise=noise)
+    gradg = wav.synthesis_adjoint(ops.residual_grad(preds, data, invcov))
+    want = ops.myula_step(X, gradg, T, delta, lmda, noise=noise)
+    assert float((got - want).abs().max()) < 1e-11 * float(want.abs().max())
