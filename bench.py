@@ -138,8 +138,8 @@ def main():
         eng["one"](eng["XA"], eng["XB"])
         eng["one"](eng["XB"], eng["XA"])
     torch.cuda.synchronize()
-    ms, nl, nb = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    lib.pxm_profile_read(ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(nb))
+    ms, nl, nb, nf = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+    lib.pxm_profile_read(ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(nb), ctypes.byref(nf))
     lib.pxm_profile_enable(0)
     X, preds = sampler._engine_state()
     assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
@@ -190,6 +190,10 @@ def main():
                 "avg_launch_us": gemm_avg_us,
                 "launches": int(nl.value),
                 "alg_bytes_per_launch": nb.value / max(nl.value, 1),
+                # the same launches against the matrix pipe (v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s dense spec,
+                # 47 TFLOP/s sustained by an MFMA-only loop on this part): the kernel is co-limited
+                "mfma_tflops": nf.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
+                "mfma_frac_of_spec": nf.value / (ms.value * 1e-3) / 78.6e12 if ms.value > 0 else 0.0,
             },
         }
         if not args.no_cpu_baseline:

@@ -41,10 +41,11 @@ int pxm_device_count(void);
 
 /* ---- live kernel timing (bench.py roofline leg) --------------------------------
  * When enabled, every launch of the SHT ring-GEMM kernel is bracketed by HIP events on the
- * stream it is launched on.  pxm_profile_read synchronises those events and returns the summed
- * kernel time (ms), the number of launches and the algorithmic bytes they moved, then resets. */
+ * stream it is launched on (kernel start / stop, as rocprofv3 reports them).  pxm_profile_read synchronises
+ * those events and returns the summed kernel time (ms), the number of launches, the algorithmic bytes they
+ * moved and the MFMA flops they executed (any pointer may be NULL), then resets. */
 int pxm_profile_enable(int on);
-int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes);
+int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes, double* gemm_flops);
 
 /* ---- device-resident iteration counter (HIP-graph replay of the MYULA step) -----------------
  * When a counter is registered, every Philox-consuming kernel uses iteration = iter + *counter, read

@@ -14,8 +14,11 @@ struct TaskList {
   GemmTask* d = nullptr;
   int n = 0;
   bool paired = false;
+  int nslab = 2;         // kernel variant: 1 unpaired, 2 +-m pairs, 4 the list holds merged (two-transform) tasks
   std::vector<int> bls;  // bandlimits of the transforms grouped in this launch (roofline accounting)
   std::vector<int> los;  // their support cuts el_lo (0 = none)
+  int merged = -1;       // index i: transforms i and i+1 share one pass over their table (counted once)
+  double mfma_units = 0; // sum over tasks of row tiles x k-steps x slabs: MFMAs per column tile
   bool gram = false;     // Gram launch: table sum_m (L-m)^2 entries, harmonic side read and written
 };
 
@@ -61,6 +64,11 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
   }
   out->n = (int)v.size();
   out->paired = paired;
+  out->nslab = paired ? 2 : 1;
+  for (const GemmTask& t : v) {
+    if (t.nslab == 4) out->nslab = 4;
+    out->mfma_units += (double)t.n_rt * ((t.k_end - t.k_beg) / 4) * t.nslab;
+  }
   if (v.empty()) return 0;
   PXM_HIP(hipMalloc(&out->d, v.size() * sizeof(GemmTask)));
   PXM_HIP(hipMemcpy(out->d, v.data(), v.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
@@ -79,7 +87,9 @@ static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, i
       if (tl.gram) bytes += 8.0 * Ld * (Ld + 1) * (2 * Ld + 1) / 6 + 2 * 16.0 * cg * Ld * Ld;
       else bytes += gemm_alg_bytes(tl.bls[i], tl.paired, cg, tl.los[i]);
     }
-    int rc = launch_gemm(tl.d, tl.n, tl.paired, X, Y, ncol, col0, ct, bytes, st, aff);
+    if (tl.merged >= 0)  // two transforms, one pass over the table: the smaller of the two row ranges is not re-read
+      bytes -= gemm_table_bytes(tl.bls[tl.merged], tl.paired, std::max(tl.los[tl.merged], tl.los[tl.merged + 1]));
+    int rc = launch_gemm(tl.d, tl.n, tl.nslab, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, aff);
     if (rc) return rc;
   }
   return 0;
@@ -368,38 +378,56 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
     }
   // task lists
   std::vector<GemmTask> v_syn_fwd, v_adj_fwdadj, v_ana_inv, v_anadj_invadj, v;
-  for (int s = 0; s < p->nsc; ++s) {
+  // The two finest scales usually share the bandlimit L (bl = min(ceil(B^(j+1)), L)) and therefore the table:
+  // their GEMMs are emitted as MERGED tasks -- one pass over the table, four column slabs.
+  const int top = p->nsc - 1;
+  const bool merge = p->fused_combine && p->nsc >= 2 && p->bl[top] == p->bl[top - 1] && p->T[top] == p->T[top - 1] &&
+                     getenv("PXM_GEMM_MERGE");  // measured time-neutral (the launch is MFMA-issue-bound): off by default
+  auto cls_of = [&](int s) { return (s == 0) ? 1 : ((s - 1) & 1); };
+  // the four per-scale stages as GemmSide descriptors
+  auto side = [&](int s, int which) {
     const int b = p->bl[s], Rb = round_up(b, 16);
-    // synthesis: G_s --A_s--> H_s
-    // class of the scale: the scaling function only overlaps the first wavelet scale, so it joins the
-    // other parity class; within a class the kernels' l-supports are disjoint
-    const int cls = (s == 0) ? 1 : ((s - 1) & 1);
-    GemmFuse fz;
-    fz.row_lo = el_lo[s];
-    fz.row_hi = b;
-    if (p->fused_combine) {
-      // synthesis: G_s --A_s--> c_s kappa_s(l) * (...) written straight into the class buffer in L layout
-      fz.rscale = p->d_kc_syn + (size_t)s * p->Rp;
-      append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, cls ? p->offHB : p->offHA, L, p->Rp, nullptr, p->offS,
-                        p->ws, v_syn_fwd, el_lo[s], fz);
-    } else {
-      append_gemm_tasks(*p->T[s], TAB_FWD, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS, p->ws, v_syn_fwd,
-                        el_lo[s]);
+    GemmSide g;
+    g.el_lo = el_lo[s];
+    g.fuse = GemmFuse();
+    g.kscale = nullptr;
+    const int64_t hcls = cls_of(s) ? p->offHB : p->offHA;
+    switch (which) {
+      case 0:  // synthesis: G_s --A_s--> c_s kappa_s(l) * (...) written straight into the class buffer in L layout
+        g.x_base = p->offG[s]; g.x_L = b; g.x_Rp = Rb;
+        g.fuse.row_lo = el_lo[s]; g.fuse.row_hi = b;
+        if (p->fused_combine) { g.y_base = hcls; g.y_L = L; g.y_Rp = p->Rp; g.fuse.rscale = p->d_kc_syn + (size_t)s * p->Rp; }
+        else { g.y_base = p->offH[s]; g.y_L = b; g.y_Rp = Rb; g.fuse = GemmFuse(); }
+        break;
+      case 1:  // synthesis adjoint: H_L (scaled by c_s kappa_s per el) --A_s^T--> G_s
+        g.x_base = p->offHL; g.x_L = L; g.x_Rp = p->Rp; g.y_base = p->offG[s]; g.y_L = b; g.y_Rp = Rb;
+        g.kscale = p->d_kc_syn + (size_t)s * p->Rp;
+        break;
+      case 2:  // analysis: H_L (scaled by c_a kappa_s) --B_s--> G_s
+        g.x_base = p->offHL; g.x_L = L; g.x_Rp = p->Rp; g.y_base = p->offG[s]; g.y_L = b; g.y_Rp = Rb;
+        g.kscale = p->d_kc_ana + (size_t)s * p->Rp;
+        break;
+      default:  // analysis adjoint: G_s --B_s^T--> class buffer (or H_s)
+        g.x_base = p->offG[s]; g.x_L = b; g.x_Rp = Rb;
+        g.fuse.row_lo = el_lo[s]; g.fuse.row_hi = b;
+        if (p->fused_combine) { g.y_base = hcls; g.y_L = L; g.y_Rp = p->Rp; g.fuse.rscale = p->d_kc_ana + (size_t)s * p->Rp; }
+        else { g.y_base = p->offH[s]; g.y_L = b; g.y_Rp = Rb; g.fuse = GemmFuse(); }
+        break;
     }
-    // synthesis adjoint: H_L (scaled by c_s kappa_s per el) --A_s^T--> G_s
-    append_gemm_tasks(*p->T[s], TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
-                      p->d_kc_syn + (size_t)s * p->Rp, p->offS, p->ws, v_adj_fwdadj, el_lo[s]);
-    // analysis: H_L (scaled by c_a kappa_s) --B_s--> G_s
-    append_gemm_tasks(*p->T[s], TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offG[s], b, Rb,
-                      p->d_kc_ana + (size_t)s * p->Rp, p->offS, p->ws, v_ana_inv, el_lo[s]);
-    // analysis adjoint: G_s --B_s^T--> H_s
-    if (p->fused_combine) {
-      fz.rscale = p->d_kc_ana + (size_t)s * p->Rp;
-      append_gemm_tasks(*p->T[s], TAB_INV_ADJ, p->ncol, p->offG[s], b, Rb, cls ? p->offHB : p->offHA, L, p->Rp, nullptr,
-                        p->offS, p->ws, v_anadj_invadj, el_lo[s], fz);
-    } else {
-      append_gemm_tasks(*p->T[s], TAB_INV_ADJ, p->ncol, p->offG[s], b, Rb, p->offH[s], b, Rb, nullptr, p->offS,
-                        p->ws, v_anadj_invadj, el_lo[s]);
+    return g;
+  };
+  const int kinds[4] = {TAB_FWD, TAB_FWD_ADJ, TAB_INV, TAB_INV_ADJ};
+  std::vector<GemmTask>* lists[4] = {&v_syn_fwd, &v_adj_fwdadj, &v_ana_inv, &v_anadj_invadj};
+  for (int s = 0; s < p->nsc; ++s) {
+    for (int w = 0; w < 4; ++w) {
+      if (merge && s == top) continue;  // emitted together with top - 1
+      if (merge && s == top - 1) {
+        append_gemm_tasks_merged(*p->T[s], kinds[w], p->ncol, side(s, w), side(top, w), p->offS, p->ws, *lists[w]);
+      } else {
+        const GemmSide g = side(s, w);
+        append_gemm_tasks(*p->T[s], kinds[w], p->ncol, g.x_base, g.x_L, g.x_Rp, g.y_base, g.y_L, g.y_Rp, g.kscale, p->offS,
+                          p->ws, *lists[w], g.el_lo, g.fuse);
+      }
     }
     p->table_bytes[0] += p->T[s]->bytes[TAB_FWD];
     p->table_bytes[1] += p->T[s]->bytes[TAB_FWD_ADJ];
@@ -410,6 +438,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl, el_lo))) return rc;
   if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl, el_lo))) return rc;
   if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl, el_lo))) return rc;
+  if (merge) p->syn_fwd.merged = p->adj_fwdadj.merged = p->ana_inv.merged = p->anadj_invadj.merged = top - 1;
   v.clear();
   GemmFuse sum2;
   sum2.x2_base = p->offHB;

@@ -25,22 +25,27 @@ inline bool kind_el_to_ring(int kind) { return kind == TAB_INV || kind == TAB_FW
 inline bool kind_rows_are_el(int kind) { return kind == TAB_FWD || kind == TAB_INV_ADJ || kind == TAB_GRAM; }
 inline bool kind_k_is_el(int kind) { return kind == TAB_INV || kind == TAB_FWD_ADJ || kind == TAB_GRAM; }
 
-// One workgroup's share of a per-m GEMM: up to 8 row tiles of 16 output rows (two per wave).
+// One workgroup's share of a per-m GEMM: up to 8 row tiles of 16 output rows.
+// Column slabs: slab 0 = +m, slab 1 = -m (spin 0 shares one table up to the sign (-1)^m).  A MERGED task
+// (nslab = 4) streams the table once for TWO transforms at the same bandlimit (the two full-size wavelet
+// scales): slabs 2, 3 are the +m / -m slabs of the second transform; slabs 2g, 2g+1 form group g and share
+// the per-k operand scale, the per-row output scale and the row mask of that transform.
 struct GemmTask {
   int64_t tab_off;     // tiled table of this (m, first row tile), in doubles relative to the workspace base
                        // (kernel-argument-relative so the loads are global_load, not flat_load)
   int64_t rt_stride;   // doubles between consecutive row tiles
-  int64_t x_off[2];    // operand slab offsets (doubles) for +m / -m
-  int64_t y_off[2];    // output slab offsets
-  int64_t ks_off;      // optional per-k scale vector (indexed by absolute k) relative to the workspace base; 0 = none
+  int64_t x_off[4];    // operand slab offsets (doubles)
+  int64_t y_off[4];    // output slab offsets
+  int64_t x2_off[4];   // optional second operand (same layout) added to the first while staging; 0 = none
+  int64_t hd_off[4];   // affine epilogue: per-row complex constant of each slab (columns 0,1 of an H-layout array)
+  int64_t ks_off[2];   // per group: optional per-k scale vector (indexed by absolute k) relative to the base; 0 = none
+  int64_t rs_off[2];   // per group: optional per-output-row scale vector (absolute row); 0 = none
+  int row_lo[2], row_hi[2];  // per group: only output rows in [row_lo, row_hi) are written
   int k_beg, k_end;    // contraction range, multiples of 16
   int row0;            // first output row of this task
   int n_rt;            // row tiles in this task (1..8)
-  double sign1;        // factor on the -m output ((-1)^m)
-  int64_t x2_off[2];   // optional second operand (same layout) added to the first while staging; 0 = none
-  int64_t rs_off;      // optional per-output-row scale vector (absolute row) relative to the base; 0 = none
-  int row_lo, row_hi;  // only output rows in [row_lo, row_hi) are written
-  int64_t hd_off[2];   // affine epilogue: per-row complex constant of each slab (columns 0,1 of an H-layout array)
+  int nslab;           // live slabs: 1 (all m stored), 2 (+-m pair) or 4 (merged pair of transforms)
+  double sign1;        // factor on the -m outputs ((-1)^m)
 };
 
 // affine epilogue of the Gram launch: out = w * (ns * acc - hd[row]) as a complex product per chain
@@ -79,17 +84,38 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
                        int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
                        const double* ws_base, std::vector<GemmTask>& tasks, int el_lo = 0,
                        const GemmFuse& fuse = GemmFuse());
+// the same for TWO transforms that share the table T (same bandlimit): one pass over the table, 4 slabs
+struct GemmSide {
+  int64_t x_base, y_base;
+  int x_L, x_Rp, y_L, y_Rp;
+  const double* kscale;
+  int el_lo;
+  GemmFuse fuse;
+};
+void append_gemm_tasks_merged(const ShtTables& T, int kind, int ncol, const GemmSide& a, const GemmSide& b,
+                              int64_t scratch_off, const double* ws_base, std::vector<GemmTask>& tasks);
 
 // launch: tasks on device; X/Y = workspace base; col0 = first column of this chain group, ct = column
 // tiles (1 or 2) of the group
 // alg_bytes: algorithmic bytes of this launch (table once + operand + result), for the live profiler
-int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double* X, double* Y, int ncol,
-                int col0, int ct, double alg_bytes, hipStream_t stream, const GemmAffine& aff = GemmAffine());
+// nslab: 1 (unpaired), 2 (+-m pairs) or 4 (the list holds merged tasks)
+int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X, double* Y, int ncol,
+                int col0, int ct, double alg_bytes, double flops, hipStream_t stream,
+                const GemmAffine& aff = GemmAffine());
 
 // algorithmic bytes of one ring-GEMM stage at bandlimit L for C chains:
 // ring table 8*L*L*(L+1)/2 [paired] or 8*L*L*L [all m] read once, harmonic side 16*C*L*L,
 // ring side 16*C*L*(2L-1)
 // With a support cut el_lo only the degrees el >= el_lo count on the table and harmonic sides.
+inline double gemm_table_bytes(int L, bool paired, int el_lo = 0) {
+  double tab_entries = 0;
+  for (int m = paired ? 0 : -(L - 1); m < L; ++m) {
+    const int am = m < 0 ? -m : m;
+    const int n = L - (am > el_lo ? am : el_lo);
+    if (n > 0) tab_entries += n;
+  }
+  return 8.0 * L * tab_entries;
+}
 inline double gemm_alg_bytes(int L, bool paired, int C, int el_lo = 0) {
   double tab_entries = 0, lm_entries = 0;  // (m, el) pairs with el >= max(|m|, el_lo)
   for (int m = paired ? 0 : -(L - 1); m < L; ++m) {

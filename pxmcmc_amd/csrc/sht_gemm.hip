@@ -58,20 +58,26 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   const int nch = (t.k_end - t.k_beg) / KC;
 
   // ---- operand staging map: thread -> (row kr, column pair) of the chunk
-  constexpr bool ALL = (NV % NT) == 0;  // every thread stages in every pass
+  constexpr bool ALL = (NV % NT) == 0 && NSLAB < 4;  // every thread stages in every pass
+  const bool live4 = NSLAB < 4 || t.nslab == 4;   // slabs 2, 3 carry a second transform (merged task)
   const double* sp[IT];
   int64_t sd[IT];
   int so[IT];
+  int64_t sk[IT];  // per-k operand scale vector of the thread's slab group (0 = none)
   bool sv[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
     const int q = tid + NT * i;
-    sv[i] = ALL || q < NV;
     const int kr = (q / (COLS / 2)) % KC, col = 2 * (q % (COLS / 2));
     const int slab = col / (16 * CT), cin = col % (16 * CT);
-    sp[i] = X + (slab ? t.x_off[1] : t.x_off[0]) + col0 + cin + (int64_t)(t.k_beg + kr) * ncol;
-    sd[i] = (slab ? t.x2_off[1] : t.x2_off[0]) - (slab ? t.x_off[1] : t.x_off[0]);
+    sv[i] = (ALL || q < NV) && (slab < 2 || live4);
+    // (per-thread slab: read from the task in memory -- a runtime index into the register copy would push
+    // the whole struct into scratch)
+    const int64_t xo = tasks[blockIdx.x].x_off[slab];
+    sp[i] = X + xo + col0 + cin + (int64_t)(t.k_beg + kr) * ncol;
+    sd[i] = tasks[blockIdx.x].x2_off[slab] - xo;
     so[i] = kr * PITCH + col;
+    sk[i] = tasks[blockIdx.x].ks_off[slab >> 1];
   }
   const bool two = t.x2_off[0] != 0;  // second operand summed in while staging (fused wavelet combine)
   double2 st[IT], st2[IT];
@@ -87,8 +93,8 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
       v.x += st2[i].x;                                                                              \
       v.y += st2[i].y;                                                                              \
     }                                                                                               \
-    if (t.ks_off) {                                                                                 \
-      const double sc = (X + t.ks_off)[t.k_beg + (CH) * KC + so[i] / PITCH];                        \
+    if (sk[i]) {                                                                                    \
+      const double sc = (X + sk[i])[t.k_beg + (CH) * KC + so[i] / PITCH];                           \
       v.x *= sc;                                                                                    \
       v.y *= sc;                                                                                    \
     }                                                                                               \
@@ -136,18 +142,18 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
         PXM_TAB_LOAD((u + NSET - 1) % NSET, ch + NSET - 1)
         __syncthreads();
         if (v0) {
-#pragma unroll
-          for (int h4 = 0; h4 < 4; ++h4) {
-            double b[NCT];
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) b[c] = xs[buf][4 * h4 + kq][16 * c + cl];
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-              const double av = (h4 & 1) ? A[u][r][h4 >> 1].y : A[u][r][h4 >> 1].x;
-#pragma unroll
-              for (int c = 0; c < NCT; ++c) acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[c], acc[r][c], 0, 0, 0);
-            }
-          }
+#define PXM_MFMA_CHUNK(NC)                                                                                     \
+  _Pragma("unroll") for (int h4 = 0; h4 < 4; ++h4) {                                                           \
+    double b[NC];                                                                                              \
+    _Pragma("unroll") for (int c = 0; c < NC; ++c) b[c] = xs[buf][4 * h4 + kq][16 * c + cl];                   \
+    _Pragma("unroll") for (int r = 0; r < RT; ++r) {                                                           \
+      const double av = (h4 & 1) ? A[u][r][h4 >> 1].y : A[u][r][h4 >> 1].x;                                    \
+      _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                           \
+          acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[c], acc[r][c], 0, 0, 0);                      \
+    }                                                                                                          \
+  }
+          if (live4) { PXM_MFMA_CHUNK(NCT) } else { PXM_MFMA_CHUNK((NSLAB == 4 ? NCT / 2 : NCT)) }
+#undef PXM_MFMA_CHUNK
         }
       }
     }
@@ -162,16 +168,17 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     if (r >= n_my) continue;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-      const int slab = c / CT, cin = 16 * (c % CT);
-      const double sg = (slab == 0) ? 1.0 : t.sign1;
+      const int slab = c / CT, cin = 16 * (c % CT), grp = slab >> 1;
+      if (slab >= 2 && !live4) continue;
+      const double sgn = (slab & 1) ? t.sign1 : 1.0;
       const int rowb = t.row0 + 16 * (RT * wave + r) + kq;
-      double* yb = Y + (slab ? t.y_off[1] : t.y_off[0]) + col0 + cin + cl + (int64_t)rowb * ncol;
+      double* yb = Y + t.y_off[slab] + col0 + cin + cl + (int64_t)rowb * ncol;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = rowb + 4 * q;
         double v = acc[r][c][q];
         if (aff.on) {  // out = w * (ns * acc - hd[row]), complex per chain: (re, im) sit in adjacent lanes
-          const double hdv = (X + (slab ? t.hd_off[1] : t.hd_off[0]))[(int64_t)row * ncol + (cl & 1)];
+          const double hdv = (X + t.hd_off[slab])[(int64_t)row * ncol + (cl & 1)];
           const double u = aff.ns * v - hdv;
           int lo = __double2loint(u), hi = __double2hiint(u);
           lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]: partner lane
@@ -179,9 +186,9 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
           const double pu = __hiloint2double(hi, lo);
           v = (cl & 1) ? (aff.wr * u + aff.wi * pu) : (aff.wr * u - aff.wi * pu);
         }
-        if (row >= t.row_lo && row < t.row_hi) {
-          const double rs = t.rs_off ? (X + t.rs_off)[row] : 1.0;
-          yb[(int64_t)(4 * q) * ncol] = sg * rs * v;
+        if (row >= t.row_lo[grp] && row < t.row_hi[grp]) {
+          const double rs = t.rs_off[grp] ? (X + t.rs_off[grp])[row] : 1.0;
+          yb[(int64_t)(4 * q) * ncol] = sgn * rs * v;
         }
       }
     }
@@ -192,16 +199,17 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 static size_t g_prof_used = 0;
-static double g_prof_bytes = 0;
+static double g_prof_bytes = 0, g_prof_flops = 0;
 
 // next event pair of the pool (or nulls when profiling is off): passed to hipExtLaunchKernelGGL, which
 // stamps them with the kernel's own start / end (what rocprofv3's kernel trace reports)
-static void profile_gemm_events(hipEvent_t* start, hipEvent_t* stop, double alg_bytes) {
+static void profile_gemm_events(hipEvent_t* start, hipEvent_t* stop, double alg_bytes, double flops) {
   *start = *stop = nullptr;
   if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return;
   *start = g_prof_pool[g_prof_used].first;
   *stop = g_prof_pool[g_prof_used].second;
   g_prof_bytes += alg_bytes;
+  g_prof_flops += flops;
   ++g_prof_used;
 }
 int profile_enable(int on) {
@@ -214,10 +222,10 @@ int profile_enable(int on) {
   }
   g_prof_on = on != 0;
   g_prof_used = 0;
-  g_prof_bytes = 0;
+  g_prof_bytes = g_prof_flops = 0;
   return 0;
 }
-int profile_read(double* ms, int64_t* launches, double* bytes) {
+int profile_read(double* ms, int64_t* launches, double* bytes, double* flops) {
   double tot = 0;
   for (size_t i = 0; i < g_prof_used; ++i) {
     PXM_HIP(hipEventSynchronize(g_prof_pool[i].second));
@@ -228,8 +236,9 @@ int profile_read(double* ms, int64_t* launches, double* bytes) {
   if (ms) *ms = tot;
   if (launches) *launches = (int64_t)g_prof_used;
   if (bytes) *bytes = g_prof_bytes;
+  if (flops) *flops = g_prof_flops;
   g_prof_used = 0;
-  g_prof_bytes = 0;
+  g_prof_bytes = g_prof_flops = 0;
   return 0;
 }
 
@@ -253,18 +262,20 @@ int gemm_geom(int ncol) {
 }
 int gemm_rows_per_task(int ncol) { return gemm_geom(ncol) == 41 ? 4 : 8; }
 
-int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double* X, double* Y, int ncol,
-                int col0, int ct, double alg_bytes, hipStream_t stream, const GemmAffine& aff) {
+int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X, double* Y, int ncol,
+                int col0, int ct, double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff) {
   if (n_tasks == 0) return 0;
   const int geom = gemm_geom(ncol);
   dim3 grid(n_tasks), block(geom == 81 ? 512 : 256);  // 41: 4 waves x 1 row tile (tasks of 4 row tiles)
   hipEvent_t ev0, ev1;
-  profile_gemm_events(&ev0, &ev1, alg_bytes);
+  profile_gemm_events(&ev0, &ev1, alg_bytes, flops);
 #define PXM_GEMM_LAUNCH(A, B)                                                                                         \
   if (geom == 81) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 8, 1>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
   else if (geom == 41) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 1>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
   else hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
-  if (paired) {
+  if (nslab == 4) {
+    if (ct == 1) { PXM_GEMM_LAUNCH(1, 4) } else { PXM_GEMM_LAUNCH(2, 4) }
+  } else if (nslab == 2) {
     if (ct == 1) { PXM_GEMM_LAUNCH(1, 2) } else { PXM_GEMM_LAUNCH(2, 2) }
   } else {
     if (ct == 1) { PXM_GEMM_LAUNCH(1, 1) } else { PXM_GEMM_LAUNCH(2, 1) }
@@ -277,13 +288,51 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, bool paired, const double*
 // ---------------------------------------------------------------------------------------
 // Task lists
 // ---------------------------------------------------------------------------------------
-void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, int x_L, int x_Rp,
-                       int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
-                       const double* ws_base, std::vector<GemmTask>& tasks, int el_lo, const GemmFuse& fuse) {
-  // el_lo: harmonic degrees below it carry no signal for this transform (compact support of a wavelet
-  // kernel): the rows (ring->el kinds) or contraction steps (el->ring kinds) below it are skipped.
+// slabs 2g, 2g+1 of task g <- one transform (side): operand / output slab offsets for +m / -m, scales, row mask
+static void fill_side(GemmTask& g, int grp, const ShtTables& T, int kind, int m, int ncol, const GemmSide& sd,
+                      int64_t scratch_off, const double* ws_base) {
+  const int s0 = 2 * grp, s1 = 2 * grp + 1;
+  g.x_off[s0] = sd.x_base + (int64_t)(m + sd.x_L - 1) * sd.x_Rp * ncol;
+  g.y_off[s0] = sd.y_base + (int64_t)(m + sd.y_L - 1) * sd.y_Rp * ncol;
+  if (T.paired) {
+    if (m == 0) {
+      g.x_off[s1] = g.x_off[s0];
+      g.y_off[s1] = scratch_off;
+    } else {
+      g.x_off[s1] = sd.x_base + (int64_t)(-m + sd.x_L - 1) * sd.x_Rp * ncol;
+      g.y_off[s1] = sd.y_base + (int64_t)(-m + sd.y_L - 1) * sd.y_Rp * ncol;
+    }
+  } else {
+    g.x_off[s1] = g.x_off[s0];
+    g.y_off[s1] = g.y_off[s0];
+  }
+  g.ks_off[grp] = sd.kscale ? (sd.kscale - ws_base) : 0;
+  g.rs_off[grp] = sd.fuse.rscale ? (sd.fuse.rscale - ws_base) : 0;
+  g.row_lo[grp] = sd.fuse.row_lo;
+  g.row_hi[grp] = sd.fuse.row_hi;
+  g.x2_off[s0] = g.x2_off[s1] = 0;
+  if (sd.fuse.x2_base >= 0) {
+    g.x2_off[s0] = sd.fuse.x2_base + (int64_t)(m + sd.x_L - 1) * sd.x_Rp * ncol;
+    g.x2_off[s1] = (T.paired && m != 0) ? sd.fuse.x2_base + (int64_t)(-m + sd.x_L - 1) * sd.x_Rp * ncol : g.x2_off[s0];
+  }
+  g.hd_off[s0] = g.hd_off[s1] = 0;
+  if (sd.fuse.hd_base >= 0) {
+    g.hd_off[s0] = sd.fuse.hd_base + (int64_t)(m + sd.y_L - 1) * sd.y_Rp * ncol;
+    g.hd_off[s1] = (T.paired && m != 0) ? sd.fuse.hd_base + (int64_t)(-m + sd.y_L - 1) * sd.y_Rp * ncol : g.hd_off[s0];
+  }
+  (void)kind;
+}
+
+static void append_tasks_impl(const ShtTables& T, int kind, int ncol, const GemmSide* sides, int nsides,
+                              int64_t scratch_off, const double* ws_base, std::vector<GemmTask>& tasks) {
+  // el_lo: harmonic degrees below it carry no signal for a transform (compact support of a wavelet
+  // kernel): the rows (ring->el kinds) or contraction steps (el->ring kinds) below it are skipped.  A merged
+  // task starts at the smaller of its two cuts; rows / steps between the cuts are masked (row_lo) or carry a
+  // zero operand scale for the transform that does not need them.
   const bool rows_el = kind_rows_are_el(kind), k_el = kind_k_is_el(kind);
   const int Rp = T.Rp;
+  int el_lo = sides[0].el_lo;
+  for (int i = 1; i < nsides; ++i) el_lo = std::min(el_lo, sides[i].el_lo);
   const int lo16 = round_down(std::max(el_lo, 0), 16);
   const int rpt = gemm_rows_per_task(ncol);  // row tiles per task
   for (int i = 0; i < T.n_m; ++i) {
@@ -300,42 +349,29 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
       GemmTask g;
       g.tab_off = (T.d_tab[kind] + T.m_off[kind][i] + tab_skip + (int64_t)rt * rt_stride) - ws_base;
       g.rt_stride = rt_stride;
-      g.x_off[0] = x_base + (int64_t)(m + x_L - 1) * x_Rp * ncol;
-      g.y_off[0] = y_base + (int64_t)(m + y_L - 1) * y_Rp * ncol;
-      if (T.paired) {
-        if (m == 0) {
-          g.x_off[1] = g.x_off[0];
-          g.y_off[1] = scratch_off;
-        } else {
-          g.x_off[1] = x_base + (int64_t)(-m + x_L - 1) * x_Rp * ncol;
-          g.y_off[1] = y_base + (int64_t)(-m + y_L - 1) * y_Rp * ncol;
-        }
-      } else {
-        g.x_off[1] = g.x_off[0];
-        g.y_off[1] = g.y_off[0];
-      }
-      g.ks_off = kscale ? (kscale - ws_base) : 0;
-      g.rs_off = fuse.rscale ? (fuse.rscale - ws_base) : 0;
-      g.row_lo = fuse.row_lo;
-      g.row_hi = fuse.row_hi;
-      g.x2_off[0] = g.x2_off[1] = 0;
-      if (fuse.x2_base >= 0) {
-        g.x2_off[0] = fuse.x2_base + (int64_t)(m + x_L - 1) * x_Rp * ncol;
-        g.x2_off[1] = (T.paired && m != 0) ? fuse.x2_base + (int64_t)(-m + x_L - 1) * x_Rp * ncol : g.x2_off[0];
-      }
+      for (int s = 0; s < 2; ++s) fill_side(g, s, T, kind, m, ncol, sides[s < nsides ? s : 0], scratch_off, ws_base);
+      g.nslab = nsides == 2 ? 4 : (T.paired ? 2 : 1);
       g.k_beg = k_beg;
       g.k_end = k_end;
       g.row0 = row_beg + 16 * rt;
       g.n_rt = std::min(rpt, n_rt_total - rt);
       g.sign1 = (kind == TAB_GRAM) ? 1.0 : ((m & 1) ? -1.0 : 1.0);  // the Gram table is even in m
-      g.hd_off[0] = g.hd_off[1] = 0;
-      if (fuse.hd_base >= 0) {
-        g.hd_off[0] = fuse.hd_base + (int64_t)(m + y_L - 1) * y_Rp * ncol;
-        g.hd_off[1] = (T.paired && m != 0) ? fuse.hd_base + (int64_t)(-m + y_L - 1) * y_Rp * ncol : g.hd_off[0];
-      }
       tasks.push_back(g);
     }
   }
+}
+
+void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, int x_L, int x_Rp,
+                       int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
+                       const double* ws_base, std::vector<GemmTask>& tasks, int el_lo, const GemmFuse& fuse) {
+  const GemmSide sd{x_base, y_base, x_L, x_Rp, y_L, y_Rp, kscale, el_lo, fuse};
+  append_tasks_impl(T, kind, ncol, &sd, 1, scratch_off, ws_base, tasks);
+}
+
+void append_gemm_tasks_merged(const ShtTables& T, int kind, int ncol, const GemmSide& a, const GemmSide& b,
+                              int64_t scratch_off, const double* ws_base, std::vector<GemmTask>& tasks) {
+  const GemmSide sides[2] = {a, b};
+  append_tasks_impl(T, kind, ncol, sides, 2, scratch_off, ws_base, tasks);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -381,8 +417,8 @@ __global__ void k_tile_table(const double* __restrict__ D, double* __restrict__ 
 }  // namespace pxm
 extern "C" {
 int pxm_profile_enable(int on) { return pxm::profile_enable(on); }
-int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes) {
-  return pxm::profile_read(gemm_ms, gemm_launches, gemm_alg_bytes);
+int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes, double* gemm_flops) {
+  return pxm::profile_read(gemm_ms, gemm_launches, gemm_alg_bytes, gemm_flops);
 }
 }
 namespace pxm {
