@@ -8,6 +8,12 @@ raises, it never falls back to a CPU implementation.
 import ctypes as C
 import os
 
+# torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so).  If this library (linked against
+# /opt/rocm's libamdhip64.so.7) were loaded before torch, the process would end up with two HIP runtimes and
+# the second one sees no device.  With torch loaded first the loader resolves our dependency to the runtime
+# torch already brought in, so kernels, streams and device pointers are shared.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PXM_LIB_PATH") or os.path.join(_HERE, "lib", "libpxmcmc_amd.so")  # override: A/B builds
 
