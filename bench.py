@@ -89,8 +89,15 @@ def main():
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
-    torch.cuda.set_device(local_rank)
-    D.init(backend="nccl", device_id=torch.device("cuda", local_rank))
+    # rehearsal aid for a one-GPU box: PXM_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo for the
+    # barrier / max-reduce (RCCL refuses two ranks on one device); never set by the driver
+    rehearse = bool(os.environ.get("PXM_BENCH_REHEARSE"))
+    dev_index = 0 if rehearse else local_rank
+    torch.cuda.set_device(dev_index)
+    if rehearse:
+        D.init(backend="gloo")
+    else:
+        D.init(backend="nccl", device_id=torch.device("cuda", dev_index))
 
     from pxmcmc_amd import ops
     from pxmcmc_amd._lib import lib
