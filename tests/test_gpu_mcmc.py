@@ -420,3 +420,46 @@ def test_full_size_step_properties_L256():
     # ... and that noise is the documented Philox stream of each chain
     ref = ops.randn(op.nparams, C, seed=3, chain0=0, it=17).cpu().numpy()
     assert np.abs(w - ref).max() < 1e-6
+
+
+def test_philox_myula_stationary_moments_toy():
+    """Statistical check of the production (device Philox) path, independent of the oracle: on the identity toy
+    problem the coordinates decouple and MYULA targets p(x) ~ exp(-(x-d)^2 / (2 sigma^2) - f_lambda(x)) with the
+    Moreau envelope f_lambda of mu |x| (a Huber function).  Moments over 4096 independent chains after burn-in
+    are compared with the 1-D integrals (Euler-Maruyama bias: relative delta / (2 sigma^2) on the variance)."""
+    import torch
+
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+
+    N, C = 64, 4096
+    rng = np.random.default_rng(5)
+    d = rng.normal(size=N) * 0.3
+    d[:8] = np.linspace(-0.02, 0.02, 8)  # some coordinates inside / at the edge of the threshold region
+    sigma, lmda, delta, mu = 0.1, 2e-3, 2e-4, 20.0
+    op, reg = _toy(d, lmda, mu)
+    p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=1, nburn=1500, ngap=1, verbosity=0, track=["chain"])
+    s = MYULA(op, reg, p, nchains=C, seed=17)
+    _quiet(s.run, start_point=np.zeros(N))
+    X = s.X_curr.cpu().numpy()
+    assert X.shape == (C, N)
+    # reference moments by quadrature
+    T = lmda * mu
+    x = np.linspace(-2, 2, 400001)
+    huber = np.where(np.abs(x) > T, mu * np.abs(x) - lmda * mu ** 2 / 2, x ** 2 / (2 * lmda))
+    mean, var, curv = np.zeros(N), np.zeros(N), np.zeros(N)
+    for i in range(N):
+        logp = -(x - d[i]) ** 2 / (2 * sigma ** 2) - huber
+        w = np.exp(logp - logp.max())
+        w /= w.sum()
+        mean[i] = (w * x).sum()
+        var[i] = (w * (x - mean[i]) ** 2).sum()
+        curv[i] = 1 / sigma ** 2 + (w * (np.abs(x) < T)).sum() / lmda  # posterior-averaged curvature of the potential
+    se = np.sqrt(var / C)
+    assert np.abs(X.mean(axis=0) - mean).max() < 5 * se.max() + 2e-4
+    # Euler-Maruyama inflates the stationary variance by ~1 / (1 - delta a / 2), a = curvature (1-6 % here)
+    ratio = X.var(axis=0) / var * (1 - delta * curv / 2)
+    assert abs(ratio.mean() - 1) < 0.012, ratio.mean()
+    assert np.abs(ratio - 1).max() < 0.12, ratio
+    # chains are independent: correlation between chains' states is at the noise level
+    cc = np.corrcoef((X - X.mean(axis=0))[:64])[np.triu_indices(64, 1)]  # N = 64 coordinates per chain: sd 0.125
+    assert np.abs(cc).max() < 0.6 and abs(cc.mean()) < 0.02
