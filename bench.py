@@ -28,8 +28,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 L, B, J_MIN, CHAINS_PER_GPU = 256, 2.0, 2, 16
-LMDA, MU, SIGMA = 1e-6, 1.0, 0.05
-DELTA = LMDA / 2
+LMDA, MU, SIGMA = 1e-6, 1.0, 0.05  # lmda: the reference's topography value (experiments/earthtopography/main.py:128)
+
+
+def stable_delta(transform, sigma, lmda, iters=30):
+    """MYULA step size delta = 0.8 / (L_f + 1/lmda) (Durmus, Moulines & Pereyra 2018), L_f = ||S||^2 / sigma^2 the
+    Lipschitz constant of the data-fidelity gradient, ||S||^2 by power iteration on S^H S.  (delta = lmda / 2 is
+    beyond this bound at sigma = 0.05 -- ||S||^2 = 1.35e4 at L = 256 -- and the chain diverges after ~600
+    iterations.)"""
+    import torch
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(transform.ncoefs, dtype=torch.complex128, generator=g).cuda()
+    lam = 0.0
+    for _ in range(iters):
+        y = transform.inverse_adjoint(transform.inverse(x))
+        lam = float(torch.linalg.norm(y) / torch.linalg.norm(x))
+        x = y / torch.linalg.norm(y)
+    return 0.8 / (lam / sigma ** 2 + 1.0 / lmda), lam
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 
 
@@ -48,7 +64,7 @@ def synthetic_field(plan_inverse, L, seed):
     return f / np.sqrt(np.mean(f ** 2)), rng
 
 
-def cpu_baseline(data, T, n_iter):
+def cpu_baseline(data, T, n_iter, delta):
     """the oracle's literal MYULA iteration (one chain, numpy, this host) -- baseline only"""
     from oracle import pxmcmc_np as ref
 
@@ -62,7 +78,7 @@ def cpu_baseline(data, T, n_iter):
     for _ in range(n_iter):
         gradg = op.calc_gradg(preds)
         px = ref.soft(X, T)
-        X = ref.chain_step(X, px, gradg, DELTA, LMDA, rng.normal(size=tr.ncoefs))
+        X = ref.chain_step(X, px, gradg, delta, LMDA, rng.normal(size=tr.ncoefs))
         preds = op.forward(X)
     dt = time.perf_counter() - t0
     assert np.isfinite(X).all()
@@ -113,7 +129,8 @@ def main():
     data = truth + SIGMA * rng.normal(size=truth.size)
     op = SphericalWaveletTransformOperator(data, SIGMA, "synthesis", L, B, J_MIN, max_chains=C)
     reg = S2_Wavelets_L1("synthesis", op.transform.inverse, op.transform.inverse_adjoint, LMDA * MU, L=L, B=B, J_min=J_MIN)
-    params = PxMCMCParams(lmda=LMDA, delta=DELTA, mu=MU, nsamples=1, nburn=0, ngap=1, verbosity=0)
+    delta, s_norm2 = stable_delta(op.transform, SIGMA, LMDA)
+    params = PxMCMCParams(lmda=LMDA, delta=delta, mu=MU, nsamples=1, nburn=0, ngap=1, verbosity=0)
     first_chain, _ = D.shard_chains(world * C, rank, world)  # weak scaling: C chains per GPU
     sampler = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain,
                     real_pairs=not args.no_real_pairs)
@@ -181,6 +198,7 @@ def main():
                             + ("two real chains per complex128 slot (real-signal symmetry, SURVEY 8d)" if eng["pairs"]
                                else "one complex128 slot per chain (reference layout)"),
                 "real_pairs": bool(eng["pairs"]),
+                "sigma": SIGMA, "lmda": LMDA, "delta": delta, "synthesis_norm2": s_norm2,
                 "chains_per_gpu": C,
                 "global_chains": world * C,
                 "parallelism": f"chains sharded over {world} GPU(s), no collective on the data path",
@@ -205,7 +223,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             T = reg.T
-            v, secs = cpu_baseline(data, T, args.cpu_iters)
+            v, secs = cpu_baseline(data, T, args.cpu_iters, delta)
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "samples/s",
