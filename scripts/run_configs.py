@@ -35,8 +35,10 @@ data = rng.normal(size=L * (2 * L - 1))
 for C in (1, 16):
     op2 = SphericalWaveletTransformOperator(data, 0.05, "synthesis", L, B, J, max_chains=C)
     reg2 = S2_Wavelets_L1("synthesis", None, None, 1e-6, L=L, B=B, J_min=J)
-    p = PxMCMCParams(lmda=1e-6, delta=5e-7, nsamples=4, nburn=0, ngap=500, verbosity=0)
-    timed(MYULA(op2, reg2, PxMCMCParams(lmda=1e-6, delta=5e-7, nsamples=2, nburn=0, ngap=20, verbosity=0), nchains=C), start_point=np.zeros(op2.nparams))
+    import bench
+    dl, _ = bench.stable_delta(op2.transform, 0.05, 1e-6)  # step size inside the MYULA stability bound
+    p = PxMCMCParams(lmda=1e-6, delta=dl, nsamples=4, nburn=0, ngap=500, verbosity=0)
+    timed(MYULA(op2, reg2, PxMCMCParams(lmda=1e-6, delta=dl, nsamples=2, nburn=0, ngap=20, verbosity=0), nchains=C), start_point=np.zeros(op2.nparams))
     s = MYULA(op2, reg2, p, nchains=C)
     dt = timed(s, start_point=np.zeros(op2.nparams))
     print(f"C2 L=64 B=1.5 (N={op2.nparams}), {C} chain(s): {s.niter} iterations in {dt:.3f} s -> {s.niter * C / dt:,.0f} samples/s (graph={s.used_graph})", flush=True)
