@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=48)
     ap.add_argument("--no-real-pairs", action="store_true", help="one complex128 slot per chain (reference layout)")
+    ap.add_argument("--no-layout-compare", action="store_true", help="skip the reference-layout side measurement")
     args = ap.parse_args()
 
     import torch
@@ -169,6 +170,25 @@ def main():
     assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
 
     dt = D.max_over_ranks(dt)
+    used_graph = eng["graph"] is not None
+
+    # informative side figure (rank 0, outside the timed region): the same iteration with one complex128 slot
+    # per chain, i.e. the reference's state layout without the real-pair packing
+    ref_layout_rate = None
+    if rank == 0 and eng["pairs"] and not args.no_layout_compare:
+        sampler._engine_stop()
+        s2 = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain, real_pairs=False)
+        s2._prepare()
+        with contextlib.redirect_stdout(io.StringIO()):
+            X2, P2 = s2._initial_sample(np.zeros(op.nparams))
+        s2._engine_start(X2, P2, 0)
+        s2._engine_advance(args.warmup)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        s2._engine_advance(args.steps)
+        torch.cuda.synchronize()
+        ref_layout_rate = C * args.steps / (time.perf_counter() - t1)
+        s2._engine_stop()
 
     if rank == 0:
         value = world * C * args.steps / dt
@@ -198,11 +218,12 @@ def main():
                             + ("two real chains per complex128 slot (real-signal symmetry, SURVEY 8d)" if eng["pairs"]
                                else "one complex128 slot per chain (reference layout)"),
                 "real_pairs": bool(eng["pairs"]),
+                "samples_per_s_one_gpu_reference_layout": ref_layout_rate,
                 "sigma": SIGMA, "lmda": LMDA, "delta": delta, "synthesis_norm2": s_norm2,
                 "chains_per_gpu": C,
                 "global_chains": world * C,
                 "parallelism": f"chains sharded over {world} GPU(s), no collective on the data path",
-                "hip_graph": eng["graph"] is not None,
+                "hip_graph": used_graph,
             },
             "roofline": {
                 "bound": "hbm",
