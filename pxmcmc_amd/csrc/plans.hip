@@ -256,6 +256,34 @@ __global__ void k_wav_combine(CombineArgs a, const double* __restrict__ ws, doub
 
 }  // namespace pxm
 
+// Side streams and their fork / join events are per-device and live for the whole process: every plan borrows
+// them.  (Destroying streams that took part in a HIP-graph capture while the capturing stream lives on
+// corrupts the runtime's capture bookkeeping: a loop that builds a sampler, captures its iteration and drops
+// the plan crashed in the 32nd hipGraphLaunch.)  Sharing only adds false ordering between plans, never a race:
+// a fork makes the side stream wait for the caller's stream, a join the reverse.
+namespace pxm {
+struct SidePool {
+  static constexpr int N = 3;
+  hipStream_t side[N] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[N] = {nullptr, nullptr, nullptr};
+};
+static int side_pool(SidePool** out) {
+  static SidePool pools[16];
+  int dev = 0;
+  PXM_HIP(hipGetDevice(&dev));
+  SidePool& sp = pools[dev & 15];
+  if (!sp.ev_fork) {
+    for (int i = 0; i < SidePool::N; ++i) {
+      PXM_HIP(hipStreamCreateWithFlags(&sp.side[i], hipStreamNonBlocking));
+      PXM_HIP(hipEventCreateWithFlags(&sp.ev_join[i], hipEventDisableTiming));
+    }
+    PXM_HIP(hipEventCreateWithFlags(&sp.ev_fork, hipEventDisableTiming));
+  }
+  *out = &sp;
+  return 0;
+}
+}  // namespace pxm
+
 struct pxm_wav_plan_s {
   int L = 0, J_min = 0, J_max = 0, Cmax = 0, Cp = 0, ncol = 0, Rp = 0;
   double B = 0;
@@ -477,11 +505,13 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   p->lane_of.assign(p->nsc, -1);
   if (!getenv("PXM_NO_SIDE_STREAMS")) {
     if (const char* e = getenv("PXM_NSIDE")) p->nside = std::max(1, std::min((int)pxm_wav_plan_s::NSIDE, atoi(e)));
-    for (int i = 0; i < p->nside; ++i) {
-      PXM_HIP(hipStreamCreateWithFlags(&p->side[i], hipStreamNonBlocking));
-      PXM_HIP(hipEventCreateWithFlags(&p->ev_join[i], hipEventDisableTiming));
+    SidePool* sp = nullptr;
+    if ((rc = side_pool(&sp))) return rc;
+    for (int i = 0; i < p->nside; ++i) {  // borrowed from the per-device pool, never destroyed
+      p->side[i] = sp->side[i];
+      p->ev_join[i] = sp->ev_join[i];
     }
-    PXM_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    p->ev_fork = sp->ev_fork;
     int k = 0;
     for (int s = p->nsc - 1; s >= 0; --s)
       if (p->bl[s] < L) p->lane_of[s] = (k++) % p->nside;
@@ -504,11 +534,7 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   if (p->ws) (void)hipFree(p->ws);
   if (p->d_kc_syn) (void)hipFree(p->d_kc_syn);
   if (p->d_kc_ana) (void)hipFree(p->d_kc_ana);
-  for (int i = 0; i < pxm_wav_plan_s::NSIDE; ++i) {
-    if (p->side[i]) (void)hipStreamDestroy(p->side[i]);
-    if (p->ev_join[i]) (void)hipEventDestroy(p->ev_join[i]);
-  }
-  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  // (side streams / events belong to the per-device pool)
   TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj, &p->adj_invadj_R, &p->gram, &p->adj_invadj_D,
                      &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj};
   for (TaskList* t : tls)

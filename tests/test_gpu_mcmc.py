@@ -463,3 +463,23 @@ def test_philox_myula_stationary_moments_toy():
     # chains are independent: correlation between chains' states is at the noise level
     cc = np.corrcoef((X - X.mean(axis=0))[:64])[np.triu_indices(64, 1)]  # N = 64 coordinates per chain: sd 0.125
     assert np.abs(cc).max() < 0.6 and abs(cc.mean()) < 0.02
+
+
+def test_many_samplers_capture_and_drop():
+    """Regression: build a sampler, capture + replay its iteration (image-space path, side streams inside the
+    capture), drop it -- 40 times in one process.  With per-plan side streams destroyed at plan teardown the
+    32nd hipGraphLaunch crashed; side streams now live in a per-device pool."""
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B = 10, 2.0
+    P = L * (2 * L - 1)
+    rng = np.random.default_rng(0)
+    reg = S2_Wavelets_L1("synthesis", None, None, 1e-3, L=L, B=B, J_min=1)
+    p = PxMCMCParams(lmda=1e-3, delta=4e-4, nsamples=3, nburn=0, ngap=4, verbosity=0)
+    for rep in range(40):
+        op = SphericalWaveletTransformOperator(rng.normal(size=P), np.linspace(0.15, 0.3, P), "synthesis", L, B, 1)
+        s = MYULA(op, reg, p, nchains=1, seed=rep)
+        _quiet(s.run, start_point=np.zeros(op.nparams))
+        assert s.used_graph and s._eng["pairs"] and not s._eng["ring"] and np.isfinite(s.chain).all()
