@@ -89,7 +89,9 @@ static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, i
     }
     if (tl.merged >= 0)  // two transforms, one pass over the table: the smaller of the two row ranges is not re-read
       bytes -= gemm_table_bytes(tl.bls[tl.merged], tl.paired, std::max(tl.los[tl.merged], tl.los[tl.merged + 1]));
-    int rc = launch_gemm(tl.d, tl.n, tl.nslab, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, aff);
+    GemmAffine a = aff;
+    if (col0) a.bump = nullptr;  // the iteration counter advances once per call, not once per column group
+    int rc = launch_gemm(tl.d, tl.n, tl.nslab, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, a);
     if (rc) return rc;
   }
   return 0;

@@ -483,3 +483,27 @@ def test_many_samplers_capture_and_drop():
         s = MYULA(op, reg, p, nchains=1, seed=rep)
         _quiet(s.run, start_point=np.zeros(op.nparams))
         assert s.used_graph and s._eng["pairs"] and not s._eng["ring"] and np.isfinite(s.chain).all()
+
+
+@pytest.mark.parametrize("pairs", [False, True])
+def test_more_than_one_column_group_equals_single_chains(pairs):
+    """More than 16 complex slots run as several column groups per GEMM launch (17 chains in the reference
+    layout, 34 chains in pairs): the Philox iteration counter must advance once per step, not once per group --
+    every chain of the batch equals the same chain run alone."""
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min = 12, 2, 2
+    C = 34 if pairs else 17
+    data = np.random.default_rng(4).normal(size=L * (2 * L - 1))
+    op = SphericalWaveletTransformOperator(data, 0.1, "synthesis", L, B, J_min, max_chains=C)
+    reg = S2_Wavelets_L1("synthesis", None, None, 1e-3, L=L, B=B, J_min=J_min)
+    p = PxMCMCParams(lmda=1e-3, delta=5e-4, nsamples=3, nburn=1, ngap=2, verbosity=0)
+    batch = MYULA(op, reg, p, nchains=C, seed=7, real_pairs=pairs)
+    _quiet(batch.run, start_point=np.zeros(op.nparams))
+    assert batch._eng["ring"] and batch._eng["pairs"] is pairs
+    for c in (0, 15, 16, C - 1):
+        one = MYULA(op, reg, p, nchains=1, seed=7, chain_offset=c, real_pairs=pairs)
+        _quiet(one.run, start_point=np.zeros(op.nparams))
+        np.testing.assert_allclose(one.chain, batch.chain[c], rtol=1e-11, atol=1e-13)
