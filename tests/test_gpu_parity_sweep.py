@@ -16,3 +16,15 @@ def test_parity_sweep_against_oracle():
 
     ntot, nfail = fuzz_parity.main(stride=3)
     assert ntot >= 40 and nfail == 0
+
+
+def test_fused_paths_equal_unfused_kernels_random_sizes():
+    """25 random (L in 5..71, B in {1.5, 2, 3}, J_min, chains, real / complex data, scalar / vector sig_d): the
+    fused wavelet MYULA engine (ring-space + Gram + grouped DFT + real pairs, or image-space) equals the chain of
+    separate calc_gradg / proxf / chain_step / forward kernels."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import fuzz_fused
+
+    ntot, nfail = fuzz_fused.main(ncase=25, seed=1)
+    assert ntot == 25 and nfail == 0
