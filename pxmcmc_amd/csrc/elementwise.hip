@@ -469,8 +469,9 @@ int pxm_wl_harmonic_mapping(const void* flm, const double* kernel, void* out, in
 
 int pxm_wl_mask_gather(const void* f, const int64_t* idx, const double* w, void* out, int64_t npix, int64_t ndata,
                        int C, pxm_stream_t stream) {
-  PXM_REQUIRE(C >= 1 && f && idx && out && ndata >= 0 && npix >= ndata, "pxm_wl_mask_gather: bad arguments");
-  if (ndata == 0) return 0;
+  PXM_REQUIRE(C >= 1 && ndata >= 0 && npix >= ndata, "pxm_wl_mask_gather: bad arguments");
+  if (ndata == 0) return 0;  // everything masked: nothing to gather
+  PXM_REQUIRE(f && idx && out, "pxm_wl_mask_gather: null buffer");
   hipLaunchKernelGGL(k_wl_gather, ew_grid(ndata, C), dim3(256), 0, (hipStream_t)stream, (const double2*)f, idx, w,
                      (double2*)out, npix, ndata);
   PXM_HIP(hipGetLastError());
@@ -479,9 +480,10 @@ int pxm_wl_mask_gather(const void* f, const int64_t* idx, const double* w, void*
 
 int pxm_wl_mask_scatter(const void* g, const int64_t* idx, const double* w, void* f, int64_t npix, int64_t ndata, int C,
                         pxm_stream_t stream) {
-  PXM_REQUIRE(C >= 1 && g && idx && f && ndata >= 0 && npix >= ndata, "pxm_wl_mask_scatter: bad arguments");
+  PXM_REQUIRE(C >= 1 && f && ndata >= 0 && npix >= ndata, "pxm_wl_mask_scatter: bad arguments");
   PXM_HIP(hipMemsetAsync(f, 0, (size_t)C * npix * 16, (hipStream_t)stream));
-  if (ndata == 0) return 0;
+  if (ndata == 0) return 0;  // everything masked: the image is zero
+  PXM_REQUIRE(g && idx, "pxm_wl_mask_scatter: null buffer");
   hipLaunchKernelGGL(k_wl_scatter, ew_grid(ndata, C), dim3(256), 0, (hipStream_t)stream, (const double2*)g, idx, w,
                      (double2*)f, npix, ndata);
   PXM_HIP(hipGetLastError());

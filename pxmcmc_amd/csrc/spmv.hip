@@ -62,11 +62,12 @@ using namespace pxm;
 extern "C" int pxm_csr_matvec(const int64_t* indptr, const int32_t* indices, const void* vals, int vals_complex,
                               int64_t nrows, int64_t ncols, const void* x, void* y, int C, int dtype,
                               pxm_stream_t stream) {
-  PXM_REQUIRE(indptr && x && y && nrows >= 0 && ncols >= 0 && C >= 1, "pxm_csr_matvec: bad arguments");
+  PXM_REQUIRE(indptr && nrows >= 0 && ncols >= 0 && C >= 1, "pxm_csr_matvec: bad arguments");
+  if (nrows == 0) return 0;  // no paths: nothing to write
+  PXM_REQUIRE(y && (x || ncols == 0), "pxm_csr_matvec: null vector");
   PXM_REQUIRE(dtype == 0 || dtype == 1, "pxm_csr_matvec: dtype must be 0 (float64) or 1 (complex128)");
   PXM_REQUIRE(!(vals_complex && dtype == 0), "pxm_csr_matvec: a complex matrix needs complex vectors");
   PXM_REQUIRE(pxm_device_count() > 0, "pxm_csr_matvec: no HIP device visible (the HIP path is the only path)");
-  if (nrows == 0) return 0;
   const int waves_per_block = 4;
   int64_t blocks = (nrows + waves_per_block - 1) / waves_per_block;
   if (blocks > 16384) blocks = 16384;

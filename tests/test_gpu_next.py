@@ -132,3 +132,12 @@ def test_pathintegral_operator_myula_matches_oracle(setting):
     np.testing.assert_allclose(s.chain, out["chain"], rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(s.logPi, np.real(out["logPi"]), rtol=1e-9)
     np.testing.assert_allclose(s.priors, out["priors"], rtol=1e-10)
+
+
+def test_error_paths_and_empty_inputs():
+    """C-ABI misuse returns error codes (PxmError), never a fault; empty measurements are legal."""
+    import os
+    import runpy
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runpy.run_path(os.path.join(root, "scripts", "check_errors.py"), run_name="__main__")
