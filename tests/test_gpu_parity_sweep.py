@@ -28,3 +28,14 @@ def test_fused_paths_equal_unfused_kernels_random_sizes():
 
     ntot, nfail = fuzz_fused.main(ncase=25, seed=1)
     assert ntot == 25 and nfail == 0
+
+
+@pytest.mark.parametrize("script", ["check_pxmala_chains.py", "check_complex_params.py", "check_many_chains.py"])
+def test_check_scripts(script):
+    """check_pxmala_chains: a PxMALA batch (per-chain delta, accept flag, Philox uniforms) equals its chains run alone,
+    identity and weak-lensing operators; check_complex_params: params.complex = True (complex noise) against the
+    oracle and across engines; check_many_chains: batches wider than one GEMM column group."""
+    import runpy
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runpy.run_path(os.path.join(root, "scripts", script), run_name="__main__")
