@@ -4,7 +4,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-serial}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export PXM_NO_SIDE_STREAMS=1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-layout-compare > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv,glob
 f=sorted(glob.glob("$OUT/*/*_kernel_stats.csv"))[-1]
