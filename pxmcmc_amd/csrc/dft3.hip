@@ -316,11 +316,19 @@ __device__ __forceinline__ void ring2px_body(const Dft3Args& a, double* __restri
     if (j < n) z[p] = stage[(trs * n + j) * (R + 1) + r];
   }
   __syncthreads();
-  bluestein_w<P, DUAL ? BW_DUAL : BW_HALF>(z, mat, c, h, a);
   const bool act = ch < C && tv;
-  if (!RING_OUT && !act) return;
   const int64_t e0 = out.ring0 + (int64_t)t * n + rowb * N1 + c;  // element of q = 0; q advances by N1
   const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
+  // the current state of the lane's elements is fetched BEFORE the transform: its latency hides behind the FFTs
+  // (the thresholds too would cost 16 more registers: 256 VGPR + spills, measured slower)
+  double2 xpre[H];
+#pragma unroll
+  for (int q = 0; q < H; ++q) {
+    const bool ok = act && out.X && (q + rowb) * N1 + c < n;
+    xpre[q] = ok ? reinterpret_cast<const double2*>(out.X)[ce0 + (int64_t)q * N1] : double2{0.0, 0.0};
+  }
+  bluestein_w<P, DUAL ? BW_DUAL : BW_HALF>(z, mat, c, h, a);
+  if (!RING_OUT && !act) return;
   double2 zn[H];  // the ring as written to out.f (RING_OUT: input of the forward transform)
 #pragma unroll
   for (int q = 0; q < H; ++q) zn[q] = double2{0.0, 0.0};
@@ -336,7 +344,7 @@ __device__ __forceinline__ void ring2px_body(const Dft3Args& a, double* __restri
         const int q = g0 + u;
         const bool ok = (q + rowb) * N1 + c < n;
         const int64_t off = (int64_t)q * N1;
-        xs[u] = ok ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
+        xs[u] = xpre[q];
         Ts[u] = (ok && out.T) ? out.T[e0 + off] : out.T_scalar;
         wn[u] = (ok && out.noise) ? px_noise_load(out, ch, e0 + off) : double2{0.0, 0.0};
       }
