@@ -165,6 +165,8 @@ def main():
     torch.cuda.synchronize()
     ms, nl, nb, nf = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
     lib.pxm_profile_read(ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(nb), ctypes.byref(nf))
+    dms, dnl, dnb = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    lib.pxm_profile_read_dft(ctypes.byref(dms), ctypes.byref(dnl), ctypes.byref(dnb))
     lib.pxm_profile_enable(0)
     X, preds = sampler._engine_state()
     assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
@@ -242,6 +244,18 @@ def main():
                 "mfma_frac_of_spec": nf.value / (ms.value * 1e-3) / 78.6e12 if ms.value > 0 else 0.0,
             },
         }
+        if dnl.value > 0 and dms.value > 0:
+            # second kernel of the iteration, the larger share of its time: the grouped phi-DFT + prox + update + Philox
+            # kernel is bound by fp64 VALU issue (Bluestein butterflies), not by HBM -- reported for completeness
+            out["dft_kernel"] = {
+                "kernel": "k_ring2px_group (rings -> X' -> rings of every wavelet scale, one grid)",
+                "bound": "fp64 VALU issue (2 waves per SIMD by registers)",
+                "avg_launch_us": dms.value * 1e3 / dnl.value,
+                "launches": int(dnl.value),
+                "alg_bytes_per_launch": dnb.value / dnl.value,
+                "achieved_GBs": dnb.value / (dms.value * 1e-3) / 1e9,
+                "hbm_frac": dnb.value / (dms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            }
         if not args.no_cpu_baseline:
             T = reg.T
             v, secs = cpu_baseline(data, T, args.cpu_iters, delta)

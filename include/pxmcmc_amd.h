@@ -46,6 +46,8 @@ int pxm_device_count(void);
  * moved and the MFMA flops they executed (any pointer may be NULL), then resets. */
 int pxm_profile_enable(int on);
 int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes, double* gemm_flops);
+/* the same for the grouped phi-DFT launches of the ring-space step (k_ring2px_group) */
+int pxm_profile_read_dft(double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes);
 
 /* ---- device-resident iteration counter (HIP-graph replay of the MYULA step) -----------------
  * When a counter is registered, every Philox-consuming kernel uses iteration = iter + *counter, read

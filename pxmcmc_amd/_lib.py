@@ -26,6 +26,7 @@ SIGNATURES = {
     "pxm_device_count": (c_int, []),
     "pxm_profile_enable": (c_int, [c_int]),
     "pxm_profile_read": (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "pxm_profile_read_dft": (c_int, [c_vp, c_vp, c_vp]),
     "pxm_set_iter_counter": (c_int, [c_vp]),
     "pxm_iter_counter_add": (c_int, [c_u64, c_vp]),
     "pxm_j_max": (c_int, [c_int, c_dbl]),

@@ -23,6 +23,8 @@
 #include "update.h"
 #include "tw32.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <vector>
@@ -682,6 +684,7 @@ int dft3_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
     g.b0 = b0;
     b0 += g.nbx * g.nby;
     lds = std::max(lds, p.lds3);
+    out->px_elems += (double)p.L * p.n;
     v.push_back(g);
   }
   out->n = (int)v.size();
@@ -705,8 +708,13 @@ void dft3_group_destroy(Dft3GroupList* g) {
 }
 
 int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
-  hipLaunchKernelGGL(k_ring2px_group, dim3(g.blocks), dim3(256), g.lds, st, reinterpret_cast<const Dft3Group*>(g.d), g.n, ws,
-                     ncol, out, C);
+  // algorithmic bytes: rings read + written (16 B per slot and coefficient, every padded slot), state read, new state
+  // written (live slots), thresholds read once
+  const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
+  hipEvent_t ev0, ev1;
+  profile_dft_events(&ev0, &ev1, bytes);
+  hipExtLaunchKernelGGL(k_ring2px_group, dim3(g.blocks), dim3(256), g.lds, st, ev0, ev1, 0,
+                        reinterpret_cast<const Dft3Group*>(g.d), g.n, ws, ncol, out, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }

@@ -132,6 +132,7 @@ inline double gemm_alg_bytes(int L, bool paired, int C, int el_lo = 0) {
 }
 
 int gemm_rows_per_task(int ncol);
+void profile_dft_events(hipEvent_t* start, hipEvent_t* stop, double alg_bytes);  // live profiler, grouped DFT launches
 
 // ---- DFT stage ---------------------------------------------------------------
 struct DftPlan {
@@ -193,6 +194,7 @@ struct Dft3GroupList {
   void* d = nullptr;  // device array of per-scale descriptors
   int n = 0, blocks = 0;
   size_t lds = 0;
+  double px_elems = 0;  // sum over scales of bl (2 bl - 1): coefficients per chain slot
 };
 int dft3_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
                       const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available

@@ -212,7 +212,44 @@ static void profile_gemm_events(hipEvent_t* start, hipEvent_t* stop, double alg_
   g_prof_flops += flops;
   ++g_prof_used;
 }
+// second pool: the grouped DFT launches of the ring-space step (dft3.hip)
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_dprof_pool;
+static size_t g_dprof_used = 0;
+static double g_dprof_bytes = 0;
+void profile_dft_events(hipEvent_t* start, hipEvent_t* stop, double alg_bytes) {
+  *start = *stop = nullptr;
+  if (!g_prof_on || g_dprof_used >= g_dprof_pool.size()) return;
+  *start = g_dprof_pool[g_dprof_used].first;
+  *stop = g_dprof_pool[g_dprof_used].second;
+  g_dprof_bytes += alg_bytes;
+  ++g_dprof_used;
+}
+int profile_read_dft(double* ms, int64_t* launches, double* bytes) {
+  double tot = 0;
+  for (size_t i = 0; i < g_dprof_used; ++i) {
+    PXM_HIP(hipEventSynchronize(g_dprof_pool[i].second));
+    float t = 0;
+    PXM_HIP(hipEventElapsedTime(&t, g_dprof_pool[i].first, g_dprof_pool[i].second));
+    tot += t;
+  }
+  if (ms) *ms = tot;
+  if (launches) *launches = (int64_t)g_dprof_used;
+  if (bytes) *bytes = g_dprof_bytes;
+  g_dprof_used = 0;
+  g_dprof_bytes = 0;
+  return 0;
+}
+
 int profile_enable(int on) {
+  if (on && g_dprof_pool.empty()) {
+    g_dprof_pool.resize(4096);
+    for (auto& pr : g_dprof_pool) {
+      PXM_HIP(hipEventCreate(&pr.first));
+      PXM_HIP(hipEventCreate(&pr.second));
+    }
+  }
+  g_dprof_used = 0;
+  g_dprof_bytes = 0;
   if (on && g_prof_pool.empty()) {
     g_prof_pool.resize(16384);
     for (auto& pr : g_prof_pool) {
@@ -419,6 +456,9 @@ extern "C" {
 int pxm_profile_enable(int on) { return pxm::profile_enable(on); }
 int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes, double* gemm_flops) {
   return pxm::profile_read(gemm_ms, gemm_launches, gemm_alg_bytes, gemm_flops);
+}
+int pxm_profile_read_dft(double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes) {
+  return pxm::profile_read_dft(dft_ms, dft_launches, dft_alg_bytes);
 }
 }
 namespace pxm {
