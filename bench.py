@@ -177,7 +177,7 @@ def main():
     # informative side figure (rank 0, outside the timed region): the same iteration with one complex128 slot
     # per chain, i.e. the reference's state layout without the real-pair packing
     ref_layout_rate = None
-    if rank == 0 and eng["pairs"] and not args.no_layout_compare:
+    if rank == 0 and world == 1 and eng["pairs"] and not args.no_layout_compare:
         sampler._engine_stop()
         s2 = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain, real_pairs=False)
         s2._prepare()
@@ -256,7 +256,7 @@ def main():
                 "achieved_GBs": dnb.value / (dms.value * 1e-3) / 1e9,
                 "hbm_frac": dnb.value / (dms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
             }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             T = reg.T
             v, secs = cpu_baseline(data, T, args.cpu_iters, delta)
             out["cpu_baseline"] = {
