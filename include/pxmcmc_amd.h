@@ -118,6 +118,20 @@ int pxm_wav_gradg_step(pxm_wav_plan_t plan, const void* X, const void* preds, co
                        uint64_t seed, uint64_t chain0, uint64_t iter, void* X_out, int C,
                        pxm_stream_t stream);
 
+/* The whole loop body pxmcmc/mcmc.py:158-161 for the identity measurement and a DIAGONAL (per-pixel) inverse
+ * covariance: pxm_wav_gradg_step followed by pxm_wav_synthesis of the new state, fused.  The rings of the
+ * residual invcov .* (preds - data) (pxmcmc/forward.py:66-69) are carried inside the plan between calls:
+ *   pxm_wav_image_init : residual rings of the start state's preds                      (start of a run)
+ *   pxm_wav_image_step : X_out = MYULA update of X (as pxm_wav_gradg_step); preds_out = forward(X_out);
+ *                        residual rings <- those of preds_out.  Any other call on the plan invalidates the
+ *                        carried rings (call pxm_wav_image_init again). */
+int pxm_wav_image_init(pxm_wav_plan_t plan, const void* preds, const void* data, const void* invcov,
+                       int invcov_complex, int C, pxm_stream_t stream);
+int pxm_wav_image_step(pxm_wav_plan_t plan, const void* X, const void* data, const void* invcov,
+                       int invcov_complex, const double* T, double T_scalar, double delta, double lmda,
+                       const void* noise, int mode, uint64_t seed, uint64_t chain0, uint64_t iter,
+                       void* X_out, void* preds_out, int C, pxm_stream_t stream);
+
 /* Ring-space MYULA iteration: identity measurement + UNIFORM inverse covariance w (complex scalar), i.e.
  * ForwardOperator(data, scalar sig_d, "synthesis", SphericalWaveletTransform, Identity).  Between
  * forward() and calc_gradg() the reference forms the image-space residual w (preds - data)

@@ -53,6 +53,11 @@ SIGNATURES = {
         c_int,
         [c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_int, c_vp],
     ),
+    "pxm_wav_image_init": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_vp]),
+    "pxm_wav_image_step": (
+        c_int,
+        [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_dbl, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_vp, c_int, c_vp],
+    ),
     "pxm_wav_ring_set_data": (c_int, [c_vp, c_vp, c_vp]),
     "pxm_wav_ring_init": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "pxm_wav_ring_step": (

@@ -371,8 +371,17 @@ __device__ __forceinline__ void ring2px_body(const Dft3Args& a, double* __restri
       if (p >= n) continue;
       double2 y = cmul(z[q], a.chirp[p]);
       y.y = -y.y;
-      zn[q] = y;
       reinterpret_cast<double2*>(out.f)[ce0 + (int64_t)q * N1] = y;
+      if (RING_OUT && out.rdata) {  // residual invcov .* (image - data) goes back to the rings
+        const int64_t e = e0 + (int64_t)q * N1;
+        y = csub(y, reinterpret_cast<const double2*>(out.rdata)[e]);
+        if (out.rinvcov_complex) y = cmul(reinterpret_cast<const double2*>(out.rinvcov)[e], y);
+        else {
+          const double wt = out.rinvcov[e];
+          y = double2{wt * y.x, wt * y.y};
+        }
+      }
+      zn[q] = y;
     }
   }
   if (!RING_OUT) return;

@@ -721,6 +721,78 @@ int pxm_wav_gradg_step(pxm_wav_plan_t p, const void* X, const void* preds, const
   return wav_synthesis_adjoint_impl(p, in, out, C, (hipStream_t)stream);
 }
 
+// Whole MYULA iteration for a DIAGONAL (per-pixel) inverse covariance (pxm_wav_gradg_step + pxm_wav_synthesis
+// fused).  The rings of the residual invcov .* (preds - data) are carried inside the plan between calls:
+//   pxm_wav_image_init : residual rings <- DFT(invcov .* (preds - data))            (start of a run)
+//   pxm_wav_image_step : X_out = MYULA update of X; preds_out = forward(X_out); residual rings of preds_out.
+// Per step: inverse-adjoint + forward-adjoint GEMMs, the grouped rings -> X' -> rings launch of every scale,
+// forward + inverse GEMMs and ONE rings -> image -> residual -> rings kernel at L.
+static void image_residual(PxOut& po, const void* data, const void* invcov, int invcov_complex) {
+  po.rdata = (const double*)data;
+  po.rinvcov = (const double*)invcov;
+  po.rinvcov_complex = invcov_complex;
+}
+
+int pxm_wav_image_init(pxm_wav_plan_t p, const void* preds, const void* data, const void* invcov, int invcov_complex,
+                       int C, pxm_stream_t stream) {
+  int rc = wav_check(p, preds, preds, C, "pxm_wav_image_init");
+  if (rc) return rc;
+  PXM_REQUIRE(data && invcov, "pxm_wav_image_init: null argument");
+  PxIn in;
+  in.f = (const double*)preds;
+  in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  in.data = (const double*)data;
+  in.invcov = (const double*)invcov;
+  in.invcov_complex = invcov_complex;
+  return launch_px2ring(p->dftL, in, p->ws + p->offGL, p->ncol, C, (hipStream_t)stream);
+}
+
+int pxm_wav_image_step(pxm_wav_plan_t p, const void* X, const void* data, const void* invcov, int invcov_complex,
+                       const double* T, double T_scalar, double delta, double lmda, const void* noise, int mode,
+                       uint64_t seed, uint64_t chain0, uint64_t iter, void* X_out, void* preds_out, int C,
+                       pxm_stream_t stream) {
+  int rc = wav_check(p, X, X_out, C, "pxm_wav_image_step");
+  if (rc) return rc;
+  PXM_REQUIRE(data && invcov && preds_out, "pxm_wav_image_step: null argument");
+  PXM_REQUIRE(X != X_out, "pxm_wav_image_step: X_out must not alias X");
+  PXM_REQUIRE(mode >= 0 && mode <= 2, "pxm_wav_image_step: mode must be 0, 1 or 2");
+  hipStream_t st = (hipStream_t)stream;
+  PxOut out;
+  out.f = (double*)X_out;
+  out.X = (const double*)X;
+  out.T = T;
+  out.T_scalar = T_scalar;
+  out.delta = delta;
+  out.lmda = lmda;
+  out.noise = (const double*)noise;
+  out.mode = mode;
+  out.seed = seed;
+  out.chain0 = chain0;
+  out.iter = iter;
+  out.iter_dev = iter_counter();
+  if ((rc = run_tasks(p->adj_invadj, p->ws, p->ws, p->ncol, C, st))) return rc;          // residual rings -> H_L
+  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;          // -> rings of every scale
+  if (wav_can_fuse_dft(p)) {
+    if ((rc = wav_rings_update_rings(p, out, C, st))) return rc;                         // X' and its rings
+  } else {
+    if ((rc = wav_rings_to_blocks(p, out, C, st))) return rc;
+    if ((rc = wav_blocks_to_rings(p, X_out, C, st))) return rc;
+  }
+  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
+  if ((rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st))) return rc;             // rings of S X'
+  PxOut po;
+  po.f = (double*)preds_out;
+  po.chain_stride = (int64_t)p->L * (2 * p->L - 1);
+  if (dft_can_fuse(p->dftL) && !getenv("PXM_NO_FUSED_DFT")) {  // rings -> preds -> residual -> rings, one kernel
+    image_residual(po, data, invcov, invcov_complex);
+    rc = launch_ring2px2ring(p->dftL, p->ws + p->offGL, p->ncol, po, C, st);
+    return rc < 0 ? rc : (rc ? -1 : 0);
+  }
+  if ((rc = launch_ring2px(p->dftL, p->ws + p->offGL, p->ncol, po, C, st))) return rc;
+  return pxm_wav_image_init(p, preds_out, data, invcov, invcov_complex, C, stream);
+}
+
 // ---- ring-space MYULA step (identity measurement, uniform inverse covariance) -------------------------
 }  // extern "C"
 namespace pxm {

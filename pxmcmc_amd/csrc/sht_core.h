@@ -181,6 +181,11 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
   int mode = 0;  // update.h: 0 complex state + real noise, 1 + complex noise, 2 two real chains per slot
   uint64_t seed = 0, chain0 = 0, iter = 0;
   const uint64_t* iter_dev = nullptr;  // optional device-resident addend to iter (graph replay)
+  // residual mode of the fused rings -> image -> rings kernel (X == null): the image is written to f and the rings
+  // of rinvcov .* (image - rdata) go back in place (pxmcmc/forward.py:66-69 between forward() and calc_gradg())
+  const double* rdata = nullptr;    // [P] complex, shared by all chains
+  const double* rinvcov = nullptr;  // [P] real or complex
+  int rinvcov_complex = 0;
 };
 const uint64_t* iter_counter();  // registered by pxm_set_iter_counter, or null
 

@@ -361,10 +361,12 @@ class MYULA(PxMCMC):
                 plan.ring_step(src, w, self.prior.T_dev, float(self.delta), self.lmda, out=dst, **kw)
                 eng["P_valid"] = False
         else:
+            plan.image_init(eng["P"], data, f.invcov.diag)  # residual rings of the start state, carried by the plan
+
             def one(src, dst):
-                plan.gradg_step(src, eng["P"], *args, out=dst, **kw)   # calc_gradg + proxf + chain_step
+                # calc_gradg + proxf + chain_step + forward of the new state (preds written in place)
+                plan.image_step(src, *args, out=dst, preds_out=eng["P"], **kw)
                 eng["cnt"].add(1)
-                plan.synthesis(dst, out=eng["P"])                       # forward model of the new state
 
         eng["one"] = one
         eng["graph"] = None
@@ -382,6 +384,8 @@ class MYULA(PxMCMC):
                 eng["cnt"].set(eng["cnt0"](i0))
                 if eng["ring"]:
                     plan.ring_init(eng["XA"])
+                else:
+                    plan.image_init(eng["P"], data, f.invcov.diag)
                 g = torch.cuda.CUDAGraph()
                 # no garbage collection while capturing: a collected plan / graph of an earlier run would
                 # call hipFree / hipStreamDestroy in the middle of the capture
@@ -405,6 +409,8 @@ class MYULA(PxMCMC):
                 eng["cnt"].set(eng["cnt0"](i0))
                 if eng["ring"]:
                     plan.ring_init(eng["XA"])
+                else:
+                    plan.image_init(eng["P"], data, f.invcov.diag)
         return eng
 
     def _engine_advance(self, k):

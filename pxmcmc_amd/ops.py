@@ -375,6 +375,47 @@ class WavPlan:
         )
         return out[0] if squeeze else out
 
+    # ---- fused iteration for a diagonal inverse covariance (residual rings carried inside the plan) ----
+    def _image_args(self, data, invcov):
+        d = as_device(data, _CPLX).reshape(-1)
+        ic = as_device(invcov).reshape(-1)
+        if d.numel() != self.npix or ic.numel() != self.npix:
+            raise ValueError("data / invcov length mismatch")
+        return d, ic
+
+    def image_init(self, preds, data, invcov):
+        p, _ = _batched(as_device(preds, _CPLX))
+        if p.shape[1] != self.npix or p.shape[0] > self.max_chains:
+            raise AssertionError("image_init: shape mismatch")
+        d, ic = self._image_args(data, invcov)
+        check(lib.pxm_wav_image_init(self._h, _p(p), _p(d), _p(ic), int(ic.is_complex()), p.shape[0], _stream()))
+
+    def image_step(self, X, data, invcov, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0,
+                   out=None, preds_out=None, pairs=False):
+        """calc_gradg + proxf + chain_step + forward of the new state; the residual rings of the current state come
+        from the previous ``image_step`` / ``image_init`` on this plan."""
+        x, squeeze = _batched(as_device(X, _CPLX))
+        if x.shape[1] != self.ncoefs or x.shape[0] > self.max_chains:
+            raise AssertionError("image_step: shape mismatch")
+        d, ic = self._image_args(data, invcov)
+        Tv, Ts = _vecT(T, self.ncoefs, x.device)
+        w, wc = _pair_noise_args(noise, x) if pairs else _noise_args(noise, x, noise_complex)
+        if out is None:
+            out = torch.empty_like(x)
+        elif out.shape != x.shape or out.dtype != _CPLX or not out.is_contiguous() or out.data_ptr() == x.data_ptr():
+            raise ValueError("out= buffer must be a distinct contiguous complex128 tensor of the state's shape")
+        if preds_out is None:
+            preds_out = torch.empty((x.shape[0], self.npix), dtype=_CPLX, device=x.device)
+        elif preds_out.shape != (x.shape[0], self.npix) or preds_out.dtype != _CPLX or not preds_out.is_contiguous():
+            raise ValueError("preds_out= buffer has the wrong shape / dtype / layout")
+        check(
+            lib.pxm_wav_image_step(
+                self._h, _p(x), _p(d), _p(ic), int(ic.is_complex()), _p(Tv), Ts, float(delta), float(lmda),
+                _p(w), wc, seed, chain0, it, _p(out), _p(preds_out), x.shape[0], _stream(),
+            )
+        )
+        return (out[0], preds_out[0]) if squeeze else (out, preds_out)
+
     # ---- ring-space MYULA step (identity measurement + uniform inverse covariance) ----
     def ring_set_data(self, data):
         d = as_device(data, _CPLX).reshape(-1)
