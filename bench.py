@@ -88,8 +88,8 @@ def cpu_baseline(data, T, n_iter, delta):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=48)
     ap.add_argument("--no-real-pairs", action="store_true", help="one complex128 slot per chain (reference layout)")
