@@ -306,6 +306,8 @@ struct pxm_wav_plan_s {
   bool have_data_rings = false;
   int64_t offHA = 0, offHB = 0;  // L-layout class buffers of the fused combine (disjoint l-supports per class)
   bool fused_combine = true;
+  bool fused_dft = true;        // PXM_NO_FUSED_DFT=1 (read once at plan creation): separate DFT kernels
+  bool dft_small_first = true;  // PXM_DFT_TOP_FIRST=1: non-grouped launch order
   static bool fused_combine_env_ok() { return !getenv("PXM_NO_FUSED_COMBINE") && !getenv("PXM_NO_GRAM"); }
   double* d_kc_syn = nullptr;  // [nsc][Rp]  c_s * kappa   (synthesis and its adjoint)
   double* d_kc_ana = nullptr;  // [nsc][Rp]  c_a * kappa   (analysis and its adjoint)
@@ -376,6 +378,8 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   p->offHA = w; w += arr_size(L, p->ncol);
   p->offHB = w; w += arr_size(L, p->ncol);
   p->fused_combine = !getenv("PXM_NO_FUSED_COMBINE");
+  p->fused_dft = !getenv("PXM_NO_FUSED_DFT");
+  p->dft_small_first = !getenv("PXM_DFT_TOP_FIRST");
   for (int s = 0; s < p->nsc; ++s) {
     p->offG.push_back(w); w += arr_size(p->bl[s], p->ncol);
     p->offH.push_back(w); w += arr_size(p->bl[s], p->ncol);
@@ -399,13 +403,15 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   PXM_HIP(hipMemcpy(p->d_kc_syn, kc_syn.data(), kc_syn.size() * sizeof(double), hipMemcpyHostToDevice));
   PXM_HIP(hipMemcpy(p->d_kc_ana, kc_ana.data(), kc_ana.size() * sizeof(double), hipMemcpyHostToDevice));
   // support cut per scale: first degree with a non-zero kernel (compact support of kappa_j)
-  std::vector<int> el_lo(p->nsc, 0);
-  if (!getenv("PXM_NO_SUPPORT_CUT"))
-    for (int s = 0; s < p->nsc; ++s) {
-      int lo = 0;
-      while (lo < p->bl[s] && kc_syn[(size_t)s * p->Rp + lo] == 0.0) ++lo;
-      el_lo[s] = lo;
-    }
+  // sup_lo: the support itself (row masks of the fused combine: class buffers are shared by scales with disjoint
+  // supports); el_lo: the rows / contraction steps actually skipped (PXM_NO_SUPPORT_CUT=1: none, for A/B timing)
+  std::vector<int> el_lo(p->nsc, 0), sup_lo(p->nsc, 0);
+  for (int s = 0; s < p->nsc; ++s) {
+    int lo = 0;
+    while (lo < p->bl[s] && kc_syn[(size_t)s * p->Rp + lo] == 0.0) ++lo;
+    sup_lo[s] = lo;
+    if (!getenv("PXM_NO_SUPPORT_CUT")) el_lo[s] = lo;
+  }
   // task lists
   std::vector<GemmTask> v_syn_fwd, v_adj_fwdadj, v_ana_inv, v_anadj_invadj, v;
   // The two finest scales usually share the bandlimit L (bl = min(ceil(B^(j+1)), L)) and therefore the table:
@@ -425,7 +431,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
     switch (which) {
       case 0:  // synthesis: G_s --A_s--> c_s kappa_s(l) * (...) written straight into the class buffer in L layout
         g.x_base = p->offG[s]; g.x_L = b; g.x_Rp = Rb;
-        g.fuse.row_lo = el_lo[s]; g.fuse.row_hi = b;
+        g.fuse.row_lo = sup_lo[s]; g.fuse.row_hi = b;
         if (p->fused_combine) { g.y_base = hcls; g.y_L = L; g.y_Rp = p->Rp; g.fuse.rscale = p->d_kc_syn + (size_t)s * p->Rp; }
         else { g.y_base = p->offH[s]; g.y_L = b; g.y_Rp = Rb; g.fuse = GemmFuse(); }
         break;
@@ -439,7 +445,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
         break;
       default:  // analysis adjoint: G_s --B_s^T--> class buffer (or H_s)
         g.x_base = p->offG[s]; g.x_L = b; g.x_Rp = Rb;
-        g.fuse.row_lo = el_lo[s]; g.fuse.row_hi = b;
+        g.fuse.row_lo = sup_lo[s]; g.fuse.row_hi = b;
         if (p->fused_combine) { g.y_base = hcls; g.y_L = L; g.y_Rp = p->Rp; g.fuse.rscale = p->d_kc_ana + (size_t)s * p->Rp; }
         else { g.y_base = p->offH[s]; g.y_L = b; g.y_Rp = Rb; g.fuse = GemmFuse(); }
         break;
@@ -627,7 +633,7 @@ static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t
 // G_s -> coefficient blocks (with out's epilogue) and, in the same kernels, the rings of the written blocks
 // back into G_s.  Only when every scale has a fused kernel (wav_can_fuse_dft).
 static bool wav_can_fuse_dft(pxm_wav_plan_t p) {
-  if (getenv("PXM_NO_FUSED_DFT")) return false;
+  if (!p->fused_dft) return false;
   for (int s = 0; s < p->nsc; ++s)
     if (!dft_can_fuse(p->dft[s])) return false;
   return true;
@@ -643,7 +649,7 @@ static int wav_rings_update_rings(pxm_wav_plan_t p, PxOut proto, int C, hipStrea
   if (rc) return rc;
   // side-stream (small) scales are enqueued first: the full-size kernels fill every wave slot of the chip
   // (2 waves per SIMD by registers), so whatever is enqueued behind them only runs in their tail
-  const bool small_first = !getenv("PXM_DFT_TOP_FIRST");
+  const bool small_first = p->dft_small_first;
   for (int pass = 0; pass < 2; ++pass)
     for (int s = p->nsc - 1; s >= 0; --s) {
       const bool side = p->lane_of[s] >= 0;
@@ -784,7 +790,7 @@ int pxm_wav_image_step(pxm_wav_plan_t p, const void* X, const void* data, const 
   PxOut po;
   po.f = (double*)preds_out;
   po.chain_stride = (int64_t)p->L * (2 * p->L - 1);
-  if (dft_can_fuse(p->dftL) && !getenv("PXM_NO_FUSED_DFT")) {  // rings -> preds -> residual -> rings, one kernel
+  if (p->dftL.use3 && p->fused_dft) {  // (only the wave path implements the residual epilogue)  // rings -> preds -> residual -> rings, one kernel
     image_residual(po, data, invcov, invcov_complex);
     rc = launch_ring2px2ring(p->dftL, p->ws + p->offGL, p->ncol, po, C, st);
     return rc < 0 ? rc : (rc ? -1 : 0);
