@@ -33,7 +33,9 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------
 constexpr int KC = 16;  // contraction rows per staged chunk
 #ifndef PXM_GEMM_NSET
-#define PXM_GEMM_NSET 3  // table register sets: the table stream runs NSET-1 chunks (of 16 k) ahead
+#define PXM_GEMM_NSET 2  // table register sets: the table stream runs NSET-1 chunks (of 16 k) ahead.  2 sets = 64 VGPR at 32
+                         // columns = 8 waves per SIMD = 4 workgroups per CU: occupancy beats prefetch depth (3 sets: 76 VGPR, 3
+                         // workgroups, 8 % slower; 4 and 6 sets slower still)
 #endif
 
 // NW waves per workgroup, RT row tiles of 16 rows per wave: a task covers NW*RT row tiles.
