@@ -1,6 +1,5 @@
-N2=$GRAFT_REPO_ROOT/pxmcmc_amd/lib/libpxmcmc_amd_n2.so
 for rep in 1 2; do
-for v in "PXM_X=0" "PXM_LIB_PATH=$N2"; do
-  echo "== $v nopairs"; env $v python bench.py --no-cpu-baseline --no-layout-compare --no-real-pairs 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],4), round(d['roofline']['avg_launch_us'],1), round(d['roofline']['frac'],3), round(d['roofline']['mfma_tflops'],1))"
+for v in "PXM_X=0" "PXM_GEMM_GEOM=41" "PXM_GEMM_MERGE=1"; do
+  echo "== $v"; env $v python bench.py --no-cpu-baseline --no-layout-compare 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],4), round(d['roofline']['avg_launch_us'],1), round(d['roofline']['frac'],3), round(d['roofline']['mfma_tflops'],1))"
 done
 done
