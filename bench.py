@@ -64,23 +64,27 @@ def synthetic_field(plan_inverse, L, seed):
     return f / np.sqrt(np.mean(f ** 2)), rng
 
 
-def cpu_baseline(data, T, n_iter, delta):
-    """the oracle's literal MYULA iteration (one chain, numpy, this host) -- baseline only"""
+def cpu_baseline(data, T, n_iter, delta, threads=1):
+    """the oracle's literal MYULA iteration (one chain, numpy, this host) -- baseline only.  ``threads`` pins the BLAS /
+    OpenMP pools (threadpoolctl), so that the reported core count is the one actually used."""
+    from threadpoolctl import threadpool_limits
+
     from oracle import pxmcmc_np as ref
 
-    tr = ref.SphericalWaveletTransform(L, int(B), J_MIN)
-    P = data.size
-    op = ref.ForwardOperator(data, SIGMA, "synthesis", tr, ref.Identity(P, P), tr.ncoefs)
-    X = np.zeros(tr.ncoefs, dtype=complex)
-    preds = op.forward(X)
-    rng = np.random.default_rng(0)
-    t0 = time.perf_counter()
-    for _ in range(n_iter):
-        gradg = op.calc_gradg(preds)
-        px = ref.soft(X, T)
-        X = ref.chain_step(X, px, gradg, delta, LMDA, rng.normal(size=tr.ncoefs))
+    with threadpool_limits(limits=threads):
+        tr = ref.SphericalWaveletTransform(L, int(B), J_MIN)
+        P = data.size
+        op = ref.ForwardOperator(data, SIGMA, "synthesis", tr, ref.Identity(P, P), tr.ncoefs)
+        X = np.zeros(tr.ncoefs, dtype=complex)
         preds = op.forward(X)
-    dt = time.perf_counter() - t0
+        rng = np.random.default_rng(0)
+        t0 = time.perf_counter()
+        for _ in range(n_iter):
+            gradg = op.calc_gradg(preds)
+            px = ref.soft(X, T)
+            X = ref.chain_step(X, px, gradg, delta, LMDA, rng.normal(size=tr.ncoefs))
+            preds = op.forward(X)
+        dt = time.perf_counter() - t0
     assert np.isfinite(X).all()
     return n_iter / dt, dt
 
@@ -258,14 +262,19 @@ def main():
             }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
             T = reg.T
-            v, secs = cpu_baseline(data, T, args.cpu_iters, delta)
+            v, secs = cpu_baseline(data, T, args.cpu_iters, delta, threads=1)
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            v_all, secs_all = cpu_baseline(data, T, max(4, args.cpu_iters // 4), delta, threads=ncpu)
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "samples/s",
                 "cores": 1,
                 "kind": "port",
                 "sample": f"{args.cpu_iters} MYULA iterations of ONE chain at L=256 (oracle numpy restatement, "
-                          f"table+FFT SHT, {secs:.1f} s) on this host",
+                          f"table+FFT SHT, BLAS / OpenMP pools pinned to 1 thread, {secs:.1f} s) on this host",
+                "value_all_cores": v_all,
+                "cores_all": ncpu,
+                "sample_all_cores": f"{max(4, args.cpu_iters // 4)} iterations with the pools at {ncpu} threads ({secs_all:.1f} s)",
             }
         print(json.dumps(out), flush=True)
     if world > 1:
