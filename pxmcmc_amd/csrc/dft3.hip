@@ -277,6 +277,9 @@ __global__ __launch_bounds__(256, 2) void k_px2ring_w(Dft3Args a, PxIn in, doubl
 template <int P, bool DUAL, bool RING_OUT>
 __device__ __forceinline__ void ring2px_body(const Dft3Args& a, double* __restrict__ G, int ncol, const PxOut& out, int C,
                                              int bx, int by, double2* lds3) {
+  // chain groups without a live chain do nothing: their (padding) slots hold zero rings from plan creation on, or
+  // stale finite values of an earlier, wider batch -- the GEMM columns are independent, nothing reads them
+  if (by * a.R >= C) return;
   PXM_W_GEOMETRY
   (void)LPR;
   {
@@ -654,8 +657,6 @@ static int ring2px_p(const DftPlan& p, const double* G, int ncol, const PxOut& o
   const int rings = p.TR3 * (DUAL ? 2 : 1);
   dim3 grid((p.L + rings - 1) / rings, (C + p.R3 - 1) / p.R3), block(256);
   if (ring_out) {
-    // every chain group must run: padded chains get zero rings written back
-    grid.y = (ncol / 2 + p.R3 - 1) / p.R3;
     hipLaunchKernelGGL((k_ring2px_w<P, DUAL, true>), grid, block, p.lds3, st, dft3_args(p), const_cast<double*>(G), ncol, out, C);
   } else {
     hipLaunchKernelGGL((k_ring2px_w<P, DUAL, false>), grid, block, p.lds3, st, dft3_args(p), const_cast<double*>(G), ncol, out, C);
