@@ -64,29 +64,94 @@ def synthetic_field(plan_inverse, L, seed):
     return f / np.sqrt(np.mean(f ** 2)), rng
 
 
-def cpu_baseline(data, T, n_iter, delta, threads=1):
-    """the oracle's literal MYULA iteration (one chain, numpy, this host) -- baseline only.  ``threads`` pins the BLAS /
-    OpenMP pools (threadpoolctl), so that the reported core count is the one actually used."""
+_CPU = {}  # oracle operator of the CPU legs: built once in this process, inherited by forked workers
+
+
+def _cpu_operator(data):
+    from oracle import pxmcmc_np as ref
+
+    if "op" not in _CPU:
+        tr = ref.SphericalWaveletTransform(L, int(B), J_MIN)
+        P = data.size
+        _CPU["op"] = ref.ForwardOperator(data, SIGMA, "synthesis", tr, ref.Identity(P, P), tr.ncoefs)
+    return _CPU["op"]
+
+
+def _cpu_chain(args):
+    """n_iter literal MYULA iterations (pxmcmc/mcmc.py:158-161) of ONE chain with the oracle; returns seconds"""
     from threadpoolctl import threadpool_limits
 
     from oracle import pxmcmc_np as ref
 
-    with threadpool_limits(limits=threads):
-        tr = ref.SphericalWaveletTransform(L, int(B), J_MIN)
-        P = data.size
-        op = ref.ForwardOperator(data, SIGMA, "synthesis", tr, ref.Identity(P, P), tr.ncoefs)
-        X = np.zeros(tr.ncoefs, dtype=complex)
+    T, n_iter, delta, seed = args
+    op = _CPU["op"]
+    with threadpool_limits(limits=1):
+        X = np.zeros(op.nparams, dtype=complex)
         preds = op.forward(X)
-        rng = np.random.default_rng(0)
+        rng = np.random.default_rng(seed)
         t0 = time.perf_counter()
         for _ in range(n_iter):
             gradg = op.calc_gradg(preds)
             px = ref.soft(X, T)
-            X = ref.chain_step(X, px, gradg, delta, LMDA, rng.normal(size=tr.ncoefs))
+            X = ref.chain_step(X, px, gradg, delta, LMDA, rng.normal(size=op.nparams))
             preds = op.forward(X)
         dt = time.perf_counter() - t0
     assert np.isfinite(X).all()
-    return n_iter / dt, dt
+    return dt
+
+
+def cpu_baseline(data, T, n_iter, delta, procs=1):
+    """The oracle's literal MYULA iteration on this host -- baseline only.  ``procs`` == 1: one chain, BLAS / OpenMP
+    pools pinned to one thread.  ``procs`` > 1: one chain per PROCESS (the reference's own way to use cores:
+    ``--jobid``, experiments/earthtopography/main.py:31-36), forked from this process so the read-only tables are
+    shared; throughput = chain-iterations of all processes / wall time."""
+    _cpu_operator(data)
+    if procs == 1:
+        dt = _cpu_chain((T, n_iter, delta, 0))
+        return n_iter / dt, dt
+    import multiprocessing as mp
+
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(procs) as pool:  # (children only run numpy; they never touch the GPU runtime)
+        pool.map(_cpu_chain, [(T, n_iter, delta, k) for k in range(procs)])
+    wall = time.perf_counter() - t0
+    return procs * n_iter / wall, wall
+
+
+def parity_leg(plan, data, T_dev, T, delta, n_iter=3, chains=(0, 9), C=CHAINS_PER_GPU):
+    """Full-size parity on the box the benchmark runs on: n_iter iterations of the benchmarked step (ring-space +
+    Gram + real pairs) with injected noise against the oracle's literal loop on the same noise.  Returns the max
+    error relative to max |X|."""
+    import torch
+
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd import ops
+
+    op = _cpu_operator(data)
+    N = op.nparams
+    rng = np.random.default_rng(123)
+    X0 = rng.normal(size=(C, N)) * 1e-3
+    noise = rng.normal(size=(n_iter, C, N))
+    d = ops.as_device(data, torch.float64)
+    X = torch.complex(ops.as_device(X0[0::2]), ops.as_device(X0[1::2]))
+    out = torch.empty_like(X)
+    w = complex(1.0 / SIGMA ** 2)
+    plan.ring_set_data(torch.complex(d, d).contiguous())
+    plan.ring_init(X)
+    for k in range(n_iter):
+        plan.ring_step(X, w, T_dev, delta, LMDA, noise=ops.as_device(noise[k]), out=out, pairs=True)
+        X, out = out, X
+    Xg = X.cpu().numpy()
+    err = 0.0
+    for c in chains:
+        Xo = X0[c].astype(complex)
+        preds = op.forward(Xo)
+        for k in range(n_iter):
+            Xo = ref.chain_step(Xo, ref.soft(Xo, T), op.calc_gradg(preds), delta, LMDA, noise[k][c])
+            preds = op.forward(Xo)
+        got = Xg[c // 2].real if c % 2 == 0 else Xg[c // 2].imag
+        err = max(err, float(np.abs(got - Xo.real).max() / np.abs(Xo).max()))
+    return err
 
 
 def main():
@@ -94,8 +159,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--ramp", type=int, default=400, help="untimed iterations before the warm-up (clock ramp; declared in the JSON)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=48)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = min(cores, 16))")
     ap.add_argument("--no-real-pairs", action="store_true", help="one complex128 slot per chain (reference layout)")
     ap.add_argument("--no-layout-compare", action="store_true", help="skip the reference-layout side measurement")
     args = ap.parse_args()
@@ -121,7 +188,6 @@ def main():
         D.init(backend="nccl", device_id=torch.device("cuda", dev_index))
 
     from pxmcmc_amd import ops
-    from pxmcmc_amd._lib import lib
     from pxmcmc_amd.forward import SphericalWaveletTransformOperator
     from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
     from pxmcmc_amd.prior import S2_Wavelets_L1
@@ -151,27 +217,34 @@ def main():
     eng = sampler._engine_start(X, preds, 0)
     barrier = D.barrier
 
+    # Declared clock ramp: the driver's default run times 20 steps = 5 ms, shorter than the time the GPU takes to
+    # reach its sustained clocks from idle; --ramp untimed iterations precede the W warm-up steps (reported below).
+    sampler._engine_advance(args.ramp)
     sampler._engine_advance(args.warmup)
     barrier()
     t0 = time.perf_counter()
     sampler._engine_advance(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    # roofline leg: the same steps once more, launched eagerly so that every k_sht_gemm launch can be
-    # bracketed by HIP events on its stream (events cannot be read back from inside a graph replay)
-    import ctypes
-
+    # roofline leg: the same steps once more through the same engine, launched eagerly (no graph replay) so that
+    # every k_sht_gemm launch can be bracketed by HIP events on its stream (events cannot be read back from
+    # inside a graph replay)
     n_prof = min(args.steps, 100)
-    lib.pxm_profile_enable(1)
-    for _ in range(n_prof // 2):
-        eng["one"](eng["XA"], eng["XB"])
-        eng["one"](eng["XB"], eng["XA"])
+    plan = eng["plan"]
+    plan.profile_enable(3 * n_prof + 8)
+    graphs = eng["graph"], eng["graph_long"]
+    eng["graph"] = eng["graph_long"] = None
+    sampler._engine_advance(n_prof)
+    eng["graph"], eng["graph_long"] = graphs
     torch.cuda.synchronize()
-    ms, nl, nb, nf = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
-    lib.pxm_profile_read(ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(nb), ctypes.byref(nf))
-    dms, dnl, dnb = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    lib.pxm_profile_read_dft(ctypes.byref(dms), ctypes.byref(dnl), ctypes.byref(dnb))
-    lib.pxm_profile_enable(0)
+    (gms, gnl, gnb, gnf), (dms_, dnl_, dnb_) = plan.profile_read()
+    plan.profile_enable(0)
+
+    class _V:  # (keeps the field names of the report below)
+        def __init__(self, v):
+            self.value = v
+
+    ms, nl, nb, nf, dms, dnl, dnb = _V(gms), _V(gnl), _V(gnb), _V(gnf), _V(dms_), _V(dnl_), _V(dnb_)
     X, preds = sampler._engine_state()
     assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
 
@@ -188,7 +261,7 @@ def main():
         with contextlib.redirect_stdout(io.StringIO()):
             X2, P2 = s2._initial_sample(np.zeros(op.nparams))
         s2._engine_start(X2, P2, 0)
-        s2._engine_advance(args.warmup)
+        s2._engine_advance(args.ramp // 2 + args.warmup)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         s2._engine_advance(args.steps)
@@ -200,11 +273,12 @@ def main():
         value = world * C * args.steps / dt
         gemm_avg_us = ms.value * 1e3 / max(nl.value, 1)
         achieved = nb.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc):  # PMC counters need their own rocprofv3 passes: a committed, static figure
             with open(pmc) as fh:
                 traffic = json.load(fh).get("k_sht_gemm_hbm_bytes_per_launch")
+            traffic_src = "profiles/pmc_summary.json (static: rocprofv3 --pmc passes of this command, not measured in this run)"
         out = {
             "metric": "MYULA samples/sec at L=256 synthesis",
             "value": value,
@@ -230,6 +304,8 @@ def main():
                 "global_chains": world * C,
                 "parallelism": f"chains sharded over {world} GPU(s), no collective on the data path",
                 "hip_graph": used_graph,
+                "graph_iterations_per_replay": 2 * sampler._GRAPH_PAIRS if used_graph else 0,
+                "clock_ramp_steps": args.ramp,
             },
             "roofline": {
                 "bound": "hbm",
@@ -239,6 +315,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_us": gemm_avg_us,
                 "launches": int(nl.value),
                 "alg_bytes_per_launch": nb.value / max(nl.value, 1),
@@ -260,11 +337,20 @@ def main():
                 "achieved_GBs": dnb.value / (dms.value * 1e-3) / 1e9,
                 "hbm_frac": dnb.value / (dms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
             }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only
+        if not args.no_cpu_baseline and world == 1:  # the CPU legs run at N = 1 only
             T = reg.T
-            v, secs = cpu_baseline(data, T, args.cpu_iters, delta, threads=1)
+            # free full-size parity evidence on this box: the benchmarked step vs the oracle on the same noise
+            if eng["pairs"]:
+                out["parity"] = {
+                    "max_rel_err_X": parity_leg(plan, data, reg.T_dev, T, delta),
+                    "what": "3 iterations of the benchmarked step (ring-space + Gram + real pairs, injected noise) vs the "
+                            "oracle's literal loop, chains 0 and 9, error relative to max |X|",
+                }
+            v, secs = cpu_baseline(data, T, args.cpu_iters, delta, procs=1)
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            v_all, secs_all = cpu_baseline(data, T, max(4, args.cpu_iters // 4), delta, threads=ncpu)
+            procs = args.cpu_procs or min(ncpu, 16)
+            it_all = max(8, args.cpu_iters // 3)
+            v_all, secs_all = cpu_baseline(data, T, it_all, delta, procs=procs)
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "samples/s",
@@ -273,8 +359,10 @@ def main():
                 "sample": f"{args.cpu_iters} MYULA iterations of ONE chain at L=256 (oracle numpy restatement, "
                           f"table+FFT SHT, BLAS / OpenMP pools pinned to 1 thread, {secs:.1f} s) on this host",
                 "value_all_cores": v_all,
-                "cores_all": ncpu,
-                "sample_all_cores": f"{max(4, args.cpu_iters // 4)} iterations with the pools at {ncpu} threads ({secs_all:.1f} s)",
+                "cores_all": procs,
+                "sample_all_cores": f"{procs} independent chains, one single-threaded process each (the reference's --jobid "
+                                    f"model), {it_all} iterations per chain, {secs_all:.1f} s wall incl. process start; "
+                                    f"host reports {ncpu} usable cores",
             }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -12,6 +12,9 @@
  *   - device buffers are caller-owned; nothing is allocated after plan creation;
  *   - all device work is enqueued on the caller-supplied HIP stream (hipStream_t
  *     passed as void*); plans are not shared across threads or devices;
+ *   - all mutable state lives in a plan (workspace, carried rings, Philox iteration counter, profiler); the
+ *     only process-wide objects are the read-only per-device table cache (pxm_tables_trim), the borrowed side
+ *     streams and the graveyard of deferred frees below;
  *   - arrays carry a leading chain-batch dimension C (independent chains); inside
  *     a chain the reference's own 1-D orders are kept: harmonic index el^2+el+m,
  *     MW images theta-major (L, 2L-1) C-order, wavelet coefficient vectors
@@ -39,22 +42,18 @@ const char* pxm_last_error(void);
 /* number of visible HIP devices (0 when none; never fails) */
 int pxm_device_count(void);
 
-/* ---- live kernel timing (bench.py roofline leg) --------------------------------
- * When enabled, every launch of the SHT ring-GEMM kernel is bracketed by HIP events on the
- * stream it is launched on (kernel start / stop, as rocprofv3 reports them).  pxm_profile_read synchronises
- * those events and returns the summed kernel time (ms), the number of launches, the algorithmic bytes they
- * moved and the MFMA flops they executed (any pointer may be NULL), then resets. */
-int pxm_profile_enable(int on);
-int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes, double* gemm_flops);
-/* the same for the grouped phi-DFT launches of the ring-space step (k_ring2px_group) */
-int pxm_profile_read_dft(double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes);
-
-/* ---- device-resident iteration counter (HIP-graph replay of the MYULA step) -----------------
- * When a counter is registered, every Philox-consuming kernel uses iteration = iter + *counter, read
- * on the device at execution time, so a captured graph draws fresh noise at every replay.
- * pxm_iter_counter_add enqueues "*counter += inc" on the stream.  NULL unregisters. */
-int pxm_set_iter_counter(uint64_t* counter_dev);
-int pxm_iter_counter_add(uint64_t inc, pxm_stream_t stream);
+/* ---- teardown during stream capture ---------------------------------------------------------
+ * hipFree is illegal while a stream capture is in progress, and the host language may tear a plan down at any
+ * moment (Python's garbage collector).  The destroy calls therefore never free directly: device memory goes to
+ * a graveyard that is emptied at safe points (plan creation, pxm_capture_end, a destroy outside any capture).
+ * Bracket a capture with pxm_capture_begin / pxm_capture_end; a capture started elsewhere is also recognised
+ * as soon as one entry point has been called on its stream.  pxm_deferred_pending: entries still queued. */
+int pxm_capture_begin(void);
+int pxm_capture_end(void);
+int pxm_deferred_pending(void);
+/* The Wigner ring tables are cached per device and shared by plans; this frees every cache entry no live plan
+ * holds (returns the MiB released). */
+int pxm_tables_trim(void);
 
 /* ---- host-side setup helpers (no GPU needed) ------------------------------ */
 /* pys2let.pys2let_j_max(B, L, J_min)            (pxmcmc/transforms.py:75) */
@@ -95,6 +94,27 @@ int pxm_wav_synthesis_adjoint(pxm_wav_plan_t plan, const void* f, void* X, int C
 int pxm_wav_analysis(pxm_wav_plan_t plan, const void* f, void* X, int C, pxm_stream_t stream);
 int pxm_wav_analysis_adjoint(pxm_wav_plan_t plan, const void* X, void* f, int C, pxm_stream_t stream);
 int64_t pxm_wav_table_bytes(pxm_wav_plan_t plan, int op /*0 synthesis,1 synthesis_adjoint*/);
+
+/* Device-resident Philox iteration counter OF ONE PLAN (HIP-graph replay of the MYULA step): when registered,
+ * the plan's fused steps use iteration = iter + *counter, read on the device at execution time, so a captured
+ * graph draws fresh noise at every replay.  Two plans (two samplers) in one process never share a counter.
+ * pxm_wav_iter_counter_add enqueues "*counter += inc" on the stream.  NULL unregisters. */
+int pxm_wav_set_iter_counter(pxm_wav_plan_t plan, uint64_t* counter_dev);
+int pxm_wav_iter_counter_add(pxm_wav_plan_t plan, uint64_t inc, pxm_stream_t stream);
+
+/* Live kernel timing of one plan (bench.py roofline leg).  pxm_wav_profile_enable(plan, n) with n > 0 creates
+ * n event pairs per kernel class; while enabled every SHT ring-GEMM launch and every grouped phi-DFT launch of
+ * this plan is bracketed by a pair on the stream it is launched on (kernel start / stop, as rocprofv3 reports
+ * them).  The read calls synchronise the events and return the summed kernel time (ms), the number of
+ * launches, the algorithmic bytes moved and the MFMA flops (any pointer may be NULL), then reset.
+ * n = 0 disables and releases the events. */
+int pxm_wav_profile_enable(pxm_wav_plan_t plan, int max_launches);
+int pxm_wav_profile_read(pxm_wav_plan_t plan, double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes,
+                         double* gemm_flops);
+int pxm_wav_profile_read_dft(pxm_wav_plan_t plan, double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes);
+/* test aid: number of non-finite doubles in the plan's workspace (ring / harmonic arrays incl. the padding
+ * chains' columns); synchronises the stream */
+int64_t pxm_wav_workspace_nonfinite(pxm_wav_plan_t plan, pxm_stream_t stream);
 
 /* Fused MYULA half-steps (pxmcmc/mcmc.py:158-161 with forward.py:66-72, prior.py:49-50):
  *   pxm_wav_gradg_step: X_out = (1-d/l) X + (d/l) soft(X,T) - d * S^H( invcov .* (preds - data) ) + sqrt(2 d) w
@@ -142,7 +162,7 @@ int pxm_wav_image_step(pxm_wav_plan_t plan, const void* X, const void* data, con
  *   pxm_wav_ring_set_data : rings of the data image (once per data set)
  *   pxm_wav_ring_init     : rings <- S X                           (start of a run)
  *   pxm_wav_ring_step     : X_out = MYULA update of X (as pxm_wav_gradg_step); rings <- S X_out.
- *                           A registered iteration counter is advanced by 1 at the START of the step
+ *                           The plan's iteration counter, if registered, is advanced by 1 at the START of the step
  *                           (the step's Philox iteration = iter + counter after the increment).
  *   pxm_wav_ring_preds    : preds = forward(X) of the carried state, [C][L(2L-1)] */
 int pxm_wav_ring_set_data(pxm_wav_plan_t plan, const void* data, pxm_stream_t stream);
@@ -175,16 +195,19 @@ int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const do
 /* N(0,1) draws of the Philox4x32-10 stream keyed (seed, chain0+c, iter): out [C][n] (f64 or c128) */
 int pxm_randn(void* out, int64_t n, int C, int dtype, uint64_t seed, uint64_t chain0, uint64_t iter,
               pxm_stream_t stream);
+/* The reductions below are deterministic two-stage sums; `scratch` is a caller-owned device buffer of
+ * pxm_reduce_scratch_doubles(C) doubles (no library-owned buffer is shared between calls or streams). */
+int64_t pxm_reduce_scratch_doubles(int C);
 /* L1.prior / S2_Wavelets_L1.prior (pxmcmc/prior.py:28-35,83-84): out[c] = sum_i |w_i X_ci| */
-int pxm_reduce_l1(const void* X, const double* w, double* out, int64_t n, int C, int dtype,
+int pxm_reduce_l1(const void* X, const double* w, double* out, double* scratch, int64_t n, int C, int dtype,
                   pxm_stream_t stream);
 /* logpi's L2 = vdot(d, invcov d), d = data - preds (pxmcmc/mcmc.py:78-79): out[c] = (re, im) */
 int pxm_reduce_l2(const void* preds, const void* data, const void* invcov, int invcov_complex,
-                  double* out, int64_t n, int C, int dtype, pxm_stream_t stream);
+                  double* out, double* scratch, int64_t n, int C, int dtype, pxm_stream_t stream);
 /* PxMALA.calc_logtransition, literal (pxmcmc/mcmc.py:281-289): out[c] = (re, im) */
 int pxm_logtransition(const void* X1, const void* X2, const void* proxf, const void* gradg,
-                      const double* delta_dev, double delta, double lmda, double* out, int64_t n,
-                      int C, int dtype, pxm_stream_t stream);
+                      const double* delta_dev, double delta, double lmda, double* out, double* scratch,
+                      int64_t n, int C, int dtype, pxm_stream_t stream);
 /* Metropolis accept + state swap + delta adaptation for every chain (pxmcmc/mcmc.py:244-260,
  * 277-279).  logalpha_terms: [C][4] = (logtrans_pc, logpi_p, logtrans_cp, logpi_c) real parts.
  * For accepted chains copies prop -> curr for each of nbuf (buffer pairs, sizes in elements).

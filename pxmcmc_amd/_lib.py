@@ -24,11 +24,17 @@ SIGNATURES = {
     "pxm_version": (c_int, []),
     "pxm_last_error": (C.c_char_p, []),
     "pxm_device_count": (c_int, []),
-    "pxm_profile_enable": (c_int, [c_int]),
-    "pxm_profile_read": (c_int, [c_vp, c_vp, c_vp, c_vp]),
-    "pxm_profile_read_dft": (c_int, [c_vp, c_vp, c_vp]),
-    "pxm_set_iter_counter": (c_int, [c_vp]),
-    "pxm_iter_counter_add": (c_int, [c_u64, c_vp]),
+    "pxm_capture_begin": (c_int, []),
+    "pxm_capture_end": (c_int, []),
+    "pxm_deferred_pending": (c_int, []),
+    "pxm_tables_trim": (c_int, []),
+    "pxm_wav_set_iter_counter": (c_int, [c_vp, c_vp]),
+    "pxm_wav_iter_counter_add": (c_int, [c_vp, c_u64, c_vp]),
+    "pxm_wav_profile_enable": (c_int, [c_vp, c_int]),
+    "pxm_wav_profile_read": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "pxm_wav_profile_read_dft": (c_int, [c_vp, c_vp, c_vp, c_vp]),
+    "pxm_wav_workspace_nonfinite": (c_i64, [c_vp, c_vp]),
+    "pxm_reduce_scratch_doubles": (c_i64, [c_int]),
     "pxm_j_max": (c_int, [c_int, c_dbl]),
     "pxm_wav_bandlimits": (c_int, [c_int, c_dbl, c_int, c_vp, c_int]),
     "pxm_wav_ncoefs": (c_i64, [c_int, c_dbl, c_int, c_vp]),
@@ -76,9 +82,9 @@ SIGNATURES = {
         [c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_i64, c_int, c_int, c_vp],
     ),
     "pxm_randn": (c_int, [c_vp, c_i64, c_int, c_int, c_u64, c_u64, c_u64, c_vp]),
-    "pxm_reduce_l1": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
-    "pxm_reduce_l2": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_int, c_vp]),
-    "pxm_logtransition": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_i64, c_int, c_int, c_vp]),
+    "pxm_reduce_l1": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "pxm_reduce_l2": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "pxm_logtransition": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_pxmala_accept": (c_int, [c_vp, c_vp, c_u64, c_u64, c_u64, c_vp, c_vp, c_int, c_dbl, c_i64, c_int, c_vp]),
     "pxm_select_copy": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_wl_harmonic_mapping": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),

@@ -25,6 +25,18 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
     }                                \
   } while (0)
 
+// ---- capture-safe teardown (host_api.cpp) ---------------------------------------------------
+// hipFree / hipEventDestroy are illegal while a stream capture is in progress, and a plan can be torn down at
+// any moment (Python's garbage collector).  Plans therefore never free device memory directly: they hand it to
+// a process-wide graveyard that is emptied at safe points -- plan creation, pxm_capture_end(), and any
+// teardown that finds no capture under way.  A capture is known to be under way between pxm_capture_begin()
+// and pxm_capture_end(), or while the stream last seen capturing by an entry point (note_stream) still is.
+void deferred_free(void* p);
+void deferred_event_destroy(hipEvent_t e);
+void note_stream(hipStream_t st);  // every stream-taking entry point reports its stream here
+bool capture_in_progress();
+int drain_deferred();  // frees what is queued unless a capture is in progress; returns the number still queued
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int round_down(int x, int m) { return x / m * m; }
 

@@ -163,24 +163,18 @@ int make_dft_plan(int L, DftPlan* p) {
   PXM_HIP(hipMemcpy(p->d_chirp, b.chirp.data(), b.chirp.size() * sizeof(double), hipMemcpyHostToDevice));
   PXM_HIP(hipMemcpy(p->d_bhat, b.bhat.data(), b.bhat.size() * sizeof(double), hipMemcpyHostToDevice));
   PXM_HIP(hipMemcpy(p->d_tw, b.tw.data(), b.tw.size() * sizeof(double), hipMemcpyHostToDevice));
-  p->use2 = dft2_supported(b.M) && !getenv("PXM_DFT_RADIX2");
-  if (p->use2) {
-    int rc = dft2_make_tables(b, &p->d_bhatn, &p->d_twm);
+  // default for L <= 256: eight points per lane (dft5.hip); PXM_DFT_NO_V=1 selects the 16-points-per-lane wave path
+  if (dft5_r0(b.n) && !getenv("PXM_DFT_NO_V") && !getenv("PXM_DFT_NO_W")) {
+    int rc = dft5_make_tables(b.n, &p->t5);
     if (rc) return rc;
-    const char* e = getenv("PXM_DFT_R");
-    int R2 = e ? atoi(e) : 4;
-    if (R2 != 1 && R2 != 2 && R2 != 4 && R2 != 8) R2 = 4;
-    for (;;) {
-      dft2_geometry(b.M, b.n, R2, &p->threads2, &p->lds2);
-      if (R2 == 1 || (p->lds2 <= 150 * 1024 && p->threads2 <= 1024)) break;
-      R2 >>= 1;
-    }
-    p->R2 = R2;
+    p->split5 = dft5_split();
+    dft5_geometry(b.n, p->split5, &p->R5, &p->TR5, &p->lds5);
+    p->use5 = true;
   }
   const int M3 = getenv("PXM_DFT_NO_W") ? 0 : dft3_size(b.n);
   if (M3) {  // wave path: square size, its own filter transform and twiddle matrix
     BluesteinTables b3 = (M3 == b.M) ? b : make_bluestein(b.n, M3);
-    int rc = dft2_make_tables(b3, &p->d_bhatn3, &p->d_twm3);
+    int rc = dft3_make_tables(b3, &p->d_bhatn3, &p->d_twm3);
     if (rc) return rc;
     const char* e3 = getenv("PXM_DFT_R3");
     p->M3 = M3;
@@ -199,9 +193,9 @@ int make_dft_plan(int L, DftPlan* p) {
     PXM_HIP(hipMemcpy(p->d_bhatn4, bn.data(), bn.size() * sizeof(double), hipMemcpyHostToDevice));
     BluesteinTables b1k = make_bluestein(2, 1024);  // only its size matters: the 32 x 32 W_1024 twiddle matrix
     double* unused = nullptr;
-    int rc = dft2_make_tables(b1k, &unused, &p->d_twm4);
+    int rc = dft3_make_tables(b1k, &unused, &p->d_twm4);
     if (rc) return rc;
-    (void)hipFree(unused);
+    deferred_free(unused);
     p->use4 = true;
   }
   static bool attr_set = false;
@@ -216,17 +210,15 @@ int make_dft_plan(int L, DftPlan* p) {
 }
 
 void free_dft_plan(DftPlan* p) {
-  if (p->d_chirp) (void)hipFree(p->d_chirp);
-  if (p->d_bhat) (void)hipFree(p->d_bhat);
-  if (p->d_tw) (void)hipFree(p->d_tw);
-  if (p->d_bhatn) (void)hipFree(p->d_bhatn);
-  if (p->d_twm) (void)hipFree(p->d_twm);
-  if (p->d_bhatn3) (void)hipFree(p->d_bhatn3);
-  if (p->d_twm3) (void)hipFree(p->d_twm3);
-  if (p->d_bhatn4) (void)hipFree(p->d_bhatn4);
-  if (p->d_twm4) (void)hipFree(p->d_twm4);
+  if (p->d_chirp) deferred_free(p->d_chirp);
+  if (p->d_bhat) deferred_free(p->d_bhat);
+  if (p->d_tw) deferred_free(p->d_tw);
+  if (p->d_bhatn3) deferred_free(p->d_bhatn3);
+  if (p->d_twm3) deferred_free(p->d_twm3);
+  if (p->d_bhatn4) deferred_free(p->d_bhatn4);
+  if (p->d_twm4) deferred_free(p->d_twm4);
   p->d_bhatn4 = p->d_twm4 = nullptr;
-  p->d_chirp = p->d_bhat = p->d_tw = p->d_bhatn = p->d_twm = p->d_bhatn3 = p->d_twm3 = nullptr;
+  p->d_chirp = p->d_bhat = p->d_tw = p->d_bhatn3 = p->d_twm3 = nullptr;
 }
 
 static DftArgs make_args(const DftPlan& p) {
@@ -244,9 +236,9 @@ static DftArgs make_args(const DftPlan& p) {
 }
 
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream) {
+  if (p.use5) return dft5_px2ring(p, in, G, ncol, C, stream);
   if (p.use3) return dft3_px2ring(p, in, G, ncol, C, stream);
   if (p.use4) return dft4_px2ring(p, in, G, ncol, C, stream);
-  if (p.use2) return dft2_px2ring(p, in, G, ncol, C, stream);
   const int Cp = ncol / 2;
   dim3 grid(p.L, (Cp + p.R - 1) / p.R), block(p.threads);
   hipLaunchKernelGGL(k_px2ring, grid, block, p.lds, stream, make_args(p), in, G, ncol, C);
@@ -255,15 +247,15 @@ int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C,
 }
 
 int launch_ring2px2ring(const DftPlan& p, double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
+  if (p.use5) return dft5_ring2px(p, G, ncol, out, C, stream, true);
   if (p.use3) return dft3_ring2px(p, G, ncol, out, C, stream, true);
-  if (p.use2) return dft2_ring2px(p, G, ncol, out, C, stream, true);
   return 1;
 }
 
 int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
+  if (p.use5) return dft5_ring2px(p, G, ncol, out, C, stream);
   if (p.use3) return dft3_ring2px(p, G, ncol, out, C, stream);
   if (p.use4) return dft4_ring2px(p, G, ncol, out, C, stream);
-  if (p.use2) return dft2_ring2px(p, G, ncol, out, C, stream);
   dim3 grid(p.L, (C + p.R - 1) / p.R), block(p.threads);
   hipLaunchKernelGGL(k_ring2px, grid, block, p.lds, stream, make_args(p), G, ncol, out, C);
   PXM_HIP(hipGetLastError());

@@ -26,6 +26,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -278,7 +279,8 @@ template <int P, bool DUAL, bool RING_OUT>
 __device__ __forceinline__ void ring2px_body(const Dft3Args& a, double* __restrict__ G, int ncol, const PxOut& out, int C,
                                              int bx, int by, double2* lds3) {
   // chain groups without a live chain do nothing: their (padding) slots hold zero rings from plan creation on, or
-  // stale finite values of an earlier, wider batch -- the GEMM columns are independent, nothing reads them
+  // the last rings of an earlier, wider batch -- the GEMMs skip column groups without a live chain and the Gram
+  // epilogue writes zeros into padding columns (GemmAffine::ncol_live), so nothing iterates on them
   if (by * a.R >= C) return;
   PXM_W_GEOMETRY
   (void)LPR;
@@ -600,6 +602,31 @@ __global__ __launch_bounds__(256, 2) void k_ring2px4(Dft4Args a4, const double* 
 }
 
 // ---- host side -----------------------------------------------------------------------------
+int dft3_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm) {
+  const int M = b.M;
+  int N1 = 1;
+  while (N1 * N1 < M) N1 <<= 1;  // square sizes only (16, 64, 256, 1024)
+  std::vector<double> bn(2 * (size_t)M), tw(2 * (size_t)N1 * N1);
+  for (int i = 0; i < M; ++i) {  // b.bhat is in bit-reversed order
+    int r = 0;
+    for (int bit = 0; bit < b.logM; ++bit) r |= ((i >> bit) & 1) << (b.logM - 1 - bit);
+    bn[2 * (size_t)r] = b.bhat[2 * (size_t)i];
+    bn[2 * (size_t)r + 1] = b.bhat[2 * (size_t)i + 1];
+  }
+  const long double PI_L = 3.141592653589793238462643383279502884L;
+  for (int j2 = 0; j2 < N1; ++j2)
+    for (int k1 = 0; k1 < N1; ++k1) {
+      const long double ang = -2 * PI_L * (long double)((k1 * j2) % M) / M;
+      tw[2 * (size_t)(j2 * N1 + k1)] = (double)cosl(ang);
+      tw[2 * (size_t)(j2 * N1 + k1) + 1] = (double)sinl(ang);
+    }
+  PXM_HIP(hipMalloc(d_bhatn, bn.size() * sizeof(double)));
+  PXM_HIP(hipMalloc(d_twm, tw.size() * sizeof(double)));
+  PXM_HIP(hipMemcpy(*d_bhatn, bn.data(), bn.size() * sizeof(double), hipMemcpyHostToDevice));
+  PXM_HIP(hipMemcpy(*d_twm, tw.data(), tw.size() * sizeof(double), hipMemcpyHostToDevice));
+  return 0;
+}
+
 // smallest square size (16, 64, 256, 1024) holding the Bluestein convolution of a length-n ring; 0 = none
 int dft3_size(int n) {
   for (int M = 16; M <= 1024; M *= 4)
@@ -712,17 +739,18 @@ int dft3_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
 }
 
 void dft3_group_destroy(Dft3GroupList* g) {
-  if (g->d) (void)hipFree(g->d);
+  if (g->d) deferred_free(g->d);
   g->d = nullptr;
   g->n = 0;
 }
 
-int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
+int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
+                      Profiler* prof) {
   // algorithmic bytes: rings read + written (16 B per slot and coefficient, every padded slot), state read, new state
   // written (live slots), thresholds read once
   const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
-  hipEvent_t ev0, ev1;
-  profile_dft_events(&ev0, &ev1, bytes);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
   hipExtLaunchKernelGGL(k_ring2px_group, dim3(g.blocks), dim3(256), g.lds, st, ev0, ev1, 0,
                         reinterpret_cast<const Dft3Group*>(g.d), g.n, ws, ncol, out, C);
   PXM_HIP(hipGetLastError());

@@ -1,0 +1,734 @@
+// phi-DFT stage, eight-points-per-lane path (every ring length n = 2L-1 <= 511, i.e. L <= 256).
+//
+// Bluestein at M = 2 Mh, Mh = max(64, nextpow2(n)) = 64 r0, r0 in {1, 2, 4, 8}.  The chirped input a[j] is zero
+// above n <= Mh, so the first radix-2 (DIF) stage of the M-point transform is free: the even bins are the
+// Mh-point transform of a[j], the odd bins that of a[j] W_M^j, and after the filter
+//     conv[j] = y_even[j] + W_M^(-j) y_odd[j],   j < n <= Mh.
+// ONE wave owns RPW = 8 / r0 rings and runs the two half-size convolutions one after the other with 8 complex
+// points per lane (Mh = 64 lanes' worth of 8 r0 ... see below), so a ring never leaves its wave (every LDS
+// exchange needs wave-local ordering only, no workgroup barrier) and the kernel stays at <= 128 VGPR = 4 waves
+// per SIMD -- the one-wave M = 1024 kernels of dft3.hip hold 16 points per lane, 203 VGPR, 2 waves per SIMD and
+// were bound by VALU issue latency at that occupancy.
+//
+// Mh-point transform, j = j0 + r0 j1 + 8 r0 j2 (j0 < r0; j1, j2 < 8), bin k = k2 + 8 k1 + 64 k0 (k0 < r0):
+//   lane = g + 8 j1, g = j0 + r0 rho (rho = ring of the wave), registers p = j2: element j = lam + 8 r0 p of ring
+//   rho, lam = j0 + r0 j1 -- consecutive lanes hold consecutive elements;
+//   pass 1: radix 8 over j2 -> k2, twiddle W_Mh^(lam k2);         T1: lane g + 8 j1, reg k2 -> lane g + 8 k2, reg j1
+//   pass 2: radix 8 over j1 -> k1, twiddle W_(8 r0)^(j0 k1);      T2: lane g + 8 k2, reg k1 -> lane k1 + 8 k2, reg g
+//   pass 3: radix r0 over j0 -> k0 for every ring;                bin k of ring rho in reg k0 + r0 rho
+// and the mirror image back (scripts/proto_dft5.py is the lane- and register-exact numpy model of this file).
+// The transposes go through a per-wave LDS plane of 8 x 72 complex: T1 at 72 k2 + 8 j1 + g, T2 at 72 k2 + 9 k1 + g;
+// with these pitches every ds_write_b128 (8 contiguous lanes per pass) and ds_read_b128 (the four 16-lane groups
+// {0-3,12-15,20-27} ...) of both directions is bank-conflict-free.
+#include "elem.h"
+#include "sht_core.h"
+#include "update.h"
+
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdlib>
+#include <vector>
+
+namespace pxm {
+
+constexpr int D5_PLANE = 8 * 72;  // complex elements of one wave's transpose plane
+constexpr int D5_NW = 4;          // waves per workgroup
+
+struct Dft5Args {
+  int L, n, Rp;
+  int R, TR;            // chains x ring groups per workgroup (R * TR = D5_NW); rings per workgroup = TR * RPW
+  const double2* cE;    // [n]  chirp c_j = exp(-i pi j^2 / n)
+  const double2* cO;    // [n]  c_j W_M^j       (input of the odd-bin half)
+  const double2* dO;    // [n]  c_j W_M^(-j)    (output weight of the odd-bin half)
+  const double2* tw1;   // [8][64] W_Mh^(lam(lane) k2)
+  const double2* wt;    // [8][8]  W_(8 r0)^(a b)
+  const double2* bE;    // [r0][64] FFT_M(filter)/M at the even bins, in the order pass 3 leaves them
+  const double2* bO;    // [r0][64] the odd bins
+};
+
+// one scale of a grouped launch
+struct Dft5Group {
+  Dft5Args a;
+  int64_t g_off;  // this scale's ring array inside the workspace (doubles)
+  int64_t ring0;  // offset of its coefficient block inside a chain (complex elements)
+  int r0;
+  int b0, nbx, nby;  // first block of the scale in the grid, its blocks along rings / chain groups
+};
+
+__device__ __forceinline__ void d5_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// v * exp(SGN i pi k / 4)
+template <int SGN>
+__device__ __forceinline__ double2 mul_w8(double2 v, int k) {
+  constexpr double s = 0.70710678118654752440;
+  switch (k & 3) {
+    case 0: return v;
+    case 1: return SGN < 0 ? double2{s * (v.x + v.y), s * (v.y - v.x)} : double2{s * (v.x - v.y), s * (v.x + v.y)};
+    case 2: return SGN < 0 ? double2{v.y, -v.x} : double2{-v.y, v.x};
+    default: return SGN < 0 ? double2{s * (v.y - v.x), -s * (v.x + v.y)} : double2{-s * (v.x + v.y), s * (v.x - v.y)};
+  }
+}
+__device__ __forceinline__ void d5_swap(double2& a, double2& b) {
+  const double2 t = a;
+  a = b;
+  b = t;
+}
+
+// in-register DFTs over consecutive registers x[B .. B + R), natural order in and out
+template <int SGN, int B>
+__device__ __forceinline__ void dft8r(double2 (&x)[8]) {
+  static_assert(B == 0, "one 8-point transform per lane");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double2 u = x[i], v = x[i + 4];
+    x[i] = cadd(u, v);
+    x[i + 4] = mul_w8<SGN>(csub(u, v), i);
+  }
+#pragma unroll
+  for (int h = 0; h < 8; h += 4)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double2 u = x[h + i], v = x[h + i + 2];
+      x[h + i] = cadd(u, v);
+      x[h + i + 2] = mul_w8<SGN>(csub(u, v), 2 * i);
+    }
+#pragma unroll
+  for (int i = 0; i < 8; i += 2) {
+    const double2 u = x[i], v = x[i + 1];
+    x[i] = cadd(u, v);
+    x[i + 1] = csub(u, v);
+  }
+  d5_swap(x[1], x[4]);  // bit reversal (compile-time register renaming)
+  d5_swap(x[3], x[6]);
+}
+template <int SGN, int B>
+__device__ __forceinline__ void dft4r(double2 (&x)[8]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double2 u = x[B + i], v = x[B + i + 2];
+    x[B + i] = cadd(u, v);
+    x[B + i + 2] = mul_w8<SGN>(csub(u, v), 2 * i);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i += 2) {
+    const double2 u = x[B + i], v = x[B + i + 1];
+    x[B + i] = cadd(u, v);
+    x[B + i + 1] = csub(u, v);
+  }
+  d5_swap(x[B + 1], x[B + 2]);
+}
+template <int B>
+__device__ __forceinline__ void dft2r(double2 (&x)[8]) {
+  const double2 u = x[B], v = x[B + 1];
+  x[B] = cadd(u, v);
+  x[B + 1] = csub(u, v);
+}
+// pass 3 / 3': radix r0 over j0 for each of the 8 / r0 rings of the wave
+template <int SGN, int R0>
+__device__ __forceinline__ void pass3(double2 (&x)[8]) {
+  if (R0 == 8) dft8r<SGN, 0>(x);
+  if (R0 == 4) {
+    dft4r<SGN, 0>(x);
+    dft4r<SGN, 4>(x);
+  }
+  if (R0 == 2) {
+    dft2r<0>(x);
+    dft2r<2>(x);
+    dft2r<4>(x);
+    dft2r<6>(x);
+  }
+}
+
+// per-lane constants of the transposes and twiddle look-ups
+struct D5Lane {
+  int lo, hi;  // lane & 7, lane >> 3
+};
+
+// forward Mh-point transform of the wave's rings: natural order -> bins (reg k0 + r0 rho, lane k1 + 8 k2)
+template <int R0>
+__device__ __forceinline__ void d5_fwd(double2 (&z)[8], double2* plane, int lane, const D5Lane& q, const Dft5Args& a) {
+  dft8r<-1, 0>(z);
+#pragma unroll
+  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], a.tw1[k * 64 + lane]);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) plane[72 * k + lane] = z[k];  // T1
+  d5_wave_sync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) z[k] = plane[72 * q.hi + 8 * k + q.lo];
+  d5_wave_sync();
+  dft8r<-1, 0>(z);
+  if (R0 > 1) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], a.wt[k * 8 + (q.lo & (R0 - 1))]);  // W^(j0(g) k1)
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) plane[72 * q.hi + 9 * k + q.lo] = z[k];  // T2
+  d5_wave_sync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) z[k] = plane[72 * q.hi + 9 * q.lo + k];
+  d5_wave_sync();
+  pass3<-1, R0>(z);
+}
+
+// the mirror image: bins -> natural order (unnormalised inverse transform)
+template <int R0>
+__device__ __forceinline__ void d5_inv(double2 (&z)[8], double2* plane, int lane, const D5Lane& q, const Dft5Args& a) {
+  pass3<+1, R0>(z);
+  if (R0 > 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k & (R0 - 1)) z[k] = cmulc(z[k], a.wt[(k & (R0 - 1)) * 8 + q.lo]);  // W^(-j0(reg) k1)
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) plane[72 * q.hi + 9 * q.lo + k] = z[k];  // T2'
+  d5_wave_sync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) z[k] = plane[72 * q.hi + 9 * k + q.lo];
+  d5_wave_sync();
+  dft8r<+1, 0>(z);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) plane[72 * q.hi + 8 * k + q.lo] = z[k];  // T1'
+  d5_wave_sync();
+#pragma unroll
+  for (int k = 0; k < 8; ++k) z[k] = plane[72 * k + lane];
+  d5_wave_sync();
+#pragma unroll
+  for (int k = 1; k < 8; ++k) z[k] = cmulc(z[k], a.tw1[k * 64 + lane]);
+  dft8r<+1, 0>(z);
+}
+
+// cyclic convolution half: z (chirped input, natural order) -> forward transform -> filter spectrum bw -> back
+template <int R0>
+__device__ __forceinline__ void d5_conv(double2 (&z)[8], double2* plane, int lane, const D5Lane& q, const Dft5Args& a,
+                                        const double2* __restrict__ bw) {
+  d5_fwd<R0>(z, plane, lane, q, a);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) z[k] = cmul(z[k], bw[(k & (R0 - 1)) * 64 + lane]);
+  d5_inv<R0>(z, plane, lane, q, a);
+}
+
+// DFT (e^{-2 pi i jk/n}) of the wave's rings, SPLIT == 1 (one wave runs both halves): in x[p] = element
+// j = jb + 8 r0 p (zero for j >= n), out the same elements of the transform.
+template <int R0>
+__device__ __forceinline__ void d5_dft_both(double2 (&x)[8], double2* plane, int lane, const D5Lane& q, int jb,
+                                            const Dft5Args& a) {
+  const int n = a.n;
+  double2 z[8], y0[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int j = jb + 8 * R0 * p;
+    z[p] = j < n ? cmul(x[p], a.cE[j]) : double2{0.0, 0.0};
+  }
+  d5_conv<R0>(z, plane, lane, q, a, a.bE);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int j = jb + 8 * R0 * p;
+    y0[p] = j < n ? cmul(z[p], a.cE[j]) : double2{0.0, 0.0};
+    z[p] = j < n ? cmul(x[p], a.cO[j]) : double2{0.0, 0.0};
+  }
+  d5_conv<R0>(z, plane, lane, q, a, a.bO);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int j = jb + 8 * R0 * p;
+    x[p] = j < n ? cadd(y0[p], cmul(z[p], a.dO[j])) : double2{0.0, 0.0};
+  }
+}
+
+// SPLIT == 2: the two waves of a ring pair run one half each (half 0: even bins, half 1: odd bins) and leave
+// their weighted share t_w[p] of every output element in x; d5_exchange then hands each wave the partner's share
+// of the FOUR elements it owns (p in [4 half, 4 half + 4)).
+template <int R0>
+__device__ __forceinline__ void d5_dft_half(double2 (&x)[8], double2* plane, int lane, const D5Lane& q, int jb, int half,
+                                            const Dft5Args& a) {
+  const int n = a.n;
+  const double2* __restrict__ cin = half ? a.cO : a.cE;
+  const double2* __restrict__ cout = half ? a.dO : a.cE;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int j = jb + 8 * R0 * p;
+    x[p] = j < n ? cmul(x[p], cin[j]) : double2{0.0, 0.0};
+  }
+  d5_conv<R0>(x, plane, lane, q, a, half ? a.bO : a.bE);
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int j = jb + 8 * R0 * p;
+    x[p] = j < n ? cmul(x[p], cout[j]) : double2{0.0, 0.0};
+  }
+}
+// lane-wise select on the (wave-uniform) half index: registers keep compile-time indices
+__device__ __forceinline__ double2 d5_sel(int half, double2 a, double2 b) { return double2{half ? a.x : b.x, half ? a.y : b.y}; }
+// The share of the partner's elements -> partner; x[0..4) <- own share + partner's share of the wave's OWN elements
+// p = 4 half + u (always kept in x[0..4): register indices stay compile-time).
+// SLOT selects one of two disjoint exchange regions of the planes (two exchanges may be in flight).
+template <int SLOT>
+__device__ __forceinline__ void d5_exchange_sum(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) plane[256 * SLOT + 64 * u + lane] = d5_sel(half, x[u], x[4 + u]);
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) x[u] = cadd(d5_sel(half, x[4 + u], x[u]), pplane[256 * SLOT + 64 * u + lane]);
+}
+// own elements x[0..4) -> partner; x <- all 8 elements of the ring in natural order (both waves then hold them)
+template <int SLOT>
+__device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) plane[256 * SLOT + 64 * u + lane] = x[u];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const double2 o = pplane[256 * SLOT + 64 * u + lane], own = x[u];
+    x[u] = d5_sel(half, o, own);
+    x[4 + u] = d5_sel(half, own, o);
+  }
+}
+
+// ---- workgroup geometry ---------------------------------------------------------------------------------------
+// SPLIT waves per ring set: wave = SPLIT * unit + half.  Unit u: chain r = u % R of the group, ring group
+// tr = u / R; lane -> ring rho of the unit.  stage: the rings of the workgroup in [ring][k][chain] order (16-B x R
+// segments per m in the ring arrays); the chain slot is rotated with k so that the lanes' strided reads
+// (consecutive k, one chain) spread over the banks.
+#define PXM_D5_GEOMETRY                                                                     \
+  constexpr int RPW = 8 / R0;                                                               \
+  const int R = a.R, TR = a.TR, n = a.n;                                                    \
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                               \
+  const int half = SPLIT == 2 ? (wave & 1) : 0, unit = SPLIT == 2 ? (wave >> 1) : wave;     \
+  const D5Lane q{lane & 7, lane >> 3};                                                      \
+  const int tr = unit / R, r = unit - tr * R;                                               \
+  const int rho = q.lo / R0;                          /* ring of the unit this lane works on */ \
+  const int jb = (q.lo & (R0 - 1)) + R0 * q.hi;       /* its first element: j = jb + 8 r0 p */ \
+  const int TRS = TR * RPW;                           /* rings per workgroup */             \
+  const int trs = tr * RPW + rho;                     /* own ring within the workgroup */   \
+  const int t = bx * TRS + trs;                       /* own ring */                        \
+  const int c0 = by * R, ch = c0 + r;                                                       \
+  const bool tv = t < a.L;                                                                  \
+  const int Cp = ncol >> 1;                                                                 \
+  const int rsh = R >= 8 ? 1 : (R == 4 ? 2 : (R == 2 ? 3 : 4));                             \
+  constexpr int P1 = SPLIT == 2 ? 4 : 8;              /* the wave owns the elements p = pb + u, u < P1, */ \
+  const int pb = SPLIT == 2 ? 4 * half : 0;           /* and keeps them in x[u] */          \
+  double2* stage = lds5;                                                                    \
+  double2* plane = lds5 + wave * D5_PLANE;                                                  \
+  double2* pplane = lds5 + (wave ^ 1) * D5_PLANE;                                           \
+  (void)pplane;
+#define PXM_D5_SLOT(RING, K, CH) (((RING)*n + (K)) * R + (((CH) + ((K) >> rsh)) & (R - 1)))
+
+// stage -> G rows of every ring of the workgroup
+#define PXM_D5_STORE_RINGS                                                                                     \
+  for (int idx = threadIdx.x; idx < TRS * n * R; idx += blockDim.x) {                                          \
+    const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);                                            \
+    const int tt = bx * TRS + trr;                                                                             \
+    if (c0 + rr >= Cp || tt >= a.L) continue;                                                                  \
+    const int m = (k < a.L) ? k : k - n;                                                                       \
+    reinterpret_cast<double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + tt) * Cp + c0 + rr] = stage[PXM_D5_SLOT(trr, k, rr)]; \
+  }
+
+// the transform of x (all 8 elements in every wave of the ring) -> the wave's own elements of the result in x[0 .. P1)
+#define PXM_D5_TRANSFORM(SLOT)                                            \
+  if (SPLIT == 2) {                                                       \
+    d5_dft_half<R0>(x, plane, lane, q, jb, half, a);                      \
+    d5_exchange_sum<SLOT>(x, plane, pplane, lane, half);                  \
+  } else {                                                                \
+    d5_dft_both<R0>(x, plane, lane, q, jb, a);                            \
+  }
+// own elements of x -> stage (after every plane of the workgroup is dead)
+#define PXM_D5_TO_STAGE                                                   \
+  __syncthreads();                                                        \
+  _Pragma("unroll") for (int u = 0; u < P1; ++u) {                        \
+    const int j = jb + 8 * R0 * (pb + u);                                 \
+    if (j < n) stage[PXM_D5_SLOT(trs, j, r)] = x[u];                      \
+  }                                                                       \
+  __syncthreads();
+
+template <int R0, int SPLIT>
+__device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in, double* __restrict__ G, int ncol, int C,
+                                              int bx, int by, double2* lds5) {
+  PXM_D5_GEOMETRY
+  double2 x[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int j = jb + 8 * R0 * p;
+    double2 v{0.0, 0.0};
+    if (j < n && ch < C && tv) {
+      const int64_t e = in.ring0 + (int64_t)t * n + j;
+      v = reinterpret_cast<const double2*>(in.f)[(int64_t)ch * in.chain_stride + e];
+      if (in.data) {  // residual invcov .* (preds - data)   (pxmcmc/forward.py:66-69)
+        v = csub(v, reinterpret_cast<const double2*>(in.data)[e]);
+        if (in.invcov_complex) v = cmul(reinterpret_cast<const double2*>(in.invcov)[e], v);
+        else {
+          const double w = in.invcov[e];
+          v = double2{w * v.x, w * v.y};
+        }
+      }
+    }
+    x[p] = v;
+  }
+  PXM_D5_TRANSFORM(0)
+  PXM_D5_TO_STAGE
+  PXM_D5_STORE_RINGS
+}
+
+// rings -> pixels (inverse DFT by conjugation) with out's epilogue; RING_OUT: the written ring is transformed
+// again and its rings go back IN PLACE over G (rings of S X -> X' and the rings of X' in one kernel).
+template <int R0, int SPLIT, bool RING_OUT>
+__device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restrict__ G, int ncol, const PxOut& out, int C,
+                                              int bx, int by, double2* lds5) {
+  // chain groups without a live chain do nothing (see run_tasks / GemmAffine::ncol_live: nothing iterates on them)
+  if (by * a.R >= C) return;
+  PXM_D5_GEOMETRY
+  {
+    constexpr int NB = 8;  // batches of independent loads: the memory latency is paid once per batch
+    const int total = TRS * n * R;
+    for (int base = threadIdx.x; base < total; base += NB * blockDim.x) {
+      double2 v[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int idx = base + u * blockDim.x;
+        const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);
+        const int tt = bx * TRS + trr;
+        v[u] = double2{0.0, 0.0};
+        if (idx < total && c0 + rr < Cp && tt < a.L) {
+          const int m = (k < a.L) ? k : k - n;
+          v[u] = reinterpret_cast<const double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + tt) * Cp + c0 + rr];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int idx = base + u * blockDim.x;
+        if (idx < total) {
+          const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);
+          stage[PXM_D5_SLOT(trr, k, rr)] = double2{v[u].x, -v[u].y};  // inverse DFT by conjugation: y = conj(DFT(conj x))
+        }
+      }
+    }
+  }
+  __syncthreads();
+  double2 x[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int j = jb + 8 * R0 * p;
+    x[p] = j < n ? stage[PXM_D5_SLOT(trs, j, r)] : double2{0.0, 0.0};
+  }
+  __syncthreads();
+  PXM_D5_TRANSFORM(0)
+  const bool act = ch < C && tv;
+  const int64_t e0 = out.ring0 + (int64_t)t * n + jb + (int64_t)(8 * R0) * pb;  // the wave's first element; u advances by 8 r0
+  const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
+  if (act && out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+    const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
+#pragma unroll
+    for (int g0 = 0; g0 < P1; g0 += 4) {  // all loads of a group first (independent), then its arithmetic
+      double2 xs[4], wn[4];
+      double Ts[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = g0 + u;
+        const bool ok = jb + 8 * R0 * (pb + p) < n;
+        const int64_t off = (int64_t)(8 * R0) * p;
+        xs[u] = ok ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
+        Ts[u] = (ok && out.T) ? out.T[e0 + off] : out.T_scalar;
+        wn[u] = (ok && out.noise) ? px_noise_load(out, ch, e0 + off) : double2{0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = g0 + u;
+        if (jb + 8 * R0 * (pb + p) >= n) {
+          x[p] = double2{0.0, 0.0};
+          continue;
+        }
+        const int64_t off = (int64_t)(8 * R0) * p;
+        const double2 y{x[p].x, -x[p].y};
+        double2 w = wn[u];
+        if (!out.noise) w = px_noise_philox(out, ch, e0 + off, it_eff);
+        x[p] = px_update(out, xs[u], Ts[u], y, w);
+        reinterpret_cast<double2*>(out.f)[ce0 + off] = x[p];
+      }
+    }
+  } else if (act) {
+#pragma unroll
+    for (int p = 0; p < P1; ++p) {
+      if (jb + 8 * R0 * (pb + p) >= n) {
+        x[p] = double2{0.0, 0.0};
+        continue;
+      }
+      const int64_t e = e0 + (int64_t)(8 * R0) * p;
+      double2 y{x[p].x, -x[p].y};
+      reinterpret_cast<double2*>(out.f)[(int64_t)ch * out.chain_stride + e] = y;
+      if (RING_OUT && out.rdata) {  // residual invcov .* (image - data) goes back to the rings
+        y = csub(y, reinterpret_cast<const double2*>(out.rdata)[e]);
+        if (out.rinvcov_complex) y = cmul(reinterpret_cast<const double2*>(out.rinvcov)[e], y);
+        else {
+          const double wt = out.rinvcov[e];
+          y = double2{wt * y.x, wt * y.y};
+        }
+      }
+      x[p] = y;
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < P1; ++p) x[p] = double2{0.0, 0.0};  // padding chains / rings: their rings are kept at zero
+  }
+  if (!RING_OUT) return;
+  // ---- forward transform of the updated ring
+  if (SPLIT == 2) {
+    d5_exchange_fill<1>(x, plane, pplane, lane, half);  // both waves of the ring need all 8 elements
+    __syncthreads();                                    // ... and every exchange read is done before the planes are reused
+  }
+  PXM_D5_TRANSFORM(0)
+  PXM_D5_TO_STAGE
+  PXM_D5_STORE_RINGS
+}
+
+template <int R0, int SPLIT>
+__global__ __launch_bounds__(64 * D5_NW * SPLIT, SPLIT == 2 ? 4 : 3) void k_px2ring5(Dft5Args a, PxIn in, double* __restrict__ G,
+                                                                                 int ncol, int C) {
+  extern __shared__ double2 lds5[];
+  if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
+  px2ring_body5<R0, SPLIT>(a, in, G, ncol, C, blockIdx.x, blockIdx.y, lds5);
+}
+
+template <int R0, int SPLIT, bool RING_OUT>
+__global__ __launch_bounds__(64 * D5_NW * SPLIT, SPLIT == 2 ? 4 : 3) void k_ring2px5(Dft5Args a, double* __restrict__ G, int ncol,
+                                                                                 PxOut out, int C) {
+  extern __shared__ double2 lds5[];
+  ring2px_body5<R0, SPLIT, RING_OUT>(a, G, ncol, out, C, blockIdx.x, blockIdx.y, lds5);
+}
+
+// Grouped launch of the ring-space step: the rings -> X' -> rings bodies of EVERY scale of a wavelet plan in one
+// grid, largest scales first (their workgroups are the long ones; the small scales fill the tail).
+template <int SPLIT>
+__global__ __launch_bounds__(64 * D5_NW * SPLIT, SPLIT == 2 ? 4 : 3) void k_ring2px_group5(const Dft5Group* __restrict__ ents, int nent,
+                                                                                       double* __restrict__ ws, int ncol, PxOut out,
+                                                                                       int C) {
+  extern __shared__ double2 lds5[];
+  int e = 0;
+  while (e + 1 < nent && (int)blockIdx.x >= ents[e + 1].b0) ++e;
+  const Dft5Group g = ents[e];
+  const int local = blockIdx.x - g.b0;
+  const int bx = local % g.nbx, by = local / g.nbx;
+  out.ring0 = g.ring0;
+  double* G = ws + g.g_off;
+  const Dft5Args a = g.a;
+  switch (g.r0) {
+    case 8: ring2px_body5<8, SPLIT, true>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 4: ring2px_body5<4, SPLIT, true>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 2: ring2px_body5<2, SPLIT, true>(a, G, ncol, out, C, bx, by, lds5); break;
+    default: ring2px_body5<1, SPLIT, true>(a, G, ncol, out, C, bx, by, lds5); break;
+  }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------
+int dft5_r0(int n) {  // 0: no eight-point path for this ring length
+  if (n > 512) return 0;
+  int Mh = 64;
+  while (Mh < n) Mh <<= 1;
+  return Mh / 64;
+}
+
+int dft5_make_tables(int n, Dft5Tables* t) {
+  typedef std::complex<long double> cld;
+  const long double PI_L = 3.141592653589793238462643383279502884L;
+  const int r0 = dft5_r0(n), Mh = 64 * r0, M = 2 * Mh;
+  auto ang = [&](long double num, long double den) { return cld(cosl(-PI_L * num / den), sinl(-PI_L * num / den)); };
+  std::vector<cld> chirp(n), filt(M, cld(0, 0));
+  for (int j = 0; j < n; ++j) chirp[j] = ang((long double)(((long long)j * j) % (2LL * n)), n);
+  for (int j = 0; j < n; ++j) {
+    filt[j] = std::conj(chirp[j]);
+    if (j) filt[M - j] = std::conj(chirp[j]);
+  }
+  // FFT_M(filter) / M in long double (radix-2 DIF, then undo the bit reversal)
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+  for (int s = M / 2; s >= 1; s >>= 1)
+    for (int g = 0; g < M; g += 2 * s)
+      for (int p = 0; p < s; ++p) {
+        const cld w = ang(2.0L * p * (M / (2 * s)), M);
+        const cld u = filt[g + p], v = filt[g + p + s];
+        filt[g + p] = u + v;
+        filt[g + p + s] = (u - v) * w;
+      }
+  std::vector<cld> bhat(M);
+  for (int i = 0; i < M; ++i) {
+    int r = 0;
+    for (int bit = 0; bit < logM; ++bit) r |= ((i >> bit) & 1) << (logM - 1 - bit);
+    bhat[r] = filt[i] / (long double)M;
+  }
+  std::vector<double> h;
+  auto put = [&](const cld& v) {
+    h.push_back((double)v.real());
+    h.push_back((double)v.imag());
+  };
+  const size_t o_cE = 0;
+  for (int j = 0; j < n; ++j) put(chirp[j]);
+  const size_t o_cO = h.size();
+  for (int j = 0; j < n; ++j) put(chirp[j] * ang(2.0L * j, M));
+  const size_t o_dO = h.size();
+  for (int j = 0; j < n; ++j) put(chirp[j] * std::conj(ang(2.0L * j, M)));
+  const size_t o_tw1 = h.size();
+  for (int k = 0; k < 8; ++k)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int lam = ((lane & 7) % r0) + r0 * (lane >> 3);
+      put(ang(2.0L * ((lam * k) % Mh), Mh));
+    }
+  const size_t o_wt = h.size();
+  for (int a = 0; a < 8; ++a)
+    for (int b = 0; b < 8; ++b) put(ang(2.0L * ((a * b) % (8 * r0)), 8 * r0));
+  size_t o_b[2];
+  for (int w = 0; w < 2; ++w) {
+    o_b[w] = h.size();
+    for (int k0 = 0; k0 < r0; ++k0)
+      for (int lane = 0; lane < 64; ++lane) put(bhat[2 * ((lane >> 3) + 8 * (lane & 7) + 64 * k0) + w]);
+  }
+  PXM_HIP(hipMalloc(&t->d_all, h.size() * sizeof(double)));
+  PXM_HIP(hipMemcpy(t->d_all, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  t->r0 = r0;
+  t->cE = t->d_all + o_cE;
+  t->cO = t->d_all + o_cO;
+  t->dO = t->d_all + o_dO;
+  t->tw1 = t->d_all + o_tw1;
+  t->wt = t->d_all + o_wt;
+  t->bE = t->d_all + o_b[0];
+  t->bO = t->d_all + o_b[1];
+  return 0;
+}
+
+// waves per ring set, read at plan creation: 2 (default) or 1 (PXM_DFT_SPLIT=1: one wave runs both halves, 3 waves per SIMD)
+int dft5_split() {
+  const char* e = getenv("PXM_DFT_SPLIT");
+  return (e && atoi(e) == 1) ? 1 : 2;
+}
+
+void dft5_geometry(int n, int split, int* R, int* TR, size_t* lds) {
+  const int r0 = dft5_r0(n), rpw = 8 / r0;
+  *R = 4;
+  *TR = D5_NW / *R;
+  const size_t planes = (size_t)D5_NW * split * D5_PLANE * 16, stage = (size_t)(*TR) * rpw * n * (*R) * 16;
+  *lds = std::max(planes, stage);
+}
+
+static Dft5Args dft5_args(const DftPlan& p) {
+  const Dft5Tables& t = p.t5;
+  auto c = [](const double* x) { return reinterpret_cast<const double2*>(x); };
+  return Dft5Args{p.L, p.n, p.Rp, p.R5, p.TR5, c(t.cE), c(t.cO), c(t.dO), c(t.tw1), c(t.wt), c(t.bE), c(t.bO)};
+}
+
+template <int R0, int SPLIT>
+static int dft5_attr() {
+  static bool done = false;
+  if (!done) {
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring5<R0, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, SPLIT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, SPLIT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  return 0;
+}
+
+template <int R0, int SPLIT>
+static int px2ring5_r(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
+  if (int rc = dft5_attr<R0, SPLIT>()) return rc;
+  const int Cp = ncol / 2, rings = p.TR5 * (8 / R0);
+  dim3 grid((p.L + rings - 1) / rings, (Cp + p.R5 - 1) / p.R5), block(64 * D5_NW * SPLIT);
+  hipLaunchKernelGGL((k_px2ring5<R0, SPLIT>), grid, block, p.lds5, st, dft5_args(p), in, G, ncol, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int R0, int SPLIT>
+static int ring2px5_r(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
+  if (int rc = dft5_attr<R0, SPLIT>()) return rc;
+  const int rings = p.TR5 * (8 / R0);
+  dim3 grid((p.L + rings - 1) / rings, (C + p.R5 - 1) / p.R5), block(64 * D5_NW * SPLIT);
+  if (ring_out) {
+    hipLaunchKernelGGL((k_ring2px5<R0, SPLIT, true>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
+  } else {
+    hipLaunchKernelGGL((k_ring2px5<R0, SPLIT, false>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
+  }
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+#define PXM_D5_DISPATCH(FN, ...)                                                   \
+  const bool two = p.split5 == 2;                                                  \
+  switch (p.t5.r0) {                                                               \
+    case 8: return two ? FN<8, 2>(__VA_ARGS__) : FN<8, 1>(__VA_ARGS__);            \
+    case 4: return two ? FN<4, 2>(__VA_ARGS__) : FN<4, 1>(__VA_ARGS__);            \
+    case 2: return two ? FN<2, 2>(__VA_ARGS__) : FN<2, 1>(__VA_ARGS__);            \
+    default: return two ? FN<1, 2>(__VA_ARGS__) : FN<1, 1>(__VA_ARGS__);           \
+  }
+
+int dft5_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
+  PXM_D5_DISPATCH(px2ring5_r, p, in, G, ncol, C, st)
+}
+int dft5_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
+  PXM_D5_DISPATCH(ring2px5_r, p, G, ncol, out, C, st, ring_out)
+}
+
+// ---- grouped launch (wavelet plan: every scale in one grid) -----------------------------------------------------
+int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
+                      const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out) {
+  // longest workgroups first: full-size scales, then the smaller ones in descending size (they fill the tail)
+  std::vector<int> order(plans.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return plans[x]->L > plans[y]->L; });
+  std::vector<Dft5Group> v;
+  int b0 = 0;
+  size_t lds = 0;
+  for (int s : order) {
+    const DftPlan& p = *plans[s];
+    if (!p.use5 || p.split5 != plans[order[0]]->split5) return 1;
+    Dft5Group g;
+    g.a = dft5_args(p);
+    g.g_off = g_off[s];
+    g.ring0 = ring0[s];
+    g.r0 = p.t5.r0;
+    const int rings = p.TR5 * (8 / g.r0);
+    g.nbx = (p.L + rings - 1) / rings;
+    g.nby = (ncol / 2 + p.R5 - 1) / p.R5;
+    g.b0 = b0;
+    b0 += g.nbx * g.nby;
+    lds = std::max(lds, p.lds5);
+    out->px_elems += (double)p.L * p.n;
+    v.push_back(g);
+  }
+  out->n = (int)v.size();
+  out->blocks = b0;
+  out->lds = lds;
+  out->five = true;
+  out->split = plans[order[0]]->split5;
+  PXM_HIP(hipMalloc(&out->d, v.size() * sizeof(Dft5Group)));
+  PXM_HIP(hipMemcpy(out->d, v.data(), v.size() * sizeof(Dft5Group), hipMemcpyHostToDevice));
+  static bool attr = false;
+  if (!attr) {
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024));
+    attr = true;
+  }
+  return 0;
+}
+
+int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st, Profiler* prof) {
+  // algorithmic bytes: rings read + written (16 B per slot and coefficient, every padded slot), state read, new state
+  // written (live slots), thresholds read once
+  const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
+  if (g.split == 2) {
+    hipExtLaunchKernelGGL(k_ring2px_group5<2>, dim3(g.blocks), dim3(64 * D5_NW * 2), g.lds, st, ev0, ev1, 0,
+                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C);
+  } else {
+    hipExtLaunchKernelGGL(k_ring2px_group5<1>, dim3(g.blocks), dim3(64 * D5_NW), g.lds, st, ev0, ev1, 0,
+                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C);
+  }
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace pxm

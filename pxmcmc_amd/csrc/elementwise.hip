@@ -51,7 +51,6 @@ struct NoiseSrc {
   const double* noise;
   int noise_complex;
   uint64_t seed, chain0, iter;
-  const uint64_t* iter_dev;
 };
 
 template <bool CPLX>
@@ -60,7 +59,7 @@ __device__ inline double2 draw_noise(const NoiseSrc& ns, int c, int64_t n, int64
     if (CPLX && ns.noise_complex) return reinterpret_cast<const double2*>(ns.noise)[(int64_t)c * n + i];
     return double2{ns.noise[(int64_t)c * n + i], 0.0};
   }
-  const uint64_t it = ns.iter + (ns.iter_dev ? *ns.iter_dev : 0);
+  const uint64_t it = ns.iter;
   if (CPLX && ns.noise_complex) {
     NormalPair q = philox_normal_pair(ns.seed, ns.chain0 + c, (uint64_t)i, it);
     return double2{q.z0, q.z1};
@@ -129,7 +128,7 @@ __global__ void k_l1_partial(const double* __restrict__ X, const double* __restr
     double a;
     if (CPLX) {
       const double2 z = reinterpret_cast<const double2*>(X)[(int64_t)c * n + i];
-      a = hypot(z.x, z.y);
+      a = sqrt(fma(z.x, z.x, z.y * z.y));  // (no overflow guard needed: |z|^2 of a chain state is far inside fp64 range)
     } else a = fabs(X[(int64_t)c * n + i]);
     acc += w ? fabs(w[i]) * a : a;
   }
@@ -209,22 +208,10 @@ __global__ void k_reduce_final(const double* __restrict__ part, double* __restri
   }
 }
 
-static uint64_t* g_iter_counter = nullptr;
-const uint64_t* iter_counter() { return g_iter_counter; }
-__global__ void k_iter_add(uint64_t* c, uint64_t inc) { *c += inc; }
-
-// scratch for partial sums: one per device, grown on demand outside of stream capture
-static double* g_part = nullptr;
-static size_t g_part_cap = 0;
-static int ensure_part(int C) {
-  size_t need = (size_t)C * RED_SLICES * 2 * sizeof(double);
-  if (need <= g_part_cap) return 0;
-  if (g_part) PXM_HIP(hipFree(g_part));
-  size_t cap = need < (1u << 20) ? (1u << 20) : need;
-  PXM_HIP(hipMalloc(&g_part, cap));
-  g_part_cap = cap;
-  return 0;
-}
+// Reductions run in two deterministic stages through a CALLER-OWNED scratch of pxm_reduce_scratch_doubles(C)
+// doubles (partial sums of every slice, then the per-chain totals): no library-owned buffer is shared between
+// calls, streams or plans.
+static inline size_t red_scratch_doubles(int C) { return (size_t)(C + 1) * RED_SLICES * 2; }
 
 __global__ void k_l1_store(const double* __restrict__ red, double* __restrict__ out, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,17 +285,7 @@ using namespace pxm;
 
 extern "C" {
 
-int pxm_set_iter_counter(uint64_t* counter_dev) {
-  g_iter_counter = counter_dev;
-  return 0;
-}
-
-int pxm_iter_counter_add(uint64_t inc, pxm_stream_t stream) {
-  PXM_REQUIRE(g_iter_counter, "pxm_iter_counter_add: no counter registered");
-  hipLaunchKernelGGL(k_iter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, g_iter_counter, inc);
-  PXM_HIP(hipGetLastError());
-  return 0;
-}
+int64_t pxm_reduce_scratch_doubles(int C) { return C >= 1 ? (int64_t)red_scratch_doubles(C) : -1; }
 
 int pxm_soft(const void* X, const double* T, double T_scalar, void* out, int64_t n, int C, int dtype,
              pxm_stream_t stream) {
@@ -342,7 +319,7 @@ int pxm_myula_step(const void* X, const void* gradg, const double* T, double T_s
   PXM_REQUIRE(X && gradg && X_out, "pxm_myula_step: null buffer");
   PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_myula_step: complex noise needs a complex state");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, g_iter_counter};
+  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter};
   if (dtype)
     hipLaunchKernelGGL((k_chain_step<true, true>), g, b, 0, st, (const double*)X, (const double*)nullptr,
                        (const double*)gradg, T, T_scalar, delta_dev, delta, lmda, ns, (double*)X_out, n);
@@ -360,7 +337,7 @@ int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const do
   PXM_REQUIRE(X && proxf && gradg && X_out, "pxm_chain_step: null buffer");
   PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_chain_step: complex noise needs a complex state");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, g_iter_counter};
+  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter};
   if (dtype)
     hipLaunchKernelGGL((k_chain_step<true, false>), g, b, 0, st, (const double*)X, (const double*)proxf,
                        (const double*)gradg, (const double*)nullptr, 0.0, delta_dev, delta, lmda, ns, (double*)X_out, n);
@@ -376,63 +353,62 @@ int pxm_randn(void* out, int64_t n, int C, int dtype, uint64_t seed, uint64_t ch
   CHECK_ARGS("pxm_randn");
   PXM_REQUIRE(out, "pxm_randn: null buffer");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{nullptr, dtype, seed, chain0, iter, g_iter_counter};
+  NoiseSrc ns{nullptr, dtype, seed, chain0, iter};
   if (dtype) hipLaunchKernelGGL(k_randn<true>, g, b, 0, st, (double*)out, n, ns);
   else hipLaunchKernelGGL(k_randn<false>, g, b, 0, st, (double*)out, n, ns);
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
-int pxm_reduce_l1(const void* X, const double* w, double* out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+int pxm_reduce_l1(const void* X, const double* w, double* out, double* scratch, int64_t n, int C, int dtype,
+                  pxm_stream_t stream) {
   PXM_REQUIRE(n >= 0 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_reduce_l1: bad n / C / dtype");
   hipStream_t st = (hipStream_t)stream;
-  PXM_REQUIRE(X && out, "pxm_reduce_l1: null buffer");
-  int rc = ensure_part(C + 1);
-  if (rc) return rc;
+  PXM_REQUIRE(X && out && scratch, "pxm_reduce_l1: null buffer");
+  double* part = scratch;
   dim3 g(RED_SLICES, C), b(256);
-  if (dtype) hipLaunchKernelGGL(k_l1_partial<true>, g, b, 0, st, (const double*)X, w, g_part, n);
-  else hipLaunchKernelGGL(k_l1_partial<false>, g, b, 0, st, (const double*)X, w, g_part, n);
-  double* red = g_part + (size_t)C * RED_SLICES * 2;
+  if (dtype) hipLaunchKernelGGL(k_l1_partial<true>, g, b, 0, st, (const double*)X, w, part, n);
+  else hipLaunchKernelGGL(k_l1_partial<false>, g, b, 0, st, (const double*)X, w, part, n);
+  double* red = part + (size_t)C * RED_SLICES * 2;
   // final sums land in the tail of the scratch, then the real parts are compacted to out[C]
-  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, g_part, red, RED_SLICES, 0, (const double*)nullptr, 0.0);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, red, RED_SLICES, 0, (const double*)nullptr, 0.0);
   hipLaunchKernelGGL(k_l1_store, dim3((C + 63) / 64), dim3(64), 0, st, red, out, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
-int pxm_reduce_l2(const void* preds, const void* data, const void* invcov, int invcov_complex, double* out, int64_t n,
-                  int C, int dtype, pxm_stream_t stream) {
+int pxm_reduce_l2(const void* preds, const void* data, const void* invcov, int invcov_complex, double* out,
+                  double* scratch, int64_t n, int C, int dtype, pxm_stream_t stream) {
   PXM_REQUIRE(n >= 0 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_reduce_l2: bad n / C / dtype");
   PXM_REQUIRE(dtype == 1 || !invcov_complex, "pxm_reduce_l2: complex invcov needs complex data");
   hipStream_t st = (hipStream_t)stream;
-  PXM_REQUIRE(preds && data && invcov && out, "pxm_reduce_l2: null buffer");
-  int rc = ensure_part(C + 1);
-  if (rc) return rc;
+  PXM_REQUIRE(preds && data && invcov && out && scratch, "pxm_reduce_l2: null buffer");
+  double* part = scratch;
   dim3 g(RED_SLICES, C), b(256);
   const double *p = (const double*)preds, *d = (const double*)data, *ic = (const double*)invcov;
-  if (dtype && invcov_complex) hipLaunchKernelGGL((k_l2_partial<true, true>), g, b, 0, st, p, d, ic, g_part, n);
-  else if (dtype) hipLaunchKernelGGL((k_l2_partial<true, false>), g, b, 0, st, p, d, ic, g_part, n);
-  else hipLaunchKernelGGL((k_l2_partial<false, false>), g, b, 0, st, p, d, ic, g_part, n);
-  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, g_part, out, RED_SLICES, 0, (const double*)nullptr, 0.0);
+  if (dtype && invcov_complex) hipLaunchKernelGGL((k_l2_partial<true, true>), g, b, 0, st, p, d, ic, part, n);
+  else if (dtype) hipLaunchKernelGGL((k_l2_partial<true, false>), g, b, 0, st, p, d, ic, part, n);
+  else hipLaunchKernelGGL((k_l2_partial<false, false>), g, b, 0, st, p, d, ic, part, n);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, out, RED_SLICES, 0, (const double*)nullptr, 0.0);
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
 int pxm_logtransition(const void* X1, const void* X2, const void* proxf, const void* gradg, const double* delta_dev,
-                      double delta, double lmda, double* out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+                      double delta, double lmda, double* out, double* scratch, int64_t n, int C, int dtype,
+                      pxm_stream_t stream) {
   PXM_REQUIRE(n >= 0 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_logtransition: bad n / C / dtype");
   hipStream_t st = (hipStream_t)stream;
-  PXM_REQUIRE(X1 && X2 && proxf && gradg && out, "pxm_logtransition: null buffer");
-  int rc = ensure_part(C + 1);
-  if (rc) return rc;
+  PXM_REQUIRE(X1 && X2 && proxf && gradg && out && scratch, "pxm_logtransition: null buffer");
+  double* part = scratch;
   dim3 g(RED_SLICES, C), b(256);
   if (dtype)
     hipLaunchKernelGGL(k_logtrans_partial<true>, g, b, 0, st, (const double*)X1, (const double*)X2, (const double*)proxf,
-                       (const double*)gradg, delta_dev, delta, lmda, g_part, n);
+                       (const double*)gradg, delta_dev, delta, lmda, part, n);
   else
     hipLaunchKernelGGL(k_logtrans_partial<false>, g, b, 0, st, (const double*)X1, (const double*)X2,
-                       (const double*)proxf, (const double*)gradg, delta_dev, delta, lmda, g_part, n);
-  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, g_part, out, RED_SLICES, 1, delta_dev, delta);
+                       (const double*)proxf, (const double*)gradg, delta_dev, delta, lmda, part, n);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, out, RED_SLICES, 1, delta_dev, delta);
   PXM_HIP(hipGetLastError());
   return 0;
 }

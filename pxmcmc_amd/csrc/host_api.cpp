@@ -13,11 +13,93 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   g_err = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
   return -2;
 }
+
+// ---- deferred frees ---------------------------------------------------------------------------
+static std::mutex g_grave_mu;
+static std::vector<void*> g_grave_mem;
+static std::vector<hipEvent_t> g_grave_ev;
+static int g_capture_depth = 0;          // pxm_capture_begin / pxm_capture_end
+static hipStream_t g_cap_stream = nullptr;  // last stream an entry point saw capturing
+static bool g_cap_seen = false;
+
+static bool stream_capturing(hipStream_t st) {
+  hipStreamCaptureStatus s = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &s) != hipSuccess) {
+    (void)hipGetLastError();  // a destroyed stream: not capturing
+    return false;
+  }
+  return s != hipStreamCaptureStatusNone;
+}
+
+void note_stream(hipStream_t st) {
+  if (!st) return;  // the null stream cannot capture
+  if (stream_capturing(st)) {
+    std::lock_guard<std::mutex> lock(g_grave_mu);
+    g_cap_stream = st;
+    g_cap_seen = true;
+  }
+}
+
+bool capture_in_progress() {
+  std::lock_guard<std::mutex> lock(g_grave_mu);
+  if (g_capture_depth > 0) return true;
+  if (g_cap_seen) {
+    if (stream_capturing(g_cap_stream)) return true;
+    g_cap_seen = false;
+    g_cap_stream = nullptr;
+  }
+  return false;
+}
+
+void deferred_free(void* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(g_grave_mu);
+  g_grave_mem.push_back(p);
+}
+void deferred_event_destroy(hipEvent_t e) {
+  if (!e) return;
+  std::lock_guard<std::mutex> lock(g_grave_mu);
+  g_grave_ev.push_back(e);
+}
+
+int drain_deferred() {
+  if (capture_in_progress()) {
+    std::lock_guard<std::mutex> lock(g_grave_mu);
+    return (int)(g_grave_mem.size() + g_grave_ev.size());
+  }
+  std::vector<void*> mem;
+  std::vector<hipEvent_t> ev;
+  {
+    std::lock_guard<std::mutex> lock(g_grave_mu);
+    mem.swap(g_grave_mem);
+    ev.swap(g_grave_ev);
+  }
+  for (void* p : mem) (void)hipFree(p);
+  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  return 0;
+}
 }  // namespace pxm
 
 extern "C" {
 
-int pxm_version(void) { return 100; }
+int pxm_version(void) { return 200; }
+
+int pxm_capture_begin(void) {
+  std::lock_guard<std::mutex> lock(pxm::g_grave_mu);
+  ++pxm::g_capture_depth;
+  return 0;
+}
+int pxm_capture_end(void) {
+  {
+    std::lock_guard<std::mutex> lock(pxm::g_grave_mu);
+    if (pxm::g_capture_depth > 0) --pxm::g_capture_depth;
+  }
+  return pxm::drain_deferred();
+}
+int pxm_deferred_pending(void) {
+  std::lock_guard<std::mutex> lock(pxm::g_grave_mu);
+  return (int)(pxm::g_grave_mem.size() + pxm::g_grave_ev.size());
+}
 
 const char* pxm_last_error(void) { return pxm::g_err.c_str(); }
 

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 
 namespace pxm {
 
@@ -77,10 +78,12 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
 
 // run a task list over all chain groups (16 chains = 32 columns per launch)
 static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, int C, hipStream_t st,
-                     const GemmAffine& aff = GemmAffine()) {
+                     const GemmAffine& aff = GemmAffine(), Profiler* prof = nullptr) {
+  note_stream(st);
   for (int col0 = 0; col0 < ncol; col0 += 32) {
     const int ct = (ncol - col0 >= 32) ? 2 : 1;
     const int cg = std::max(0, std::min(C - col0 / 2, 8 * ct));  // live chains in this column group
+    if (cg == 0) break;  // column groups of padding chains only: nothing reads them
     double bytes = 0;
     for (size_t i = 0; i < tl.bls.size(); ++i) {
       const double Ld = tl.bls[i];
@@ -91,10 +94,16 @@ static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, i
       bytes -= gemm_table_bytes(tl.bls[tl.merged], tl.paired, std::max(tl.los[tl.merged], tl.los[tl.merged + 1]));
     GemmAffine a = aff;
     if (col0) a.bump = nullptr;  // the iteration counter advances once per call, not once per column group
-    int rc = launch_gemm(tl.d, tl.n, tl.nslab, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, a);
+    a.ncol_live = 2 * C;
+    int rc = launch_gemm(tl.d, tl.n, tl.nslab, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, a, prof);
     if (rc) return rc;
   }
   return 0;
+}
+
+static void free_tasks(TaskList* t) {
+  if (t->d) deferred_free(t->d);
+  t->d = nullptr;
 }
 
 static inline int64_t arr_size(int L, int ncol) { return (int64_t)(2 * L - 1) * round_up(L, 16) * ncol; }
@@ -124,7 +133,10 @@ int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht
   PXM_REQUIRE(std::abs(spin) < L || L == 1, "pxm_sht_plan_create: |spin| must be < L");
   PXM_REQUIRE(max_chains >= 1, "pxm_sht_plan_create: max_chains must be >= 1");
   PXM_REQUIRE(pxm_device_count() > 0, "pxm_sht_plan_create: no HIP device visible (the HIP path is the only path)");
-  pxm_sht_plan_s* p = new pxm_sht_plan_s();
+  drain_deferred();
+  // (owned by a guard until it is complete: every error return below releases what was built so far)
+  std::unique_ptr<pxm_sht_plan_s, int (*)(pxm_sht_plan_t)> guard(new pxm_sht_plan_s(), pxm_sht_plan_destroy);
+  pxm_sht_plan_s* p = guard.get();
   p->L = L;
   p->spin = spin;
   p->Cmax = max_chains;
@@ -132,9 +144,10 @@ int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht
   p->ncol = 2 * p->Cp;
   p->Rp = round_up(L, 16);
   int rc = get_tables(L, spin, 0xF, &p->T);
-  if (rc) { delete p; return rc; }
+  if (rc) { p->T = nullptr; return rc; }
+  retain_tables(p->T);
   rc = make_dft_plan(L, &p->dft);
-  if (rc) { delete p; return rc; }
+  if (rc) return rc;
   const int64_t sz = arr_size(L, p->ncol);
   p->offG = 0;
   p->offH = sz;
@@ -150,17 +163,18 @@ int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht
     rc = upload_tasks(v, p->T->paired, &p->tl[k], {L});
     if (rc) return rc;
   }
-  *plan = p;
+  *plan = guard.release();
   return 0;
 }
 
 int pxm_sht_plan_destroy(pxm_sht_plan_t p) {
   if (!p) return 0;
   free_dft_plan(&p->dft);
-  if (p->ws) (void)hipFree(p->ws);
-  for (int k = 0; k < 4; ++k)
-    if (p->tl[k].d) (void)hipFree(p->tl[k].d);
+  deferred_free(p->ws);
+  for (int k = 0; k < 4; ++k) free_tasks(&p->tl[k]);
+  release_tables(p->T);
   delete p;
+  drain_deferred();  // (a no-op while a stream capture is in progress: freed at the next safe point)
   return 0;
 }
 
@@ -177,6 +191,7 @@ static int sht_check(pxm_sht_plan_t p, const void* a, const void* b, int C, cons
 }
 
 static int sht_el_to_ring(pxm_sht_plan_t p, int kind, const void* flm, void* f, int C, hipStream_t st) {
+  note_stream(st);
   int rc = launch_lm_to_mel((const double*)flm, p->ws + p->offH, p->L, p->Rp, p->ncol, C, p->spin, st);
   if (rc) return rc;
   rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, C, st);
@@ -188,6 +203,7 @@ static int sht_el_to_ring(pxm_sht_plan_t p, int kind, const void* flm, void* f, 
 }
 
 static int sht_ring_to_el(pxm_sht_plan_t p, int kind, const void* f, void* flm, int C, hipStream_t st) {
+  note_stream(st);
   PxIn in;
   in.f = (const double*)f;
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
@@ -324,7 +340,16 @@ struct pxm_wav_plan_s {
   int nside = 2;
   std::vector<int> lane_of;  // per scale: -1 = caller's stream, else side stream index
   Dft3GroupList dft_group;   // every scale's rings -> X' -> rings kernel in one grid (ring-space step)
+  std::vector<ShtTables*> held;  // table-cache entries this plan retains (each once)
+  uint64_t* iter_dev = nullptr;  // device-resident Philox iteration counter of THIS plan (pxm_wav_set_iter_counter)
+  Profiler prof;                 // live kernel timing of THIS plan (pxm_wav_profile_*)
 };
+
+static void wav_hold(pxm_wav_plan_s* p, ShtTables* T) {
+  if (std::find(p->held.begin(), p->held.end(), T) != p->held.end()) return;
+  retain_tables(T);
+  p->held.push_back(T);
+}
 
 extern "C" {
 
@@ -334,7 +359,10 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   PXM_REQUIRE(L >= 1 && B > 1.0 && J_min >= 0, "pxm_wav_plan_create: bad (L, B, J_min)");
   PXM_REQUIRE(max_chains >= 1, "pxm_wav_plan_create: max_chains must be >= 1");
   PXM_REQUIRE(pxm_device_count() > 0, "pxm_wav_plan_create: no HIP device visible (the HIP path is the only path)");
-  pxm_wav_plan_s* p = new pxm_wav_plan_s();
+  drain_deferred();
+  // (owned by a guard until it is complete: every error return below releases what was built so far)
+  std::unique_ptr<pxm_wav_plan_s, int (*)(pxm_wav_plan_t)> guard(new pxm_wav_plan_s(), pxm_wav_plan_destroy);
+  pxm_wav_plan_s* p = guard.get();
   p->L = L;
   p->B = B;
   p->J_min = J_min;
@@ -360,11 +388,13 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   for (int s = 0; s < p->nsc; ++s) {
     rc = get_tables(p->bl[s], 0, 0xF, &p->T[s]);
     if (rc) return rc;
+    wav_hold(p, p->T[s]);
     rc = make_dft_plan(p->bl[s], &p->dft[s]);
     if (rc) return rc;
   }
   rc = get_tables(L, 0, 0xF, &p->TL);
   if (rc) return rc;
+  wav_hold(p, p->TL);
   rc = make_dft_plan(L, &p->dftL);
   if (rc) return rc;
   // workspace
@@ -527,28 +557,97 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   if (!getenv("PXM_NO_DFT_GROUP")) {
     std::vector<const DftPlan*> dp;
     for (int s = 0; s < p->nsc; ++s) dp.push_back(&p->dft[s]);
-    rc = dft3_group_create(dp, p->offG, p->coef_off, p->ncol, &p->dft_group);
+    rc = dft5_group_create(dp, p->offG, p->coef_off, p->ncol, &p->dft_group);
+    if (rc == 1) rc = dft3_group_create(dp, p->offG, p->coef_off, p->ncol, &p->dft_group);
     if (rc < 0) return rc;  // rc == 1: some scale has no wave path -> per-scale launches
   }
-  *plan = p;
+  *plan = guard.release();
   return 0;
 }
 
 int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   if (!p) return 0;
+  // Nothing is freed here directly: device memory and events go to the graveyard, which is emptied at once unless
+  // a stream capture is in progress (the garbage collector may run this in the middle of one).
   dft3_group_destroy(&p->dft_group);
   for (auto& d : p->dft) free_dft_plan(&d);
   free_dft_plan(&p->dftL);
-  if (p->ws) (void)hipFree(p->ws);
-  if (p->d_kc_syn) (void)hipFree(p->d_kc_syn);
-  if (p->d_kc_ana) (void)hipFree(p->d_kc_ana);
+  deferred_free(p->ws);
+  deferred_free(p->d_kc_syn);
+  deferred_free(p->d_kc_ana);
   // (side streams / events belong to the per-device pool)
   TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj, &p->adj_invadj_R, &p->gram, &p->adj_invadj_D,
                      &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj};
-  for (TaskList* t : tls)
-    if (t->d) (void)hipFree(t->d);
+  for (TaskList* t : tls) free_tasks(t);
+  profiler_release(&p->prof);
+  for (ShtTables* T : p->held) release_tables(T);
   delete p;
+  drain_deferred();
   return 0;
+}
+
+int pxm_wav_set_iter_counter(pxm_wav_plan_t p, uint64_t* counter_dev) {
+  PXM_REQUIRE(p, "pxm_wav_set_iter_counter: null plan");
+  p->iter_dev = counter_dev;
+  return 0;
+}
+
+}  // extern "C"
+namespace pxm {
+__global__ void k_iter_add(uint64_t* c, uint64_t inc) { *c += inc; }
+}
+extern "C" {
+
+int pxm_wav_iter_counter_add(pxm_wav_plan_t p, uint64_t inc, pxm_stream_t stream) {
+  PXM_REQUIRE(p && p->iter_dev, "pxm_wav_iter_counter_add: no counter registered on this plan");
+  hipLaunchKernelGGL(k_iter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, p->iter_dev, inc);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_wav_profile_enable(pxm_wav_plan_t p, int max_launches) {
+  PXM_REQUIRE(p, "pxm_wav_profile_enable: null plan");
+  return profiler_enable(&p->prof, max_launches);
+}
+int pxm_wav_profile_read(pxm_wav_plan_t p, double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes,
+                         double* gemm_flops) {
+  PXM_REQUIRE(p, "pxm_wav_profile_read: null plan");
+  return profiler_read(&p->prof.gemm, gemm_ms, gemm_launches, gemm_alg_bytes, gemm_flops);
+}
+int pxm_wav_profile_read_dft(pxm_wav_plan_t p, double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes) {
+  PXM_REQUIRE(p, "pxm_wav_profile_read_dft: null plan");
+  return profiler_read(&p->prof.dft, dft_ms, dft_launches, dft_alg_bytes, nullptr);
+}
+
+}  // extern "C"
+namespace pxm {
+__global__ void k_count_nonfinite(const double* __restrict__ x, int64_t n, unsigned long long* cnt) {
+  unsigned long long c = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (!isfinite(x[i])) ++c;
+  if (c) atomicAdd(cnt, c);
+}
+}  // namespace pxm
+extern "C" {
+
+int64_t pxm_wav_workspace_nonfinite(pxm_wav_plan_t p, pxm_stream_t stream) {
+  PXM_REQUIRE(p, "pxm_wav_workspace_nonfinite: null plan");
+  hipStream_t st = (hipStream_t)stream;
+  // (the scratch row block at the end of the workspace doubles as the counter: nothing of a finished step lives there)
+  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(p->ws + p->offS);
+  PXM_HIP(hipMemsetAsync(cnt, 0, sizeof(*cnt), st));
+  hipLaunchKernelGGL(k_count_nonfinite, dim3(1024), dim3(256), 0, st, p->ws, p->offS, cnt);
+  PXM_HIP(hipGetLastError());
+  unsigned long long h = 0;
+  PXM_HIP(hipMemcpyAsync(&h, cnt, sizeof(h), hipMemcpyDeviceToHost, st));
+  PXM_HIP(hipStreamSynchronize(st));
+  PXM_HIP(hipMemsetAsync(cnt, 0, sizeof(*cnt), st));
+  return (int64_t)h;
+}
+
+int pxm_tables_trim(void) {
+  const int64_t freed = tables_trim();
+  return (int)std::min<int64_t>(freed >> 20, 1 << 30);  // MiB released
 }
 
 static int wav_check(pxm_wav_plan_t p, const void* a, const void* b, int C, const char* who) {
@@ -642,7 +741,8 @@ static bool wav_can_fuse_dft(pxm_wav_plan_t p) {
 static int wav_rings_update_rings(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
   if (p->dft_group.d) {  // one grid for every scale, small scales first
     proto.chain_stride = p->ncoefs;
-    return dft3_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st);
+    if (p->dft_group.five) return dft5_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof);
+    return dft3_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof);
   }
   bool used[pxm_wav_plan_s::NSIDE];
   int rc = wav_fork(p, st, used);
@@ -668,9 +768,9 @@ int pxm_wav_synthesis(pxm_wav_plan_t p, const void* X, void* f, int C, pxm_strea
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
-  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
-  if ((rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   PxOut out;
   out.f = (double*)f;
   out.chain_stride = (int64_t)p->L * (2 * p->L - 1);
@@ -680,8 +780,8 @@ int pxm_wav_synthesis(pxm_wav_plan_t p, const void* X, void* f, int C, pxm_strea
 static int wav_synthesis_adjoint_impl(pxm_wav_plan_t p, const PxIn& in, const PxOut& out, int C, hipStream_t st) {
   int rc;
   if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offGL, p->ncol, C, st))) return rc;
-  if ((rc = run_tasks(p->adj_invadj, p->ws, p->ws, p->ncol, C, st))) return rc;
-  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->adj_invadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
+  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   return wav_rings_to_blocks(p, out, C, st);
 }
 
@@ -723,7 +823,7 @@ int pxm_wav_gradg_step(pxm_wav_plan_t p, const void* X, const void* preds, const
   out.seed = seed;
   out.chain0 = chain0;
   out.iter = iter;
-  out.iter_dev = iter_counter();
+  out.iter_dev = p->iter_dev;
   return wav_synthesis_adjoint_impl(p, in, out, C, (hipStream_t)stream);
 }
 
@@ -775,22 +875,22 @@ int pxm_wav_image_step(pxm_wav_plan_t p, const void* X, const void* data, const 
   out.seed = seed;
   out.chain0 = chain0;
   out.iter = iter;
-  out.iter_dev = iter_counter();
-  if ((rc = run_tasks(p->adj_invadj, p->ws, p->ws, p->ncol, C, st))) return rc;          // residual rings -> H_L
-  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;          // -> rings of every scale
+  out.iter_dev = p->iter_dev;
+  if ((rc = run_tasks(p->adj_invadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;          // residual rings -> H_L
+  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;          // -> rings of every scale
   if (wav_can_fuse_dft(p)) {
     if ((rc = wav_rings_update_rings(p, out, C, st))) return rc;                         // X' and its rings
   } else {
     if ((rc = wav_rings_to_blocks(p, out, C, st))) return rc;
     if ((rc = wav_blocks_to_rings(p, X_out, C, st))) return rc;
   }
-  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
-  if ((rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st))) return rc;             // rings of S X'
+  if ((rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;             // rings of S X'
   PxOut po;
   po.f = (double*)preds_out;
   po.chain_stride = (int64_t)p->L * (2 * p->L - 1);
-  if (p->dftL.use3 && p->fused_dft) {  // (only the wave path implements the residual epilogue)  // rings -> preds -> residual -> rings, one kernel
+  if ((p->dftL.use5 || p->dftL.use3) && p->fused_dft) {  // (only the wave paths implement the residual epilogue)  // rings -> preds -> residual -> rings, one kernel
     image_residual(po, data, invcov, invcov_complex);
     rc = launch_ring2px2ring(p->dftL, p->ws + p->offGL, p->ncol, po, C, st);
     return rc < 0 ? rc : (rc ? -1 : 0);
@@ -819,6 +919,7 @@ int pxm_wav_ring_set_data(pxm_wav_plan_t p, const void* data, pxm_stream_t strea
   int rc;
   if (p->use_gram && !p->gram.d) {  // first use: Gram tables + the two extra task lists
     if ((rc = get_tables(p->L, 0, 1u << TAB_GRAM, &p->TL))) return rc;
+    wav_hold(p, p->TL);
     std::vector<GemmTask> v;
     GemmFuse fz;
     fz.x2_base = p->offHB;
@@ -834,7 +935,7 @@ int pxm_wav_ring_set_data(pxm_wav_plan_t p, const void* data, pxm_stream_t strea
   in.f = (const double*)data;
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
   if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offGD, p->ncol, 1, st))) return rc;  // chain 0 of G_D
-  if (p->use_gram && (rc = run_tasks(p->adj_invadj_D, p->ws, p->ws, p->ncol, 1, st))) return rc;  // H_D = B^T DFT(data)
+  if (p->use_gram && (rc = run_tasks(p->adj_invadj_D, p->ws, p->ws, p->ncol, 1, st, GemmAffine(), &p->prof))) return rc;  // H_D = B^T DFT(data)
   p->have_data_rings = true;
   return 0;
 }
@@ -843,10 +944,10 @@ int pxm_wav_ring_set_data(pxm_wav_plan_t p, const void* data, pxm_stream_t strea
 static int wav_coeffs_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st, uint64_t* bump = nullptr) {
   int rc;
   if ((rc = wav_blocks_to_rings(p, X, C, st, bump))) return rc;
-  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   if (p->use_gram) return 0;
   if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
-  return run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st);
+  return run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);
 }
 
 int pxm_wav_ring_init(pxm_wav_plan_t p, const void* X, int C, pxm_stream_t stream) {
@@ -858,7 +959,7 @@ int pxm_wav_ring_preds(pxm_wav_plan_t p, void* preds, int C, pxm_stream_t stream
   int rc = wav_check(p, preds, preds, C, "pxm_wav_ring_preds");
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (p->use_gram && (rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st))) return rc;  // rings on demand
+  if (p->use_gram && (rc = run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;  // rings on demand
   PxOut out;
   out.f = (double*)preds;
   out.chain_stride = (int64_t)p->L * (2 * p->L - 1);
@@ -881,19 +982,19 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
     aff.ns = (double)(2 * p->L - 1);
     aff.wr = w_re;
     aff.wi = w_im;
-    aff.bump = const_cast<uint64_t*>(iter_counter());  // the step's iteration number = counter after this bump
-    if ((rc = run_tasks(p->gram, p->ws, p->ws, p->ncol, C, st, aff))) return rc;
+    aff.bump = p->iter_dev;  // the step's iteration number = counter after this bump
+    if ((rc = run_tasks(p->gram, p->ws, p->ws, p->ncol, C, st, aff, &p->prof))) return rc;
   } else {
-    if (iter_counter() && (rc = pxm_iter_counter_add(1, stream))) return rc;
+    if (p->iter_dev && (rc = pxm_wav_iter_counter_add(p, 1, stream))) return rc;
     const int Cp = p->ncol / 2;
     const int64_t total = (int64_t)(2 * p->L - 1) * p->Rp * Cp;
     hipLaunchKernelGGL(k_ring_residual, dim3(2048), dim3(256), 0, st, reinterpret_cast<const double2*>(p->ws + p->offGL),
                        reinterpret_cast<const double2*>(p->ws + p->offGD), reinterpret_cast<double2*>(p->ws + p->offGR),
                        total, Cp, (double)(2 * p->L - 1), double2{w_re, w_im});
     PXM_HIP(hipGetLastError());
-    if ((rc = run_tasks(p->adj_invadj_R, p->ws, p->ws, p->ncol, C, st))) return rc;
+    if ((rc = run_tasks(p->adj_invadj_R, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   }
-  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   PxOut out;
   out.f = (double*)X_out;
   out.X = (const double*)X;
@@ -906,14 +1007,14 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
   out.seed = seed;
   out.chain0 = chain0;
   out.iter = iter;
-  out.iter_dev = iter_counter();
+  out.iter_dev = p->iter_dev;
   if (wav_can_fuse_dft(p)) {
     // rings -> X_out -> rings of X_out in one kernel per scale, then the per-scale forward GEMMs
     if ((rc = wav_rings_update_rings(p, out, C, st))) return rc;
-    if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
+    if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
     if (p->use_gram) return 0;
     if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;
-    return run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st);
+    return run_tasks(p->syn_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);
   }
   if ((rc = wav_rings_to_blocks(p, out, C, st))) return rc;
   return wav_coeffs_to_rings(p, X_out, C, st);
@@ -927,8 +1028,8 @@ int pxm_wav_analysis(pxm_wav_plan_t p, const void* f, void* X, int C, pxm_stream
   in.f = (const double*)f;
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
   if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offGL, p->ncol, C, st))) return rc;
-  if ((rc = run_tasks(p->ana_fwd, p->ws, p->ws, p->ncol, C, st))) return rc;
-  if ((rc = run_tasks(p->ana_inv, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->ana_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
+  if ((rc = run_tasks(p->ana_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   PxOut out;
   out.f = (double*)X;
   return wav_rings_to_blocks(p, out, C, st);
@@ -939,9 +1040,9 @@ int pxm_wav_analysis_adjoint(pxm_wav_plan_t p, const void* X, void* f, int C, px
   if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
-  if ((rc = run_tasks(p->anadj_invadj, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->anadj_invadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   if (!p->fused_combine && (rc = launch_combine(p->comb_ana, p->ws, p->ws + p->offHL, st))) return rc;
-  if ((rc = run_tasks(p->anadj_fwdadj, p->ws, p->ws, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->anadj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   PxOut out;
   out.f = (double*)f;
   out.chain_stride = (int64_t)p->L * (2 * p->L - 1);

@@ -52,8 +52,33 @@ struct GemmTask {
 struct GemmAffine {
   double ns = 0, wr = 0, wi = 0;
   int on = 0;
+  int ncol_live = 1 << 30;   // columns >= ncol_live (padding chains) are written as zero: they must not iterate
   uint64_t* bump = nullptr;  // optional: workgroup 0 adds 1 to this counter before anything of this step reads it
 };
+
+// Live kernel timing of one plan (bench.py roofline leg): event pairs handed to hipExtLaunchKernelGGL, which
+// stamps them with the kernel's own start / end on the stream it runs on.  Owned by the plan -- no process state.
+struct Profiler {
+  struct Pool {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    double bytes = 0, flops = 0;
+  };
+  bool on = false;
+  Pool gemm, dft;
+  void next(Pool& p, hipEvent_t* start, hipEvent_t* stop, double alg_bytes, double flops) {
+    *start = *stop = nullptr;
+    if (!on || p.used >= p.ev.size()) return;
+    *start = p.ev[p.used].first;
+    *stop = p.ev[p.used].second;
+    p.bytes += alg_bytes;
+    p.flops += flops;
+    ++p.used;
+  }
+};
+int profiler_enable(Profiler* pr, int max_launches);  // 0 = off (events are released)
+int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* bytes, double* flops);
+void profiler_release(Profiler* pr);
 
 // extras of append_gemm_tasks for the fused wavelet combine
 struct GemmFuse {
@@ -71,11 +96,17 @@ struct ShtTables {
   size_t bytes[TAB_KINDS] = {0, 0, 0, 0, 0};
   std::vector<int64_t> m_off[TAB_KINDS];  // per stored-m offset (doubles) into d_tab[kind]
   std::vector<int> k_beg[TAB_KINDS];      // per stored-m contraction start (el->ring kinds) / first row tile*16 (ring->el)
+  int refs = 0;                           // plans holding this entry of the per-device cache
   int m_of(int i) const { return paired ? i : i - (L - 1); }
 };
 
-// builds (or returns cached) tables for (L, spin); kinds_mask selects which of the 4 to build
+// builds (or returns cached) tables for (L, spin); kinds_mask selects which of the 4 to build.  The cache is
+// per device and shared by plans: a plan retains every entry it uses once and releases it at teardown;
+// tables_trim() frees the entries nobody holds (pxm_tables_trim).
 int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out);
+void retain_tables(ShtTables* T);
+void release_tables(ShtTables* T);
+int64_t tables_trim();  // returns the bytes released
 
 // Append the tasks of one transform's GEMM stage.  x_base / y_base are offsets (doubles) of the
 // [2L-1][Rp][ncol] operand / output arrays inside the workspace; x rows may belong to a larger
@@ -101,7 +132,7 @@ void append_gemm_tasks_merged(const ShtTables& T, int kind, int ncol, const Gemm
 // nslab: 1 (unpaired), 2 (+-m pairs) or 4 (the list holds merged tasks)
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X, double* Y, int ncol,
                 int col0, int ct, double alg_bytes, double flops, hipStream_t stream,
-                const GemmAffine& aff = GemmAffine());
+                const GemmAffine& aff = GemmAffine(), Profiler* prof = nullptr);
 
 // algorithmic bytes of one ring-GEMM stage at bandlimit L for C chains:
 // ring table 8*L*L*(L+1)/2 [paired] or 8*L*L*L [all m] read once, harmonic side 16*C*L*L,
@@ -132,25 +163,31 @@ inline double gemm_alg_bytes(int L, bool paired, int C, int el_lo = 0) {
 }
 
 int gemm_rows_per_task(int ncol);
-void profile_dft_events(hipEvent_t* start, hipEvent_t* stop, double alg_bytes);  // live profiler, grouped DFT launches
 
 // ---- DFT stage ---------------------------------------------------------------
+// device tables of the eight-points-per-lane path (dft5.hip): one allocation, typed views into it
+struct Dft5Tables {
+  double* d_all = nullptr;
+  int r0 = 0;  // Mh / 64
+  const double *cE = nullptr, *cO = nullptr, *dO = nullptr, *tw1 = nullptr, *wt = nullptr, *bE = nullptr, *bO = nullptr;
+};
+
 struct DftPlan {
   int L = 0, n = 0, M = 0, logM = 0, Rp = 0;
   int R = 0;        // chains per workgroup
   int threads = 0;  // workgroup size
   size_t lds = 0;
   double *d_chirp = nullptr, *d_bhat = nullptr, *d_tw = nullptr;
-  // two-factor register-FFT path (dft2.hip), used when M <= 1024
-  bool use2 = false;
-  int R2 = 0, threads2 = 0;
-  size_t lds2 = 0;
-  double *d_bhatn = nullptr, *d_twm = nullptr;
   // wave path (dft3.hip): square Bluestein size M3 in {16, 64, 256, 1024}, used for every L <= 256
   bool use3 = false;
   int M3 = 0, R3 = 0, TR3 = 0;  // R3 chains x TR3 rings per workgroup
   size_t lds3 = 0;
   double *d_bhatn3 = nullptr, *d_twm3 = nullptr;
+  // eight-points-per-lane path (dft5.hip): M = 2 Mh, two half-size convolutions per wave, every L <= 256 (default)
+  bool use5 = false;
+  Dft5Tables t5;
+  int R5 = 0, TR5 = 0, split5 = 2;  // split5: waves per ring set (2: one half-size convolution per wave)
+  size_t lds5 = 0;
   // two-wave path (dft3.hip, k_*4): M = 2048 for 256 < L <= 512
   bool use4 = false;
   double *d_bhatn4 = nullptr, *d_twm4 = nullptr;  // FFT_2048(filter)/2048 natural order; 32 x 32 W_1024 table
@@ -187,16 +224,15 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
   const double* rinvcov = nullptr;  // [P] real or complex
   int rinvcov_complex = 0;
 };
-const uint64_t* iter_counter();  // registered by pxm_set_iter_counter, or null
 
-bool dft2_supported(int M);
-int dft2_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm);
-void dft2_geometry(int M, int n, int R, int* threads, size_t* lds);
-int dft2_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
-int dft2_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
+// device tables of the wave paths for a square (or M = 2 x square) Bluestein size: the filter transform in
+// natural order and the [N1][N1] twiddle matrix W_M^(k1 j2)
+int dft3_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm);
 // grouped launch of every scale's rings -> X' -> rings kernel (dft3.hip)
 struct Dft3GroupList {
   void* d = nullptr;  // device array of per-scale descriptors
+  bool five = false;  // descriptors of the eight-points-per-lane kernel (dft5.hip)
+  int split = 2;      // ... and its waves per ring set
   int n = 0, blocks = 0;
   size_t lds = 0;
   double px_elems = 0;  // sum over scales of bl (2 bl - 1): coefficients per chain slot
@@ -204,7 +240,19 @@ struct Dft3GroupList {
 int dft3_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
                       const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available
 void dft3_group_destroy(Dft3GroupList* g);
-int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st);
+int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
+                      Profiler* prof = nullptr);
+// eight-points-per-lane path (dft5.hip)
+int dft5_r0(int n);  // Mh / 64 for ring length n, 0 = not covered (n > 512)
+int dft5_make_tables(int n, Dft5Tables* t);
+int dft5_split();  // PXM_DFT_SPLIT at the time of the call (plan creation)
+void dft5_geometry(int n, int split, int* R, int* TR, size_t* lds);
+int dft5_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
+int dft5_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
+int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
+                      const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available
+int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
+                      Profiler* prof = nullptr);
 int dft4_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft4_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
 int dft3_size(int n);  // square Bluestein size of the wave path for ring length n, 0 = none
@@ -218,7 +266,7 @@ int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out
 // fused: rings -> out.f (with out's epilogue) and the rings of what was written, in place over G.
 // Returns 1 (nothing launched) when the plan's DFT size has no fused kernel.
 int launch_ring2px2ring(const DftPlan& p, double* G, int ncol, const PxOut& out, int C, hipStream_t stream);
-inline bool dft_can_fuse(const DftPlan& p) { return p.use2 || p.use3; }
+inline bool dft_can_fuse(const DftPlan& p) { return p.use5 || p.use3; }
 
 // ---- layout repack (public harmonic layout el^2+el+m <-> internal [m][el][c]) ----------
 int launch_lm_to_mel(const double* flm, double* H, int L, int Rp, int ncol, int C, int spin, hipStream_t stream);

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
           hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
           const double pu = __hiloint2double(hi, lo);
           v = (cl & 1) ? (aff.wr * u + aff.wi * pu) : (aff.wr * u - aff.wi * pu);
+          if (col0 + cin + cl >= aff.ncol_live) v = 0.0;  // padding chains stay at zero (they have no prox / damping)
         }
         if (row >= t.row_lo[grp] && row < t.row_hi[grp]) {
           const double rs = t.rs_off[grp] ? (X + t.rs_off[grp])[row] : 1.0;
@@ -197,87 +198,47 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   }
 }
 
-// ---- live profiler: event pairs around GEMM launches --------------------------------------
-static bool g_prof_on = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
-static size_t g_prof_used = 0;
-static double g_prof_bytes = 0, g_prof_flops = 0;
-
-// next event pair of the pool (or nulls when profiling is off): passed to hipExtLaunchKernelGGL, which
-// stamps them with the kernel's own start / end (what rocprofv3's kernel trace reports)
-static void profile_gemm_events(hipEvent_t* start, hipEvent_t* stop, double alg_bytes, double flops) {
-  *start = *stop = nullptr;
-  if (!g_prof_on || g_prof_used >= g_prof_pool.size()) return;
-  *start = g_prof_pool[g_prof_used].first;
-  *stop = g_prof_pool[g_prof_used].second;
-  g_prof_bytes += alg_bytes;
-  g_prof_flops += flops;
-  ++g_prof_used;
+// ---- live profiler: event pairs around GEMM / grouped-DFT launches, owned by a plan ----------------
+int profiler_enable(Profiler* pr, int max_launches) {
+  profiler_release(pr);
+  if (max_launches <= 0) return 0;
+  for (Profiler::Pool* p : {&pr->gemm, &pr->dft}) {
+    p->ev.resize((size_t)max_launches);
+    for (auto& e : p->ev) {
+      e.first = e.second = nullptr;
+      PXM_HIP(hipEventCreate(&e.first));
+      PXM_HIP(hipEventCreate(&e.second));
+    }
+  }
+  pr->on = true;
+  return 0;
 }
-// second pool: the grouped DFT launches of the ring-space step (dft3.hip)
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_dprof_pool;
-static size_t g_dprof_used = 0;
-static double g_dprof_bytes = 0;
-void profile_dft_events(hipEvent_t* start, hipEvent_t* stop, double alg_bytes) {
-  *start = *stop = nullptr;
-  if (!g_prof_on || g_dprof_used >= g_dprof_pool.size()) return;
-  *start = g_dprof_pool[g_dprof_used].first;
-  *stop = g_dprof_pool[g_dprof_used].second;
-  g_dprof_bytes += alg_bytes;
-  ++g_dprof_used;
+void profiler_release(Profiler* pr) {
+  pr->on = false;
+  for (Profiler::Pool* p : {&pr->gemm, &pr->dft}) {
+    for (auto& e : p->ev) {
+      deferred_event_destroy(e.first);
+      deferred_event_destroy(e.second);
+    }
+    p->ev.clear();
+    p->used = 0;
+    p->bytes = p->flops = 0;
+  }
 }
-int profile_read_dft(double* ms, int64_t* launches, double* bytes) {
+int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* bytes, double* flops) {
   double tot = 0;
-  for (size_t i = 0; i < g_dprof_used; ++i) {
-    PXM_HIP(hipEventSynchronize(g_dprof_pool[i].second));
+  for (size_t i = 0; i < p->used; ++i) {
+    PXM_HIP(hipEventSynchronize(p->ev[i].second));
     float t = 0;
-    PXM_HIP(hipEventElapsedTime(&t, g_dprof_pool[i].first, g_dprof_pool[i].second));
+    PXM_HIP(hipEventElapsedTime(&t, p->ev[i].first, p->ev[i].second));
     tot += t;
   }
   if (ms) *ms = tot;
-  if (launches) *launches = (int64_t)g_dprof_used;
-  if (bytes) *bytes = g_dprof_bytes;
-  g_dprof_used = 0;
-  g_dprof_bytes = 0;
-  return 0;
-}
-
-int profile_enable(int on) {
-  if (on && g_dprof_pool.empty()) {
-    g_dprof_pool.resize(4096);
-    for (auto& pr : g_dprof_pool) {
-      PXM_HIP(hipEventCreate(&pr.first));
-      PXM_HIP(hipEventCreate(&pr.second));
-    }
-  }
-  g_dprof_used = 0;
-  g_dprof_bytes = 0;
-  if (on && g_prof_pool.empty()) {
-    g_prof_pool.resize(16384);
-    for (auto& pr : g_prof_pool) {
-      PXM_HIP(hipEventCreate(&pr.first));
-      PXM_HIP(hipEventCreate(&pr.second));
-    }
-  }
-  g_prof_on = on != 0;
-  g_prof_used = 0;
-  g_prof_bytes = g_prof_flops = 0;
-  return 0;
-}
-int profile_read(double* ms, int64_t* launches, double* bytes, double* flops) {
-  double tot = 0;
-  for (size_t i = 0; i < g_prof_used; ++i) {
-    PXM_HIP(hipEventSynchronize(g_prof_pool[i].second));
-    float t = 0;
-    PXM_HIP(hipEventElapsedTime(&t, g_prof_pool[i].first, g_prof_pool[i].second));
-    tot += t;
-  }
-  if (ms) *ms = tot;
-  if (launches) *launches = (int64_t)g_prof_used;
-  if (bytes) *bytes = g_prof_bytes;
-  if (flops) *flops = g_prof_flops;
-  g_prof_used = 0;
-  g_prof_bytes = g_prof_flops = 0;
+  if (launches) *launches = (int64_t)p->used;
+  if (bytes) *bytes = p->bytes;
+  if (flops) *flops = p->flops;
+  p->used = 0;
+  p->bytes = p->flops = 0;
   return 0;
 }
 
@@ -302,12 +263,12 @@ int gemm_geom(int ncol) {
 int gemm_rows_per_task(int ncol) { return gemm_geom(ncol) == 41 ? 4 : 8; }
 
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X, double* Y, int ncol,
-                int col0, int ct, double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff) {
+                int col0, int ct, double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff, Profiler* prof) {
   if (n_tasks == 0) return 0;
   const int geom = gemm_geom(ncol);
   dim3 grid(n_tasks), block(geom == 81 ? 512 : 256);  // 41: 4 waves x 1 row tile (tasks of 4 row tiles)
-  hipEvent_t ev0, ev1;
-  profile_gemm_events(&ev0, &ev1, alg_bytes, flops);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (prof) prof->next(prof->gemm, &ev0, &ev1, alg_bytes, flops);
 #define PXM_GEMM_LAUNCH(A, B)                                                                                         \
   if (geom == 81) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 8, 1>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
   else if (geom == 41) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 1>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
@@ -453,18 +414,6 @@ __global__ void k_tile_table(const double* __restrict__ D, double* __restrict__ 
   out[((int64_t)rt * nk2 + kk2) * 128 + threadIdx.x] = v;
 }
 
-}  // namespace pxm
-extern "C" {
-int pxm_profile_enable(int on) { return pxm::profile_enable(on); }
-int pxm_profile_read(double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes, double* gemm_flops) {
-  return pxm::profile_read(gemm_ms, gemm_launches, gemm_alg_bytes, gemm_flops);
-}
-int pxm_profile_read_dft(double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes) {
-  return pxm::profile_read_dft(dft_ms, dft_launches, dft_alg_bytes);
-}
-}
-namespace pxm {
-
 static std::mutex g_tab_mutex;
 static std::map<std::pair<int, int>, ShtTables*> g_tab_cache;
 
@@ -565,6 +514,34 @@ int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out) {
   }
   *out = T;
   return 0;
+}
+
+void retain_tables(ShtTables* T) {
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  if (T) ++T->refs;
+}
+void release_tables(ShtTables* T) {
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  if (T && T->refs > 0) --T->refs;
+}
+int64_t tables_trim() {
+  std::lock_guard<std::mutex> lock(g_tab_mutex);
+  int64_t freed = 0;
+  for (auto it = g_tab_cache.begin(); it != g_tab_cache.end();) {
+    ShtTables* T = it->second;
+    if (T->refs > 0) {
+      ++it;
+      continue;
+    }
+    for (int k = 0; k < TAB_KINDS; ++k) {
+      if (T->d_tab[k]) deferred_free(T->d_tab[k]);
+      freed += (int64_t)T->bytes[k];
+    }
+    delete T;
+    it = g_tab_cache.erase(it);
+  }
+  drain_deferred();
+  return freed;
 }
 
 }  // namespace pxm

@@ -39,10 +39,13 @@ def init(backend=None, device_id=None):
 
 
 def barrier():
-    if dist.is_initialized():
-        dist.barrier()
+    """device idle on every rank, then the ranks aligned (and the barrier's own work drained)"""
     if torch.cuda.is_available():
         torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
 
 
 def max_over_ranks(value):

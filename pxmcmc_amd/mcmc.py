@@ -21,8 +21,6 @@ Extensions (all optional, defaults reproduce the reference's one-chain behaviour
 
 SKROCK (pxmcmc/mcmc.py:292-383) is out of scope.
 """
-import gc
-
 import numpy as np
 import torch
 from scipy.stats import laplace
@@ -323,11 +321,15 @@ class MYULA(PxMCMC):
         return ops.as_device(w)
 
     # ---- HIP-graph engine for the fused wavelet path ----------------------------------------------
+    _GRAPH_PAIRS = 4  # iterations per graph replay = 2 * _GRAPH_PAIRS (fewer, longer launches of the host)
+
     def _graph_ok(self):
-        return self._fused_wav and self.rng == "philox" and self.use_graph and not bool(self.complex)
+        return self._fused_wav and self.rng == "philox" and self.use_graph
 
     def _engine_start(self, X, preds, i0):
-        """Static ping-pong state (XA, XB, P), a device iteration counter and a captured 2-iteration graph."""
+        """Static ping-pong state (XA, XB, P), a device iteration counter and a captured graph of 2 * _GRAPH_PAIRS
+        iterations."""
+        self._engine_stop()  # an engine left over from an interrupted run gives its counter / buffers back first
         f = self.forward
         plan = f.transform._plan
         data = f.data_dev_c128
@@ -338,10 +340,11 @@ class MYULA(PxMCMC):
             X, preds = self._pack(X), self._pack(preds)
         eng["plan"] = plan
         eng["XA"], eng["XB"], eng["P"] = X.clone(), torch.empty_like(X), preds.clone()
-        eng["cnt"] = ops.IterCounter(i0)
+        eng["cnt"] = ops.IterCounter(plan, i0)  # per-plan device counter: the steps below read it at execution time
         eng["side"] = "A"  # which buffer holds the current state
         args = (data, f.invcov.diag, self.prior.T_dev, float(self.delta), self.lmda)
-        kw = dict(noise_complex=False, seed=self.seed, chain0=self.chain_offset, it=0, pairs=self._pairs)
+        # params.complex: randn + 1j randn (pxmcmc/mcmc.py:193-195) -> PXM_MODE_CPLX_NOISE in the fused epilogues
+        kw = dict(noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=0, pairs=self._pairs)
         # Uniform inverse covariance (scalar sig_d): the image-space residual is applied on the rings and the
         # L-level iDFT/DFT pair between forward() and calc_gradg() drops out (pxm_wav_ring_step); preds is
         # then materialised only when it is observed.
@@ -369,7 +372,7 @@ class MYULA(PxMCMC):
                 eng["cnt"].add(1)
 
         eng["one"] = one
-        eng["graph"] = None
+        eng["graph"] = eng["graph_long"] = None
         if self._graph_ok():
             try:
                 stream = torch.cuda.Stream()
@@ -386,23 +389,22 @@ class MYULA(PxMCMC):
                     plan.ring_init(eng["XA"])
                 else:
                     plan.image_init(eng["P"], data, f.invcov.diag)
-                g = torch.cuda.CUDAGraph()
-                # no garbage collection while capturing: a collected plan / graph of an earlier run would
-                # call hipFree / hipStreamDestroy in the middle of the capture
-                gc.collect()
-                gc_was_on = gc.isenabled()
-                gc.disable()
-                try:
-                    with torch.cuda.graph(g):
-                        one(eng["XA"], eng["XB"])
-                        one(eng["XB"], eng["XA"])
-                finally:
-                    if gc_was_on:
-                        gc.enable()
+                # two graphs: 2 iterations (short advances between observable events) and 2 * _GRAPH_PAIRS
+                # iterations (long advances: fewer launches by the host).  A plan torn down while a capture is in
+                # progress (the garbage collector may run at any point) only queues its device frees: the
+                # library empties the queue at the end of the scope.
+                graphs = []
+                for pairs in (1, self._GRAPH_PAIRS):
+                    g = torch.cuda.CUDAGraph()
+                    with ops.capture_scope(), torch.cuda.graph(g):
+                        for _ in range(pairs):
+                            one(eng["XA"], eng["XB"])
+                            one(eng["XB"], eng["XA"])
+                    graphs.append(g)
                 # capture does not execute: state is still (X, preds, i0)
-                eng["graph"] = g
+                eng["graph"], eng["graph_long"] = graphs
             except Exception as exc:  # capture unsupported in this environment: eager stepping, same results
-                eng["graph"] = None
+                eng["graph"] = eng["graph_long"] = None
                 eng["graph_error"] = repr(exc)
                 eng["XA"].copy_(X)
                 eng["P"].copy_(preds)
@@ -414,13 +416,18 @@ class MYULA(PxMCMC):
         return eng
 
     def _engine_advance(self, k):
-        """advance the engine's state by k MYULA iterations (graph replays of 2 + eager remainder)"""
+        """advance the engine's state by k MYULA iterations (graph replays of 2 * _GRAPH_PAIRS + eager remainder)"""
         eng = self._eng
         if eng["side"] == "B" and k > 0:  # realign so that replays start from XA
             eng["one"](eng["XB"], eng["XA"])
             eng["side"] = "A"
             k -= 1
         if eng["graph"] is not None:
+            per = 2 * self._GRAPH_PAIRS
+            while k >= per:
+                eng["graph_long"].replay()
+                eng["P_valid"] = not eng["ring"]
+                k -= per
             while k >= 2:
                 eng["graph"].replay()
                 eng["P_valid"] = not eng["ring"]
@@ -451,7 +458,7 @@ class MYULA(PxMCMC):
         if eng is not None and eng.get("cnt") is not None:
             eng["cnt"].close()
             eng["graph"] = eng["graph"] is not None  # keep the flags (ring, pairs, graph) for inspection
-            for k in ("one", "XA", "XB", "P", "plan", "cnt", "cnt0"):
+            for k in ("one", "XA", "XB", "P", "plan", "cnt", "cnt0", "graph_long"):
                 eng[k] = None
 
     def run(self, start_point=None):
@@ -618,6 +625,7 @@ class PxMALA(MYULA):
             if k == self._CHUNK - 1:
                 acc_chunks.append(acc_buf.cpu().numpy().copy())
                 delta_chunks.append(delta_buf.cpu().numpy().copy())
+                n_acc += int(acc_chunks[-1][:, 0].sum())  # running count of chain 0 (progress print)
 
             gap_it = i >= self.nburn and (self.ngap == 0 or (i - self.nburn) % self.ngap == 0)
             if gap_it:
@@ -628,8 +636,8 @@ class PxMALA(MYULA):
                                    chains=chains if C > 1 else None)
                     j[chains] += 1
             if self.verbosity > 0 and (i + 1) % self.verbosity == 0:
-                done = acc_chunks + [acc_buf[: k + 1].cpu().numpy()]
-                rate = np.concatenate(done)[:, 0].mean()
+                pending = 0 if k == self._CHUNK - 1 else int(acc_buf[: k + 1, 0].sum().item())  # rows not yet flushed
+                rate = (n_acc + pending) / (i + 1)
                 self._print_progress(
                     int(j[0]) - 1, float(logpiXc[0].real), L2=float(L2Xc[0].real), prior=float(priorXc[0]), acceptanceRate=rate
                 )

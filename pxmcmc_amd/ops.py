@@ -171,6 +171,11 @@ def randn(n, C_=1, complex_=False, seed=0, chain0=0, it=0):
     return out
 
 
+def _red_scratch(C_, dev):
+    """caller-owned scratch of the two-stage reductions (torch's caching allocator: stream-ordered reuse)"""
+    return torch.empty(int(lib.pxm_reduce_scratch_doubles(int(C_))), dtype=_REAL, device=dev)
+
+
 def reduce_l1(X, w=None):
     """sum |w X| per chain (pxmcmc/prior.py:28-35,83-84) -> float64 [C]."""
     x, _ = _batched(as_device(X))
@@ -178,7 +183,7 @@ def reduce_l1(X, w=None):
     if wv is not None and wv.numel() != x.shape[1]:
         raise ValueError("weight length mismatch")
     out = torch.empty(x.shape[0], dtype=_REAL, device=x.device)
-    check(lib.pxm_reduce_l1(_p(x), _p(wv), _p(out), x.shape[1], x.shape[0], _dt(x), _stream()))
+    check(lib.pxm_reduce_l1(_p(x), _p(wv), _p(out), _p(_red_scratch(x.shape[0], x.device)), x.shape[1], x.shape[0], _dt(x), _stream()))
     return out
 
 
@@ -193,7 +198,7 @@ def reduce_l2(preds, data, invcov):
     if d.numel() != n or ic.numel() != n:
         raise ValueError("data / invcov length mismatch")
     out = torch.empty(p.shape[0], dtype=_CPLX, device=p.device)
-    check(lib.pxm_reduce_l2(_p(p), _p(d), _p(ic), int(ic.is_complex()), _p(out), n, p.shape[0], _dt(p), _stream()))
+    check(lib.pxm_reduce_l2(_p(p), _p(d), _p(ic), int(ic.is_complex()), _p(out), _p(_red_scratch(p.shape[0], p.device)), n, p.shape[0], _dt(p), _stream()))
     return out
 
 
@@ -205,7 +210,7 @@ def logtransition(X1, X2, proxf, gradg, delta, lmda):
     g, _ = _batched(as_device(gradg, x1.dtype))
     dd, ds = _delta_args(delta, x1.shape[0], x1.device)
     out = torch.empty(x1.shape[0], dtype=_CPLX, device=x1.device)
-    check(lib.pxm_logtransition(_p(x1), _p(x2), _p(px), _p(g), _p(dd), ds, float(lmda), _p(out), x1.shape[1], x1.shape[0], _dt(x1), _stream()))
+    check(lib.pxm_logtransition(_p(x1), _p(x2), _p(px), _p(g), _p(dd), ds, float(lmda), _p(out), _p(_red_scratch(x1.shape[0], x1.device)), x1.shape[1], x1.shape[0], _dt(x1), _stream()))
     return out
 
 
@@ -459,25 +464,44 @@ class WavPlan:
     def table_bytes(self, op):
         return int(lib.pxm_wav_table_bytes(self._h, op))
 
+    def workspace_nonfinite(self):
+        """test aid: non-finite values anywhere in the plan's workspace (padding chains' columns included)"""
+        return int(check(lib.pxm_wav_workspace_nonfinite(self._h, _stream())))
+
+    # ---- live kernel timing of this plan (bench.py roofline leg) ----
+    def profile_enable(self, max_launches):
+        check(lib.pxm_wav_profile_enable(self._h, int(max_launches)))
+
+    def profile_read(self):
+        """(gemm: ms, launches, algorithmic bytes, flops), (grouped phi-DFT: ms, launches, algorithmic bytes)"""
+        ms, nl, nb, nf = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        check(lib.pxm_wav_profile_read(self._h, C.byref(ms), C.byref(nl), C.byref(nb), C.byref(nf)))
+        dms, dnl, dnb = C.c_double(), C.c_int64(), C.c_double()
+        check(lib.pxm_wav_profile_read_dft(self._h, C.byref(dms), C.byref(dnl), C.byref(dnb)))
+        return (ms.value, nl.value, nb.value, nf.value), (dms.value, dnl.value, dnb.value)
+
 
 # ---- device-resident iteration counter (HIP-graph replay) -----------------------------------
 class IterCounter:
-    """Registers a device int64 as the Philox iteration counter for the lifetime of the object."""
+    """A device int64 registered as the Philox iteration counter of ONE wavelet plan for the lifetime of the
+    object (per-plan state: two samplers in one process never share a counter)."""
 
-    def __init__(self, start=0):
+    def __init__(self, plan, start=0):
+        self.plan = plan
         self.t = torch.full((1,), int(start), dtype=torch.int64, device=device())
-        check(lib.pxm_set_iter_counter(C.c_void_p(self.t.data_ptr())))
+        check(lib.pxm_wav_set_iter_counter(plan._h, C.c_void_p(self.t.data_ptr())))
         self.active = True
 
     def set(self, value):
         self.t.fill_(int(value))
 
     def add(self, inc=1):
-        check(lib.pxm_iter_counter_add(int(inc), _stream()))
+        check(lib.pxm_wav_iter_counter_add(self.plan._h, int(inc), _stream()))
 
     def close(self):
         if self.active:
-            lib.pxm_set_iter_counter(C.c_void_p(0))
+            if getattr(self.plan, "_h", None):
+                lib.pxm_wav_set_iter_counter(self.plan._h, C.c_void_p(0))
             self.active = False
 
     def __del__(self):
@@ -485,6 +509,19 @@ class IterCounter:
             self.close()
         except Exception:
             pass
+
+
+class capture_scope:
+    """Tells the library that a stream capture is (about to be) in progress: plan teardown inside the scope only
+    queues its frees (include/pxmcmc_amd.h, pxm_capture_begin / pxm_capture_end)."""
+
+    def __enter__(self):
+        check(lib.pxm_capture_begin())
+        return self
+
+    def __exit__(self, *exc):
+        lib.pxm_capture_end()
+        return False
 
 
 # ---- host helpers ------------------------------------------------------------------------

@@ -1,0 +1,308 @@
+"""
+GPU parity AT THE BASELINE SIZES and on every kernel path those sizes select, against the oracle
+(HIP vs numpy restatement, never HIP vs HIP):
+
+* L = 256 (M = 1024 one-wave phi-DFT, paired spin-0 ring tables, Gram table, support-cut task lists);
+* 256 < L <= 512 (two-wave phi-DFT at M = 2048) with spin 2 (unpaired tables, n_m = 2L-1);
+* BASELINE.json configs[1] exactly (L=64, B=1.5, J_min=2, one chain, complex data = the reference-literal
+  topography set-up with its complex-variance rule, pxmcmc/forward.py:81-82);
+* configs[4] at full size (L=512 weak lensing + PxMALA): size-independent properties.
+
+Tolerances (fp64): transforms 1e-11 of the data scale; a MYULA state after K chained iterations 1e-9 of its scale
+(the oracle's FFT / einsum summation order differs from the kernels').
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-11
+
+
+def _quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1.0, np.abs(b).max())
+
+
+def _bandlimited_real_field(L, seed, slope=-1.0):
+    """real band-limited MW image from Hermitian-symmetric flm (reference tests/conftest.py:34-44), unit RMS"""
+    from oracle import ssht
+
+    rng = np.random.default_rng(seed)
+    flm = np.zeros(L * L, dtype=complex)
+    for el in range(L):
+        amp = (1.0 + el) ** slope
+        flm[el * el + el] = amp * rng.normal()
+        m = np.arange(1, el + 1)
+        v = amp * (rng.normal(size=el) + 1j * rng.normal(size=el)) / np.sqrt(2)
+        flm[el * el + el + m] = v
+        flm[el * el + el - m] = (-1.0) ** m * np.conj(v)
+    f = ssht.inverse(flm, L, 0)
+    assert np.abs(f.imag).max() < 1e-10 * np.abs(f.real).max()
+    f = f.real.reshape(-1)
+    return f / np.sqrt(np.mean(f ** 2)), rng
+
+
+# ---- (i) the four SHT operators -----------------------------------------------------------------------------
+@pytest.mark.parametrize("L,spin,C", [(256, 0, 3), (272, 2, 2)])
+def test_sht_four_ops_match_oracle_full_size(L, spin, C):
+    """L=256 spin 0: the benchmark's table / DFT path.  L=272 spin 2: two waves per ring (M = 2048) and
+    unpaired tables -- the path BASELINE configs[4] (L=512 weak lensing) takes."""
+    from oracle import ssht
+    from pxmcmc_amd import ops
+
+    rng = np.random.default_rng(L + spin)
+    plan = ops.ShtPlan(L, spin, max_chains=C)
+    flm = rng.normal(size=(C, L * L)) + 1j * rng.normal(size=(C, L * L))
+    flm[:, : spin * spin] = 0
+    f = rng.normal(size=(C, L * (2 * L - 1))) + 1j * rng.normal(size=(C, L * (2 * L - 1)))
+    T = ssht.get_transform(L, spin)
+    for name, arg, fn in (
+        ("inverse", flm, lambda x: T.inverse(x).ravel()),
+        ("forward_adjoint", flm, lambda x: T.forward_adjoint(x).ravel()),
+        ("forward", f, T.forward),
+        ("inverse_adjoint", f, T.inverse_adjoint),
+    ):
+        got = getattr(plan, name)(arg).cpu().numpy()
+        ref = np.stack([fn(x) for x in arg])
+        assert _rel(got, ref) < TOL, (name, _rel(got, ref))
+
+
+# ---- (ii) the fused MYULA iteration of the benchmark ---------------------------------------------------------
+def _plan_steps(path, plan, X0, data_c, invcov, T_dev, delta, lmda, noises, pairs):
+    """K MYULA iterations through the very C-ABI calls the stepping engine makes (pxmcmc_amd/mcmc.py
+    _engine_start), with injected noise.  Returns (X, preds) in the plan's slot layout."""
+    import torch
+
+    X = X0.clone()
+    out = torch.empty_like(X)
+    P = torch.empty((X.shape[0], plan.npix), dtype=torch.complex128, device=X.device)
+    if path == "ring":
+        w = complex(invcov[0].item())
+        plan.ring_set_data(data_c)
+        plan.ring_init(X)
+        for nz in noises:
+            plan.ring_step(X, w, T_dev, delta, lmda, noise=nz, out=out, pairs=pairs)
+            X, out = out, X
+        plan.ring_preds(X.shape[0], out=P)
+    else:
+        plan.synthesis(X, out=P)
+        plan.image_init(P, data_c, invcov)
+        for nz in noises:
+            plan.image_step(X, data_c, invcov, T_dev, delta, lmda, noise=nz, out=out, preds_out=P, pairs=pairs)
+            X, out = out, X
+    return X, P
+
+
+@pytest.mark.parametrize("path", ["ring", "image"])
+def test_fused_myula_steps_match_oracle_L256_16chains(path):
+    """BASELINE configs[2]: L=256, B=2, J_min=2, 16 chains as 8 real pairs, K iterations with injected noise
+    through the ring-space + Gram step (scalar sig_d) and the image-space step (vector sig_d), against
+    oracle.pxmcmc_np.myula_run chain by chain (pxmcmc/mcmc.py:157-164)."""
+    import torch
+
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd import ops
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min, C, K = 256, 2, 2, 16, 3
+    P = L * (2 * L - 1)
+    truth, rng = _bandlimited_real_field(L, seed=2)
+    sig = 0.05
+    data = truth + sig * rng.normal(size=P)
+    sig_d = sig if path == "ring" else sig * (1 + 0.5 * np.sin(np.arange(P) * 0.01))
+    lmda, delta, mu = 1e-6, 1e-7, 1.0
+    op = SphericalWaveletTransformOperator(data, sig_d, "synthesis", L, B, J_min, max_chains=C)
+    reg = S2_Wavelets_L1("synthesis", None, None, lmda * mu, L=L, B=B, J_min=J_min)
+    N = op.nparams
+    X0 = rng.normal(size=(C, N)) * 1e-3
+    noise = rng.normal(size=(K, C, N))
+    plan = ops.WavPlan(L, B, J_min, max_chains=C // 2)
+    d = op.data_dev.to(torch.float64)
+    Xp = torch.complex(ops.as_device(X0[0::2]), ops.as_device(X0[1::2]))
+    Xk, Pk = _plan_steps(path, plan, Xp, torch.complex(d, d).contiguous(), op.invcov.diag, reg.T_dev, delta, lmda,
+                         [ops.as_device(noise[k]) for k in range(K)], pairs=True)
+    Xk, Pk = Xk.cpu().numpy(), Pk.cpu().numpy()
+    T = ref.SphericalWaveletTransform(L, B, J_min)
+    oop = ref.ForwardOperator(data, sig_d, "synthesis", T, ref.Identity(P, P), T.ncoefs)
+    oreg = ref.S2_Wavelets_L1("synthesis", None, None, lmda * mu, L, B, J_min)
+    np.testing.assert_allclose(reg.map_weights, oreg.map_weights, rtol=1e-12)
+    for c in (0, 5, 14, 15):
+        out = ref.myula_run(oop, oreg, lmda, delta, mu, 1, K - 1, 1, X0[c].astype(complex), lambda i: noise[i][c])
+        got = Xk[c // 2].real if c % 2 == 0 else Xk[c // 2].imag
+        gp = Pk[c // 2].real if c % 2 == 0 else Pk[c // 2].imag
+        assert np.abs(out["X"].imag).max() < 1e-12 * np.abs(out["X"]).max()
+        sx, sp = np.abs(out["X"]).max(), np.abs(out["preds"]).max()
+        assert np.abs(got - out["X"].real).max() < 1e-9 * sx, (c, np.abs(got - out["X"].real).max() / sx)
+        assert np.abs(gp - out["preds"].real).max() < 1e-9 * sp, (c, np.abs(gp - out["preds"].real).max() / sp)
+
+
+def test_fused_myula_complex_slots_match_oracle_L256():
+    """the reference layout (one complex128 slot per chain, complex data => complex-variance rule) at L=256:
+    ring-space + Gram step with a COMPLEX uniform inverse covariance, 3 chains (padding columns live)."""
+    import torch
+
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd import ops
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min, C, K = 256, 2, 2, 3, 2
+    P = L * (2 * L - 1)
+    truth, rng = _bandlimited_real_field(L, seed=4)
+    data = (truth + 0.05 * rng.normal(size=P)).astype(complex)
+    lmda, delta, mu = 1e-6, 1e-7, 1.0
+    op = SphericalWaveletTransformOperator(data, 0.05, "synthesis", L, B, J_min, max_chains=C)
+    assert op.invcov.diag.is_complex()
+    reg = S2_Wavelets_L1("synthesis", None, None, lmda * mu, L=L, B=B, J_min=J_min)
+    N = op.nparams
+    X0 = rng.normal(size=(C, N)) * 1e-3
+    noise = rng.normal(size=(K, C, N))
+    plan = op.transform._plan
+    Xk, Pk = _plan_steps("ring", plan, ops.as_device(X0, torch.complex128), op.data_dev_c128, op.invcov.diag, reg.T_dev,
+                         delta, lmda, [ops.as_device(noise[k]) for k in range(K)], pairs=False)
+    Xk, Pk = Xk.cpu().numpy(), Pk.cpu().numpy()
+    T = ref.SphericalWaveletTransform(L, B, J_min)
+    oop = ref.ForwardOperator(data, 0.05, "synthesis", T, ref.Identity(P, P), T.ncoefs)
+    oreg = ref.S2_Wavelets_L1("synthesis", None, None, lmda * mu, L, B, J_min)
+    for c in (0, 2):
+        out = ref.myula_run(oop, oreg, lmda, delta, mu, 1, K - 1, 1, X0[c].astype(complex), lambda i: noise[i][c])
+        assert np.abs(out["X"].imag).max() > 1e-6 * np.abs(out["X"]).max()  # the quirk makes the state complex
+        assert np.abs(Xk[c] - out["X"]).max() < 1e-9 * np.abs(out["X"]).max()
+        assert np.abs(Pk[c] - out["preds"]).max() < 1e-9 * np.abs(out["preds"]).max()
+
+
+# ---- (iii) weak lensing on the L > 256 kernel path --------------------------------------------------------------
+def test_weaklensing_matches_oracle_two_wave_path():
+    """WeakLensing.forward / adjoint (pxmcmc/measurements.py:221-240) at L = 272: spin-0 and spin-2 transforms on
+    the two-wave DFT + unpaired spin-2 tables, with a mask and galaxy counts, vs oracle.pxmcmc_np.WeakLensing."""
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd.measurements import WeakLensing
+
+    L, C = 272, 2
+    rng = np.random.default_rng(7)
+    theta = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+    mask = np.ones((L, 2 * L - 1), dtype=int)
+    mask[np.abs(90 - np.degrees(theta)) < 10] = 0
+    mask[:, 100:140] = 0
+    ngal = rng.integers(1, 40, size=mask.shape).astype(float)
+    op = WeakLensing(L, mask=mask, ngal=ngal, max_chains=C)
+    oop = ref.WeakLensing(L, mask=mask, ngal=ngal)
+    assert op.ndata == oop.ndata
+    kappa = rng.normal(size=(C, op.npix)) + 1j * rng.normal(size=(C, op.npix))
+    gamma = rng.normal(size=(C, op.ndata)) + 1j * rng.normal(size=(C, op.ndata))
+    k_to_g, g_to_k = op.forward(kappa), op.adjoint(gamma)
+    for c in range(C):
+        r = oop.forward(kappa[c])
+        assert np.abs(k_to_g[c] - r).max() < TOL * np.abs(r).max() * 10
+        r = oop.adjoint(gamma[c])
+        assert np.abs(g_to_k[c] - r).max() < TOL * np.abs(r).max() * 10
+    a, b = np.vdot(kappa[0], g_to_k[0]), np.vdot(k_to_g[0], gamma[0])  # <k, A^H g> == <A k, g>
+    assert abs(a - b) < 1e-10 * abs(a)
+
+
+# ---- (iv) BASELINE configs[1] exactly ---------------------------------------------------------------------------
+@pytest.mark.parametrize("path", ["sampler", "ring"])
+def test_config2_topography_literal_matches_oracle(path):
+    """L=64, B=1.5, J_min=2 (experiments/earthtopography/main.py:72-74), one chain, COMPLEX data as alm2map_mw
+    returns it (:82) => complex variance (forward.py:81-82), lmda = 1e-6 (:128), S2_Wavelets_L1 threshold.
+    'sampler': MYULA.run with the reference's numpy noise order (gradg_step + synthesis kernels);
+    'ring': the engine's ring-space + Gram calls with the same noise."""
+    import torch
+
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd import ops
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min, K = 64, 1.5, 2, 6
+    P = L * (2 * L - 1)
+    truth, rng = _bandlimited_real_field(L, seed=1, slope=-2.0)
+    data = (truth + 0.05 * rng.normal(size=P)).astype(complex)
+    lmda, delta, mu, sig = 1e-6, 2e-7, 1.0, 0.05
+    op = SphericalWaveletTransformOperator(data, sig, "synthesis", L, B, J_min)
+    assert op.nparams == 28390 and P == 8128
+    reg = S2_Wavelets_L1("synthesis", op.transform.inverse, op.transform.inverse_adjoint, lmda * mu, L=L, B=B, J_min=J_min)
+    N = op.nparams
+    X0 = rng.normal(size=N) * 1e-3
+    T = ref.SphericalWaveletTransform(L, B, J_min)
+    oop = ref.ForwardOperator(data, sig, "synthesis", T, ref.Identity(P, P), T.ncoefs)
+    oreg = ref.S2_Wavelets_L1("synthesis", None, None, lmda * mu, L, B, J_min)
+    np.random.seed(11)
+    noise = np.stack([np.random.randn(N) for _ in range(K)])
+    out = ref.myula_run(oop, oreg, lmda, delta, mu, K, 0, 1, X0.astype(complex), lambda i: noise[i], cplx=True)
+    if path == "sampler":
+        p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=K, nburn=0, ngap=1, verbosity=0)
+        s = MYULA(op, reg, p, rng="numpy")
+        np.random.seed(11)
+        _quiet(s.run, start_point=X0)
+        assert s._fused_wav and not s._pairs
+        np.testing.assert_allclose(s.chain, out["chain"].real, rtol=1e-9, atol=1e-9 * np.abs(out["chain"]).max())
+        np.testing.assert_allclose(s.logPi, np.real(out["logPi"]), rtol=1e-9)
+        got = s.X_curr[0].cpu().numpy()
+    else:
+        Xk, _ = _plan_steps("ring", op.transform._plan, ops.as_device(X0[None], torch.complex128), op.data_dev_c128,
+                            op.invcov.diag, reg.T_dev, delta, lmda, [ops.as_device(noise[k][None]) for k in range(K)],
+                            pairs=False)
+        got = Xk[0].cpu().numpy()
+    assert np.abs(got - out["X"]).max() < 1e-9 * np.abs(out["X"]).max()
+
+
+# ---- (v) BASELINE configs[4] at full size: properties ---------------------------------------------------------------
+def test_config5_L512_weaklensing_pxmala_properties():
+    """L=512, B=2, J_min=2 (experiments/weaklensing/main.py:85-87), weak-lensing measurement with a mask, PxMALA:
+    adjoint dot tests of the wavelet synthesis and of the weak-lensing operator at full size, batch == single
+    chains, finite output, delta within its clip range."""
+    import torch
+
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    L, B, J_min, C = 512, 2, 2, 2
+    tr = SphericalWaveletTransform(L, B, J_min, max_chains=C)
+    assert tr.ncoefs == 1221796
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(C, tr.ncoefs, dtype=torch.complex128, generator=g).cuda()
+    f = torch.randn(C, L * (2 * L - 1), dtype=torch.complex128, generator=g).cuda()
+    lhs = torch.sum(torch.conj(f) * tr.inverse(X), dim=1)
+    rhs = torch.sum(torch.conj(tr.inverse_adjoint(f)) * X, dim=1)
+    assert float(((lhs - rhs).abs() / lhs.abs()).max()) < 1e-11
+    theta = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+    mask = np.ones((L, 2 * L - 1), dtype=int)
+    mask[np.abs(90 - np.degrees(theta)) < 10] = 0
+    wl = WeakLensing(L, mask, ngal=np.full(mask.shape, 30.0), max_chains=C)
+    kap = torch.randn(C, wl.npix, dtype=torch.complex128, generator=g).cuda()
+    gam = torch.randn(C, wl.ndata, dtype=torch.complex128, generator=g).cuda()
+    a = torch.sum(torch.conj(gam) * wl.forward(kap), dim=1)
+    b = torch.sum(torch.conj(wl.adjoint(gam)) * kap, dim=1)
+    assert float(((a - b).abs() / a.abs()).max()) < 1e-11
+    # batch == single chains on the operator (the chains of a batch never mix)
+    one = wl.forward(kap[1])
+    assert float((one - wl.forward(kap)[1]).abs().max()) <= 1e-12 * float(one.abs().max())
+    data = (wl.forward(torch.randn(1, wl.npix, dtype=torch.complex128, generator=g).cuda())[0]).cpu().numpy()
+    op = ForwardOperator(data, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+    p = PxMCMCParams(nsamples=2, nburn=2, ngap=1, delta=1e-6, lmda=5e-7, verbosity=0)
+    reg = S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, p.lmda * p.mu, L=L, B=B, J_min=J_min)
+    s = PxMALA(op, reg, p, tune_delta=True, nchains=C, seed=3)
+    _quiet(s.run, start_point=np.zeros(tr.ncoefs))
+    assert np.isfinite(s.chain).all() and s.chain.shape == (C, 2, tr.ncoefs)
+    adapted = s.deltas_trace[1:]
+    assert (adapted <= p.lmda / 2 + 1e-20).all() and (adapted >= p.lmda * 1e-8).all()
+    # chain 1 of the batch == the same chain run alone (Philox keyed by global chain id, per-chain delta / accept)
+    s1 = PxMALA(op, reg, p, tune_delta=True, nchains=1, seed=3, chain_offset=1)
+    _quiet(s1.run, start_point=np.zeros(tr.ncoefs))
+    n1 = min(len(s1.acceptance_trace), s.acceptance_trace.shape[0])
+    assert list(s1.acceptance_trace[:n1]) == list(s.acceptance_trace[:n1, 1])
+    np.testing.assert_allclose(s1.chain[0], s.chain[1, 0], rtol=1e-9, atol=1e-12 * np.abs(s.chain).max())

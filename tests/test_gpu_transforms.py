@@ -149,3 +149,34 @@ def test_two_wave_dft_path_L_above_256(monkeypatch):
     gradg = wav.synthesis_adjoint(ops.residual_grad(preds, data, invcov))
     want = ops.myula_step(X, gradg, T, delta, lmda, noise=noise)
     assert float((got - want).abs().max()) < 1e-11 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("L", [4, 10, 33, 64, 100, 128, 200, 256])
+def test_dft_kernel_variants_agree_and_match_oracle(L, monkeypatch):
+    """The phi-DFT of every L <= 256 has three kernels: eight points per lane with one half-size convolution per
+    wave (default, csrc/dft5.hip), the same with both halves in one wave (PXM_DFT_SPLIT=1), and the 16-points-per-
+    lane wave path (PXM_DFT_NO_V=1, csrc/dft3.hip).  All four SHT operators through each of them match the oracle;
+    L covers every Mh = 64 ... 512 (1, 2, 4, 8 rings per wave) and lengths that are not powers of two."""
+    from oracle import ssht
+    from pxmcmc_amd import ops
+
+    C, spin = 3, 0
+    rng = np.random.default_rng(L)
+    flm = rng.normal(size=(C, L * L)) + 1j * rng.normal(size=(C, L * L))
+    f = rng.normal(size=(C, L * (2 * L - 1))) + 1j * rng.normal(size=(C, L * (2 * L - 1)))
+    T = ssht.get_transform(L, spin)
+    refs = {
+        "inverse": np.stack([T.inverse(x).ravel() for x in flm]),
+        "forward_adjoint": np.stack([T.forward_adjoint(x).ravel() for x in flm]),
+        "forward": np.stack([T.forward(x) for x in f]),
+        "inverse_adjoint": np.stack([T.inverse_adjoint(x) for x in f]),
+    }
+    for env in ({}, {"PXM_DFT_SPLIT": "1"}, {"PXM_DFT_NO_V": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = ops.ShtPlan(L, spin, max_chains=C)
+        for k in env:
+            monkeypatch.delenv(k)
+        for name, ref in refs.items():
+            got = getattr(plan, name)(flm if name in ("inverse", "forward_adjoint") else f).cpu().numpy()
+            assert _rel(got, ref) < TOL, (env, name, _rel(got, ref))
