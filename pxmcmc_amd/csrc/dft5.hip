@@ -35,14 +35,14 @@
 namespace pxm {
 
 constexpr int D5_PLANE = 8 * 72;  // complex elements of one wave's transpose plane
-constexpr int D5_NW = 4;          // waves per workgroup
+constexpr int D5_NW = 4;          // ring sets (units) per workgroup: D5_R chains of one ring set
+constexpr int D5_R = 4;           // chains per workgroup (64-B segments of the ring arrays)
 
 struct Dft5Args {
   int L, n, Rp;
-  int R, TR;            // chains x ring groups per workgroup (R * TR = D5_NW); rings per workgroup = TR * RPW
-  const double2* cE;    // [n]  chirp c_j = exp(-i pi j^2 / n)
-  const double2* cO;    // [n]  c_j W_M^j       (input of the odd-bin half)
-  const double2* dO;    // [n]  c_j W_M^(-j)    (output weight of the odd-bin half)
+  const double2* cE;    // [Mh] chirp c_j = exp(-i pi j^2 / n), zero for j >= n
+  const double2* cO;    // [Mh] c_j W_M^j       (input of the odd-bin half)
+  const double2* dO;    // [Mh] c_j W_M^(-j)    (output weight of the odd-bin half)
   const double2* tw1;   // [8][64] W_Mh^(lam(lane) k2)
   const double2* wt;    // [8][8]  W_(8 r0)^(a b)
   const double2* bE;    // [r0][64] FFT_M(filter)/M at the even bins, in the order pass 3 leaves them
@@ -219,26 +219,20 @@ __device__ __forceinline__ void d5_conv(double2 (&z)[8], double2* plane, int lan
 template <int R0>
 __device__ __forceinline__ void d5_dft_both(double2 (&x)[8], double2* plane, int lane, const D5Lane& q, int jb,
                                             const Dft5Args& a) {
-  const int n = a.n;
   double2 z[8], y0[8];
+  // (the chirp tables are zero-padded to Mh entries: elements j >= n enter and leave as zeros without a test)
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int j = jb + 8 * R0 * p;
-    z[p] = j < n ? cmul(x[p], a.cE[j]) : double2{0.0, 0.0};
-  }
+  for (int p = 0; p < 8; ++p) z[p] = cmul(x[p], a.cE[jb + 8 * R0 * p]);
   d5_conv<R0>(z, plane, lane, q, a, a.bE);
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int j = jb + 8 * R0 * p;
-    y0[p] = j < n ? cmul(z[p], a.cE[j]) : double2{0.0, 0.0};
-    z[p] = j < n ? cmul(x[p], a.cO[j]) : double2{0.0, 0.0};
+    y0[p] = cmul(z[p], a.cE[j]);
+    z[p] = cmul(x[p], a.cO[j]);
   }
   d5_conv<R0>(z, plane, lane, q, a, a.bO);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int j = jb + 8 * R0 * p;
-    x[p] = j < n ? cadd(y0[p], cmul(z[p], a.dO[j])) : double2{0.0, 0.0};
-  }
+  for (int p = 0; p < 8; ++p) x[p] = cadd(y0[p], cmul(z[p], a.dO[jb + 8 * R0 * p]));
 }
 
 // SPLIT == 2: the two waves of a ring pair run one half each (half 0: even bins, half 1: odd bins) and leave
@@ -247,20 +241,14 @@ __device__ __forceinline__ void d5_dft_both(double2 (&x)[8], double2* plane, int
 template <int R0>
 __device__ __forceinline__ void d5_dft_half(double2 (&x)[8], double2* plane, int lane, const D5Lane& q, int jb, int half,
                                             const Dft5Args& a) {
-  const int n = a.n;
-  const double2* __restrict__ cin = half ? a.cO : a.cE;
-  const double2* __restrict__ cout = half ? a.dO : a.cE;
+  // (the chirp tables are zero-padded to Mh entries: elements j >= n enter and leave as zeros without a test)
+  const double2* __restrict__ cin = (half ? a.cO : a.cE) + jb;
+  const double2* __restrict__ cout = (half ? a.dO : a.cE) + jb;
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int j = jb + 8 * R0 * p;
-    x[p] = j < n ? cmul(x[p], cin[j]) : double2{0.0, 0.0};
-  }
+  for (int p = 0; p < 8; ++p) x[p] = cmul(x[p], cin[8 * R0 * p]);
   d5_conv<R0>(x, plane, lane, q, a, half ? a.bO : a.bE);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int j = jb + 8 * R0 * p;
-    x[p] = j < n ? cmul(x[p], cout[j]) : double2{0.0, 0.0};
-  }
+  for (int p = 0; p < 8; ++p) x[p] = cmul(x[p], cout[8 * R0 * p]);
 }
 // lane-wise select on the (wave-uniform) half index: registers keep compile-time indices
 __device__ __forceinline__ double2 d5_sel(int half, double2 a, double2 b) { return double2{half ? a.x : b.x, half ? a.y : b.y}; }
@@ -296,20 +284,21 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 // (consecutive k, one chain) spread over the banks.
 #define PXM_D5_GEOMETRY                                                                     \
   constexpr int RPW = 8 / R0;                                                               \
-  const int R = a.R, TR = a.TR, n = a.n;                                                    \
+  constexpr int R = D5_R;                             /* chains per workgroup; one ring set per unit */ \
+  const int n = a.n;                                                                        \
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                               \
   const int half = SPLIT == 2 ? (wave & 1) : 0, unit = SPLIT == 2 ? (wave >> 1) : wave;     \
   const D5Lane q{lane & 7, lane >> 3};                                                      \
-  const int tr = unit / R, r = unit - tr * R;                                               \
+  const int r = unit;                                 /* chain of the workgroup */          \
   const int rho = q.lo / R0;                          /* ring of the unit this lane works on */ \
   const int jb = (q.lo & (R0 - 1)) + R0 * q.hi;       /* its first element: j = jb + 8 r0 p */ \
-  const int TRS = TR * RPW;                           /* rings per workgroup */             \
-  const int trs = tr * RPW + rho;                     /* own ring within the workgroup */   \
+  constexpr int TRS = RPW;                            /* rings per workgroup */             \
+  const int trs = rho;                                /* own ring within the workgroup */   \
   const int t = bx * TRS + trs;                       /* own ring */                        \
   const int c0 = by * R, ch = c0 + r;                                                       \
   const bool tv = t < a.L;                                                                  \
   const int Cp = ncol >> 1;                                                                 \
-  const int rsh = R >= 8 ? 1 : (R == 4 ? 2 : (R == 2 ? 3 : 4));                             \
+  constexpr int rsh = 2;                              /* 16 / R: rotation period of the chain slot */ \
   constexpr int P1 = SPLIT == 2 ? 4 : 8;              /* the wave owns the elements p = pb + u, u < P1, */ \
   const int pb = SPLIT == 2 ? 4 * half : 0;           /* and keeps them in x[u] */          \
   double2* stage = lds5;                                                                    \
@@ -320,12 +309,20 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 
 // stage -> G rows of every ring of the workgroup
 #define PXM_D5_STORE_RINGS                                                                                     \
-  for (int idx = threadIdx.x; idx < TRS * n * R; idx += blockDim.x) {                                          \
-    const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);                                            \
-    const int tt = bx * TRS + trr;                                                                             \
-    if (c0 + rr >= Cp || tt >= a.L) continue;                                                                  \
-    const int m = (k < a.L) ? k : k - n;                                                                       \
-    reinterpret_cast<double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + tt) * Cp + c0 + rr] = stage[PXM_D5_SLOT(trr, k, rr)]; \
+  {                                                                                                            \
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> 2, kstep = (int)blockDim.x >> 2;                 \
+    const int mstride = a.Rp * Cp; /* complex elements between consecutive m */                                \
+    double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;                                                     \
+    if (c0 + rr < Cp) {                                                                                        \
+      _Pragma("nounroll") for (int trr = 0; trr < TRS; ++trr) {                                                \
+        const int tt = bx * TRS + trr;                                                                         \
+        if (tt >= a.L) break;                                                                                  \
+        for (int k = kq; k < n; k += kstep) {                                                                  \
+          const int mi = (k < a.L) ? k + a.L - 1 : k - a.L; /* m + L - 1 */                                    \
+          Gc[mi * mstride + tt * Cp] = stage[PXM_D5_SLOT(trr, k, rr)];                                         \
+        }                                                                                                      \
+      }                                                                                                        \
+    }                                                                                                          \
   }
 
 // the transform of x (all 8 elements in every wave of the ring) -> the wave's own elements of the result in x[0 .. P1)
@@ -379,30 +376,30 @@ template <int R0, int SPLIT, bool RING_OUT>
 __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restrict__ G, int ncol, const PxOut& out, int C,
                                               int bx, int by, double2* lds5) {
   // chain groups without a live chain do nothing (see run_tasks / GemmAffine::ncol_live: nothing iterates on them)
-  if (by * a.R >= C) return;
+  if (by * D5_R >= C) return;
   PXM_D5_GEOMETRY
-  {
-    constexpr int NB = 8;  // batches of independent loads: the memory latency is paid once per batch
-    const int total = TRS * n * R;
-    for (int base = threadIdx.x; base < total; base += NB * blockDim.x) {
-      double2 v[NB];
+  {  // rings of the workgroup -> stage; thread -> (chain rr, k), k advances by threads / R: no integer division
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> 2, kstep = (int)blockDim.x >> 2;
+    const int mstride = a.Rp * Cp;  // complex elements between consecutive m
+    const double2* Gc = reinterpret_cast<const double2*>(G) + c0 + rr;
+    const bool cv = c0 + rr < Cp;
+#pragma nounroll
+    for (int trr = 0; trr < TRS; ++trr) {
+      const int tt = bx * TRS + trr;
+      const bool rv = cv && tt < a.L;
+      constexpr int NB = 4;  // batches of independent loads: the memory latency is paid once per batch
+      for (int kb = kq; kb < n; kb += NB * kstep) {
+        double2 v[NB];
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int idx = base + u * blockDim.x;
-        const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);
-        const int tt = bx * TRS + trr;
-        v[u] = double2{0.0, 0.0};
-        if (idx < total && c0 + rr < Cp && tt < a.L) {
-          const int m = (k < a.L) ? k : k - n;
-          v[u] = reinterpret_cast<const double2*>(G)[((int64_t)(m + a.L - 1) * a.Rp + tt) * Cp + c0 + rr];
+        for (int u = 0; u < NB; ++u) {
+          const int k = kb + u * kstep;
+          v[u] = double2{0.0, 0.0};
+          if (rv && k < n) v[u] = Gc[((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + tt * Cp];
         }
-      }
 #pragma unroll
-      for (int u = 0; u < NB; ++u) {
-        const int idx = base + u * blockDim.x;
-        if (idx < total) {
-          const int rr = idx % R, k = (idx / R) % n, trr = idx / (R * n);
-          stage[PXM_D5_SLOT(trr, k, rr)] = double2{v[u].x, -v[u].y};  // inverse DFT by conjugation: y = conj(DFT(conj x))
+        for (int u = 0; u < NB; ++u) {
+          const int k = kb + u * kstep;
+          if (k < n) stage[PXM_D5_SLOT(trr, k, rr)] = double2{v[u].x, -v[u].y};  // inverse DFT by conjugation: y = conj(DFT(conj x))
         }
       }
     }
@@ -563,12 +560,13 @@ int dft5_make_tables(int n, Dft5Tables* t) {
     h.push_back((double)v.real());
     h.push_back((double)v.imag());
   };
+  const cld zero(0, 0);  // the three chirp tables are zero-padded to Mh entries (the kernels read them without a j < n test)
   const size_t o_cE = 0;
-  for (int j = 0; j < n; ++j) put(chirp[j]);
+  for (int j = 0; j < Mh; ++j) put(j < n ? chirp[j] : zero);
   const size_t o_cO = h.size();
-  for (int j = 0; j < n; ++j) put(chirp[j] * ang(2.0L * j, M));
+  for (int j = 0; j < Mh; ++j) put(j < n ? chirp[j] * ang(2.0L * j, M) : zero);
   const size_t o_dO = h.size();
-  for (int j = 0; j < n; ++j) put(chirp[j] * std::conj(ang(2.0L * j, M)));
+  for (int j = 0; j < Mh; ++j) put(j < n ? chirp[j] * std::conj(ang(2.0L * j, M)) : zero);
   const size_t o_tw1 = h.size();
   for (int k = 0; k < 8; ++k)
     for (int lane = 0; lane < 64; ++lane) {
@@ -605,16 +603,17 @@ int dft5_split() {
 
 void dft5_geometry(int n, int split, int* R, int* TR, size_t* lds) {
   const int r0 = dft5_r0(n), rpw = 8 / r0;
-  *R = 4;
-  *TR = D5_NW / *R;
-  const size_t planes = (size_t)D5_NW * split * D5_PLANE * 16, stage = (size_t)(*TR) * rpw * n * (*R) * 16;
+  *R = D5_R;
+  *TR = 1;
+  static_assert(D5_NW == D5_R, "one unit (ring set) per chain of the workgroup");
+  const size_t planes = (size_t)D5_NW * split * D5_PLANE * 16, stage = (size_t)rpw * n * D5_R * 16;
   *lds = std::max(planes, stage);
 }
 
 static Dft5Args dft5_args(const DftPlan& p) {
   const Dft5Tables& t = p.t5;
   auto c = [](const double* x) { return reinterpret_cast<const double2*>(x); };
-  return Dft5Args{p.L, p.n, p.Rp, p.R5, p.TR5, c(t.cE), c(t.cO), c(t.dO), c(t.tw1), c(t.wt), c(t.bE), c(t.bO)};
+  return Dft5Args{p.L, p.n, p.Rp, c(t.cE), c(t.cO), c(t.dO), c(t.tw1), c(t.wt), c(t.bE), c(t.bO)};
 }
 
 template <int R0, int SPLIT>

@@ -18,7 +18,7 @@ __device__ inline double2 csub(double2 a, double2 b) { return double2{a.x - b.x,
 __device__ inline double soft_real(double x, double T) {
   const double a = fabs(x);
   if (a <= T) return 0.0;
-  return (x / a) * (a - T);
+  return copysign(a - T, x);  // == (x / a) * (a - T) bit for bit: x / |x| is exactly +-1 for a finite non-zero x
 }
 __device__ inline double2 soft_cplx(double2 z, double T) {
   const double a = hypot(z.x, z.y);
