@@ -167,8 +167,7 @@ int make_dft_plan(int L, DftPlan* p) {
   if (dft5_r0(b.n) && !getenv("PXM_DFT_NO_V") && !getenv("PXM_DFT_NO_W")) {
     int rc = dft5_make_tables(b.n, &p->t5);
     if (rc) return rc;
-    p->split5 = dft5_split();
-    dft5_geometry(b.n, p->split5, &p->R5, &p->TR5, &p->lds5);
+    dft5_geometry(b.n, &p->R5, &p->TR5, &p->lds5);
     p->use5 = true;
   }
   const int M3 = getenv("PXM_DFT_NO_W") ? 0 : dft3_size(b.n);

@@ -4,11 +4,12 @@
 // above n <= Mh, so the first radix-2 (DIF) stage of the M-point transform is free: the even bins are the
 // Mh-point transform of a[j], the odd bins that of a[j] W_M^j, and after the filter
 //     conv[j] = y_even[j] + W_M^(-j) y_odd[j],   j < n <= Mh.
-// ONE wave owns RPW = 8 / r0 rings and runs the two half-size convolutions one after the other with 8 complex
-// points per lane (Mh = 64 lanes' worth of 8 r0 ... see below), so a ring never leaves its wave (every LDS
-// exchange needs wave-local ordering only, no workgroup barrier) and the kernel stays at <= 128 VGPR = 4 waves
-// per SIMD -- the one-wave M = 1024 kernels of dft3.hip hold 16 points per lane, 203 VGPR, 2 waves per SIMD and
-// were bound by VALU issue latency at that occupancy.
+// A PAIR of waves owns a ring set of RPW = 8 / r0 rings (one ring of 512 slots, two of 256, ...): wave 0 runs the
+// even-bin convolution, wave 1 the odd-bin one, each with 8 complex points per lane; they exchange their shares
+// through LDS (workgroup barrier) and each finishes FOUR of the eight elements a lane holds (epilogue, Philox).
+// 84-127 VGPR, no spills: 4 waves per SIMD -- the one-wave M = 1024 kernels of dft3.hip hold 16 points per lane at
+// 203 VGPR, 2 waves per SIMD, and were bound by VALU issue latency at that occupancy with 1.5x the instructions
+// (DESIGN.md section 9).  Inside a wave every transpose of the transform needs wave-local ordering only.
 //
 // Mh-point transform, j = j0 + r0 j1 + 8 r0 j2 (j0 < r0; j1, j2 < 8), bin k = k2 + 8 k1 + 64 k0 (k0 < r0):
 //   lane = g + 8 j1, g = j0 + r0 rho (rho = ring of the wave), registers p = j2: element j = lam + 8 r0 p of ring
@@ -32,14 +33,34 @@
 #include <cstdlib>
 #include <vector>
 
+// timing-only ablations for DESIGN.md (wrong results): 1 no Philox, 2 no table loads, 4 no LDS transposes
+#ifndef PXM_D5_ABLATE
+#define PXM_D5_ABLATE 0
+#endif
+
 namespace pxm {
 
+#if PXM_D5_ABLATE & 2
+#define D5_TAB(EXPR) (double2{0.8, 0.6})
+#else
+#define D5_TAB(EXPR) (EXPR)
+#endif
+
+#if PXM_D5_ABLATE & 4
+#define D5_PW(DST, V) ((void)0)
+#define D5_PR(V, SRC) ((void)0)
+#else
+#define D5_PW(DST, V) (DST) = (V)
+#define D5_PR(V, SRC) (V) = (SRC)
+#endif
+
 constexpr int D5_PLANE = 8 * 72;  // complex elements of one wave's transpose plane
-constexpr int D5_NW = 4;          // ring sets (units) per workgroup: D5_R chains of one ring set
-constexpr int D5_R = 4;           // chains per workgroup (64-B segments of the ring arrays)
+constexpr int D5_TW = 512;        // LDS copy of the pass twiddles: tw1 rows k = 1..7 ([7][64]) then wt ([8][8])
+constexpr int D5_RMAX = 4;        // most chains (units: ring sets) per workgroup; the launch bound of the kernels
 
 struct Dft5Args {
   int L, n, Rp;
+  int lgR;              // log2 of R = chains (units) per workgroup: 1, 2 or 4 (16 R-byte segments of the ring arrays)
   const double2* cE;    // [Mh] chirp c_j = exp(-i pi j^2 / n), zero for j >= n
   const double2* cO;    // [Mh] c_j W_M^j       (input of the odd-bin half)
   const double2* dO;    // [Mh] c_j W_M^(-j)    (output weight of the odd-bin half)
@@ -59,6 +80,9 @@ struct Dft5Group {
 };
 
 __device__ __forceinline__ void d5_wave_sync() {
+#if PXM_D5_ABLATE & 4
+  return;
+#endif
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -153,102 +177,81 @@ struct D5Lane {
 
 // forward Mh-point transform of the wave's rings: natural order -> bins (reg k0 + r0 rho, lane k1 + 8 k2)
 template <int R0>
-__device__ __forceinline__ void d5_fwd(double2 (&z)[8], double2* plane, int lane, const D5Lane& q, const Dft5Args& a) {
+__device__ __forceinline__ void d5_fwd(double2 (&z)[8], double2* plane, int lane, const D5Lane& q, const double2* tw) {
   dft8r<-1, 0>(z);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], a.tw1[k * 64 + lane]);
+  for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], D5_TAB(tw[(k - 1) * 64 + lane]));
 #pragma unroll
-  for (int k = 0; k < 8; ++k) plane[72 * k + lane] = z[k];  // T1
+  for (int k = 0; k < 8; ++k) D5_PW(plane[72 * k + lane], z[k]);  // T1
   d5_wave_sync();
 #pragma unroll
-  for (int k = 0; k < 8; ++k) z[k] = plane[72 * q.hi + 8 * k + q.lo];
+  for (int k = 0; k < 8; ++k) D5_PR(z[k], plane[72 * q.hi + 8 * k + q.lo]);
   d5_wave_sync();
   dft8r<-1, 0>(z);
   if (R0 > 1) {
 #pragma unroll
-    for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], a.wt[k * 8 + (q.lo & (R0 - 1))]);  // W^(j0(g) k1)
+    for (int k = 1; k < 8; ++k) z[k] = cmul(z[k], D5_TAB(tw[448 + k * 8 + (q.lo & (R0 - 1))]));  // W^(j0(g) k1)
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) plane[72 * q.hi + 9 * k + q.lo] = z[k];  // T2
+  for (int k = 0; k < 8; ++k) D5_PW(plane[72 * q.hi + 9 * k + q.lo], z[k]);  // T2
   d5_wave_sync();
 #pragma unroll
-  for (int k = 0; k < 8; ++k) z[k] = plane[72 * q.hi + 9 * q.lo + k];
+  for (int k = 0; k < 8; ++k) D5_PR(z[k], plane[72 * q.hi + 9 * q.lo + k]);
   d5_wave_sync();
   pass3<-1, R0>(z);
 }
 
 // the mirror image: bins -> natural order (unnormalised inverse transform)
 template <int R0>
-__device__ __forceinline__ void d5_inv(double2 (&z)[8], double2* plane, int lane, const D5Lane& q, const Dft5Args& a) {
+__device__ __forceinline__ void d5_inv(double2 (&z)[8], double2* plane, int lane, const D5Lane& q, const double2* tw) {
   pass3<+1, R0>(z);
   if (R0 > 1) {
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (k & (R0 - 1)) z[k] = cmulc(z[k], a.wt[(k & (R0 - 1)) * 8 + q.lo]);  // W^(-j0(reg) k1)
+      if (k & (R0 - 1)) z[k] = cmulc(z[k], D5_TAB(tw[448 + (k & (R0 - 1)) * 8 + q.lo]));  // W^(-j0(reg) k1)
   }
 #pragma unroll
-  for (int k = 0; k < 8; ++k) plane[72 * q.hi + 9 * q.lo + k] = z[k];  // T2'
+  for (int k = 0; k < 8; ++k) D5_PW(plane[72 * q.hi + 9 * q.lo + k], z[k]);  // T2'
   d5_wave_sync();
 #pragma unroll
-  for (int k = 0; k < 8; ++k) z[k] = plane[72 * q.hi + 9 * k + q.lo];
+  for (int k = 0; k < 8; ++k) D5_PR(z[k], plane[72 * q.hi + 9 * k + q.lo]);
   d5_wave_sync();
   dft8r<+1, 0>(z);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) plane[72 * q.hi + 8 * k + q.lo] = z[k];  // T1'
+  for (int k = 0; k < 8; ++k) D5_PW(plane[72 * q.hi + 8 * k + q.lo], z[k]);  // T1'
   d5_wave_sync();
 #pragma unroll
-  for (int k = 0; k < 8; ++k) z[k] = plane[72 * k + lane];
+  for (int k = 0; k < 8; ++k) D5_PR(z[k], plane[72 * k + lane]);
   d5_wave_sync();
 #pragma unroll
-  for (int k = 1; k < 8; ++k) z[k] = cmulc(z[k], a.tw1[k * 64 + lane]);
+  for (int k = 1; k < 8; ++k) z[k] = cmulc(z[k], D5_TAB(tw[(k - 1) * 64 + lane]));
   dft8r<+1, 0>(z);
 }
 
 // cyclic convolution half: z (chirped input, natural order) -> forward transform -> filter spectrum bw -> back
 template <int R0>
-__device__ __forceinline__ void d5_conv(double2 (&z)[8], double2* plane, int lane, const D5Lane& q, const Dft5Args& a,
+__device__ __forceinline__ void d5_conv(double2 (&z)[8], double2* plane, int lane, const D5Lane& q, const double2* tw,
                                         const double2* __restrict__ bw) {
-  d5_fwd<R0>(z, plane, lane, q, a);
+  d5_fwd<R0>(z, plane, lane, q, tw);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) z[k] = cmul(z[k], bw[(k & (R0 - 1)) * 64 + lane]);
-  d5_inv<R0>(z, plane, lane, q, a);
+  for (int k = 0; k < 8; ++k) z[k] = cmul(z[k], D5_TAB(bw[(k & (R0 - 1)) * 64 + lane]));
+  d5_inv<R0>(z, plane, lane, q, tw);
 }
 
-// DFT (e^{-2 pi i jk/n}) of the wave's rings, SPLIT == 1 (one wave runs both halves): in x[p] = element
-// j = jb + 8 r0 p (zero for j >= n), out the same elements of the transform.
-template <int R0>
-__device__ __forceinline__ void d5_dft_both(double2 (&x)[8], double2* plane, int lane, const D5Lane& q, int jb,
-                                            const Dft5Args& a) {
-  double2 z[8], y0[8];
-  // (the chirp tables are zero-padded to Mh entries: elements j >= n enter and leave as zeros without a test)
-#pragma unroll
-  for (int p = 0; p < 8; ++p) z[p] = cmul(x[p], a.cE[jb + 8 * R0 * p]);
-  d5_conv<R0>(z, plane, lane, q, a, a.bE);
-#pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    const int j = jb + 8 * R0 * p;
-    y0[p] = cmul(z[p], a.cE[j]);
-    z[p] = cmul(x[p], a.cO[j]);
-  }
-  d5_conv<R0>(z, plane, lane, q, a, a.bO);
-#pragma unroll
-  for (int p = 0; p < 8; ++p) x[p] = cadd(y0[p], cmul(z[p], a.dO[jb + 8 * R0 * p]));
-}
-
-// SPLIT == 2: the two waves of a ring pair run one half each (half 0: even bins, half 1: odd bins) and leave
+// The two waves of a ring set run one half each (half 0: even bins, half 1: odd bins) and leave
 // their weighted share t_w[p] of every output element in x; d5_exchange then hands each wave the partner's share
 // of the FOUR elements it owns (p in [4 half, 4 half + 4)).
 template <int R0>
 __device__ __forceinline__ void d5_dft_half(double2 (&x)[8], double2* plane, int lane, const D5Lane& q, int jb, int half,
-                                            const Dft5Args& a) {
+                                            const Dft5Args& a, const double2* tw) {
   // (the chirp tables are zero-padded to Mh entries: elements j >= n enter and leave as zeros without a test)
   const double2* __restrict__ cin = (half ? a.cO : a.cE) + jb;
   const double2* __restrict__ cout = (half ? a.dO : a.cE) + jb;
 #pragma unroll
-  for (int p = 0; p < 8; ++p) x[p] = cmul(x[p], cin[8 * R0 * p]);
-  d5_conv<R0>(x, plane, lane, q, a, half ? a.bO : a.bE);
+  for (int p = 0; p < 8; ++p) x[p] = cmul(x[p], D5_TAB(cin[8 * R0 * p]));
+  d5_conv<R0>(x, plane, lane, q, tw, half ? a.bO : a.bE);
 #pragma unroll
-  for (int p = 0; p < 8; ++p) x[p] = cmul(x[p], cout[8 * R0 * p]);
+  for (int p = 0; p < 8; ++p) x[p] = cmul(x[p], D5_TAB(cout[8 * R0 * p]));
 }
 // lane-wise select on the (wave-uniform) half index: registers keep compile-time indices
 __device__ __forceinline__ double2 d5_sel(int half, double2 a, double2 b) { return double2{half ? a.x : b.x, half ? a.y : b.y}; }
@@ -278,16 +281,15 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 }
 
 // ---- workgroup geometry ---------------------------------------------------------------------------------------
-// SPLIT waves per ring set: wave = SPLIT * unit + half.  Unit u: chain r = u % R of the group, ring group
-// tr = u / R; lane -> ring rho of the unit.  stage: the rings of the workgroup in [ring][k][chain] order (16-B x R
+// Two waves per ring set: wave = 2 * unit + half; unit u = chain u of the workgroup; lane -> ring rho of the unit.  stage: the rings of the workgroup in [ring][k][chain] order (16-B x R
 // segments per m in the ring arrays); the chain slot is rotated with k so that the lanes' strided reads
 // (consecutive k, one chain) spread over the banks.
 #define PXM_D5_GEOMETRY                                                                     \
   constexpr int RPW = 8 / R0;                                                               \
-  constexpr int R = D5_R;                             /* chains per workgroup; one ring set per unit */ \
+  const int lgR = a.lgR, R = 1 << lgR;                /* chains per workgroup; one ring set per unit */ \
   const int n = a.n;                                                                        \
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                               \
-  const int half = SPLIT == 2 ? (wave & 1) : 0, unit = SPLIT == 2 ? (wave >> 1) : wave;     \
+  const int half = wave & 1, unit = wave >> 1;        /* two waves per ring set */          \
   const D5Lane q{lane & 7, lane >> 3};                                                      \
   const int r = unit;                                 /* chain of the workgroup */          \
   const int rho = q.lo / R0;                          /* ring of the unit this lane works on */ \
@@ -298,19 +300,20 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
   const int c0 = by * R, ch = c0 + r;                                                       \
   const bool tv = t < a.L;                                                                  \
   const int Cp = ncol >> 1;                                                                 \
-  constexpr int rsh = 2;                              /* 16 / R: rotation period of the chain slot */ \
-  constexpr int P1 = SPLIT == 2 ? 4 : 8;              /* the wave owns the elements p = pb + u, u < P1, */ \
-  const int pb = SPLIT == 2 ? 4 * half : 0;           /* and keeps them in x[u] */          \
+  const int rsh = 4 - lgR;                            /* 16 / R: rotation period of the chain slot */ \
+  constexpr int P1 = 4;                               /* the wave owns the elements p = pb + u, u < P1, */ \
+  const int pb = 4 * half;                            /* and keeps them in x[u] */          \
   double2* stage = lds5;                                                                    \
   double2* plane = lds5 + wave * D5_PLANE;                                                  \
   double2* pplane = lds5 + (wave ^ 1) * D5_PLANE;                                           \
-  (void)pplane;
-#define PXM_D5_SLOT(RING, K, CH) (((RING)*n + (K)) * R + (((CH) + ((K) >> rsh)) & (R - 1)))
+  const double2* tw = lds5 + 2 * R * D5_PLANE;        /* twiddles of the transform passes (LDS copy) */ \
+  for (int i = threadIdx.x; i < D5_TW; i += blockDim.x) lds5[2 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : a.wt[i - 448];
+#define PXM_D5_SLOT(RING, K, CH) ((((RING)*n + (K)) << lgR) + (((CH) + ((K) >> rsh)) & (R - 1)))
 
 // stage -> G rows of every ring of the workgroup
 #define PXM_D5_STORE_RINGS                                                                                     \
   {                                                                                                            \
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> 2, kstep = (int)blockDim.x >> 2;                 \
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;                 \
     const int mstride = a.Rp * Cp; /* complex elements between consecutive m */                                \
     double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;                                                     \
     if (c0 + rr < Cp) {                                                                                        \
@@ -327,12 +330,8 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 
 // the transform of x (all 8 elements in every wave of the ring) -> the wave's own elements of the result in x[0 .. P1)
 #define PXM_D5_TRANSFORM(SLOT)                                            \
-  if (SPLIT == 2) {                                                       \
-    d5_dft_half<R0>(x, plane, lane, q, jb, half, a);                      \
-    d5_exchange_sum<SLOT>(x, plane, pplane, lane, half);                  \
-  } else {                                                                \
-    d5_dft_both<R0>(x, plane, lane, q, jb, a);                            \
-  }
+  d5_dft_half<R0>(x, plane, lane, q, jb, half, a, tw);                    \
+  d5_exchange_sum<SLOT>(x, plane, pplane, lane, half);
 // own elements of x -> stage (after every plane of the workgroup is dead)
 #define PXM_D5_TO_STAGE                                                   \
   __syncthreads();                                                        \
@@ -342,7 +341,7 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
   }                                                                       \
   __syncthreads();
 
-template <int R0, int SPLIT>
+template <int R0>
 __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in, double* __restrict__ G, int ncol, int C,
                                               int bx, int by, double2* lds5) {
   PXM_D5_GEOMETRY
@@ -365,6 +364,7 @@ __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in,
     }
     x[p] = v;
   }
+  __syncthreads();  // the LDS copy of the twiddles is complete
   PXM_D5_TRANSFORM(0)
   PXM_D5_TO_STAGE
   PXM_D5_STORE_RINGS
@@ -372,14 +372,14 @@ __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in,
 
 // rings -> pixels (inverse DFT by conjugation) with out's epilogue; RING_OUT: the written ring is transformed
 // again and its rings go back IN PLACE over G (rings of S X -> X' and the rings of X' in one kernel).
-template <int R0, int SPLIT, bool RING_OUT>
+template <int R0, bool RING_OUT>
 __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restrict__ G, int ncol, const PxOut& out, int C,
                                               int bx, int by, double2* lds5) {
   // chain groups without a live chain do nothing (see run_tasks / GemmAffine::ncol_live: nothing iterates on them)
-  if (by * D5_R >= C) return;
+  if ((by << a.lgR) >= C) return;
   PXM_D5_GEOMETRY
   {  // rings of the workgroup -> stage; thread -> (chain rr, k), k advances by threads / R: no integer division
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> 2, kstep = (int)blockDim.x >> 2;
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;
     const int mstride = a.Rp * Cp;  // complex elements between consecutive m
     const double2* Gc = reinterpret_cast<const double2*>(G) + c0 + rr;
     const bool cv = c0 + rr < Cp;
@@ -441,7 +441,9 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
         const int64_t off = (int64_t)(8 * R0) * p;
         const double2 y{x[p].x, -x[p].y};
         double2 w = wn[u];
+#if !(PXM_D5_ABLATE & 1)
         if (!out.noise) w = px_noise_philox(out, ch, e0 + off, it_eff);
+#endif
         x[p] = px_update(out, xs[u], Ts[u], y, w);
         reinterpret_cast<double2*>(out.f)[ce0 + off] = x[p];
       }
@@ -472,50 +474,53 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
   }
   if (!RING_OUT) return;
   // ---- forward transform of the updated ring
-  if (SPLIT == 2) {
-    d5_exchange_fill<1>(x, plane, pplane, lane, half);  // both waves of the ring need all 8 elements
-    __syncthreads();                                    // ... and every exchange read is done before the planes are reused
-  }
+  d5_exchange_fill<1>(x, plane, pplane, lane, half);  // both waves of the ring set need all 8 elements
+  __syncthreads();                                    // ... and every exchange read is done before the planes are reused
   PXM_D5_TRANSFORM(0)
   PXM_D5_TO_STAGE
   PXM_D5_STORE_RINGS
 }
 
-template <int R0, int SPLIT>
-__global__ __launch_bounds__(64 * D5_NW * SPLIT, SPLIT == 2 ? 4 : 3) void k_px2ring5(Dft5Args a, PxIn in, double* __restrict__ G,
+template <int R0>
+__global__ __launch_bounds__(128 * D5_RMAX, 4) void k_px2ring5(Dft5Args a, PxIn in, double* __restrict__ G,
                                                                                  int ncol, int C) {
   extern __shared__ double2 lds5[];
   if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
-  px2ring_body5<R0, SPLIT>(a, in, G, ncol, C, blockIdx.x, blockIdx.y, lds5);
+  px2ring_body5<R0>(a, in, G, ncol, C, blockIdx.x, blockIdx.y, lds5);
 }
 
-template <int R0, int SPLIT, bool RING_OUT>
-__global__ __launch_bounds__(64 * D5_NW * SPLIT, SPLIT == 2 ? 4 : 3) void k_ring2px5(Dft5Args a, double* __restrict__ G, int ncol,
+template <int R0, bool RING_OUT>
+__global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px5(Dft5Args a, double* __restrict__ G, int ncol,
                                                                                  PxOut out, int C) {
   extern __shared__ double2 lds5[];
-  ring2px_body5<R0, SPLIT, RING_OUT>(a, G, ncol, out, C, blockIdx.x, blockIdx.y, lds5);
+  ring2px_body5<R0, RING_OUT>(a, G, ncol, out, C, blockIdx.x, blockIdx.y, lds5);
 }
 
 // Grouped launch of the ring-space step: the rings -> X' -> rings bodies of EVERY scale of a wavelet plan in one
 // grid, largest scales first (their workgroups are the long ones; the small scales fill the tail).
-template <int SPLIT>
-__global__ __launch_bounds__(64 * D5_NW * SPLIT, SPLIT == 2 ? 4 : 3) void k_ring2px_group5(const Dft5Group* __restrict__ ents, int nent,
+__global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5Group* __restrict__ ents, int nent,
                                                                                        double* __restrict__ ws, int ncol, PxOut out,
                                                                                        int C) {
   extern __shared__ double2 lds5[];
   int e = 0;
   while (e + 1 < nent && (int)blockIdx.x >= ents[e + 1].b0) ++e;
   const Dft5Group g = ents[e];
+  // XCD-aware order inside a scale: the chain groups (by) of one ring set share the 128-B lines of the ring arrays
+  // (8 chain slots per (m, ring)), so they are given block ids that differ by 8 -- same XCD (same L2) under the
+  // round-robin placement of blocks, dispatched back to back: the second one finds its half-lines in L2 and their
+  // half-line stores merge there.  (b0 and the per-scale block counts are multiples of 8.)
   const int local = blockIdx.x - g.b0;
-  const int bx = local % g.nbx, by = local / g.nbx;
+  const int rest = local >> 3;
+  const int by = rest % g.nby, bx = (rest / g.nby) * 8 + (local & 7);
+  if (bx >= g.nbx) return;
   out.ring0 = g.ring0;
   double* G = ws + g.g_off;
   const Dft5Args a = g.a;
   switch (g.r0) {
-    case 8: ring2px_body5<8, SPLIT, true>(a, G, ncol, out, C, bx, by, lds5); break;
-    case 4: ring2px_body5<4, SPLIT, true>(a, G, ncol, out, C, bx, by, lds5); break;
-    case 2: ring2px_body5<2, SPLIT, true>(a, G, ncol, out, C, bx, by, lds5); break;
-    default: ring2px_body5<1, SPLIT, true>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 8: ring2px_body5<8, true>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 4: ring2px_body5<4, true>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 2: ring2px_body5<2, true>(a, G, ncol, out, C, bx, by, lds5); break;
+    default: ring2px_body5<1, true>(a, G, ncol, out, C, bx, by, lds5); break;
   }
 }
 
@@ -595,70 +600,68 @@ int dft5_make_tables(int n, Dft5Tables* t) {
   return 0;
 }
 
-// waves per ring set, read at plan creation: 2 (default) or 1 (PXM_DFT_SPLIT=1: one wave runs both halves, 3 waves per SIMD)
-int dft5_split() {
-  const char* e = getenv("PXM_DFT_SPLIT");
-  return (e && atoi(e) == 1) ? 1 : 2;
-}
-
-void dft5_geometry(int n, int split, int* R, int* TR, size_t* lds) {
+void dft5_geometry(int n, int* R, int* TR, size_t* lds) {
   const int r0 = dft5_r0(n), rpw = 8 / r0;
-  *R = D5_R;
+  // chains per workgroup: 4 = 64-B segments of the ring arrays; PXM_DFT_R=1|2: smaller workgroups (one ring set
+  // is then two waves), whose barriers synchronise fewer waves, at the price of 16 / 32-B segments
+  const char* e = getenv("PXM_DFT_R");
+  const int r = e ? atoi(e) : D5_RMAX;
+  *R = (r == 1 || r == 2) ? r : D5_RMAX;
   *TR = 1;
-  static_assert(D5_NW == D5_R, "one unit (ring set) per chain of the workgroup");
-  const size_t planes = (size_t)D5_NW * split * D5_PLANE * 16, stage = (size_t)rpw * n * D5_R * 16;
-  *lds = std::max(planes, stage);
+  const size_t planes = (size_t)(*R) * 2 * D5_PLANE * 16, stage = (size_t)rpw * n * (*R) * 16;
+  // the planes (aliased by the stage) and behind them the LDS copy of the pass twiddles; with R = 4:
+  // 8 x 9216 + 8192 = 81 920 B -- exactly two workgroups (16 waves, 4 per SIMD) in the 160 KiB of a CU
+  *lds = std::max(planes, stage) + (size_t)D5_TW * 16;
 }
 
 static Dft5Args dft5_args(const DftPlan& p) {
   const Dft5Tables& t = p.t5;
   auto c = [](const double* x) { return reinterpret_cast<const double2*>(x); };
-  return Dft5Args{p.L, p.n, p.Rp, c(t.cE), c(t.cO), c(t.dO), c(t.tw1), c(t.wt), c(t.bE), c(t.bO)};
+  return Dft5Args{p.L, p.n, p.Rp, p.R5 == 4 ? 2 : (p.R5 == 2 ? 1 : 0), c(t.cE), c(t.cO), c(t.dO), c(t.tw1), c(t.wt), c(t.bE), c(t.bO)};
 }
 
-template <int R0, int SPLIT>
+template <int R0>
 static int dft5_attr() {
   static bool done = false;
   if (!done) {
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring5<R0, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, SPLIT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, SPLIT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring5<R0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
   return 0;
 }
 
-template <int R0, int SPLIT>
+template <int R0>
 static int px2ring5_r(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
-  if (int rc = dft5_attr<R0, SPLIT>()) return rc;
+  if (int rc = dft5_attr<R0>()) return rc;
   const int Cp = ncol / 2, rings = p.TR5 * (8 / R0);
-  dim3 grid((p.L + rings - 1) / rings, (Cp + p.R5 - 1) / p.R5), block(64 * D5_NW * SPLIT);
-  hipLaunchKernelGGL((k_px2ring5<R0, SPLIT>), grid, block, p.lds5, st, dft5_args(p), in, G, ncol, C);
+  dim3 grid((p.L + rings - 1) / rings, (Cp + p.R5 - 1) / p.R5), block(128 * p.R5);
+  hipLaunchKernelGGL((k_px2ring5<R0>), grid, block, p.lds5, st, dft5_args(p), in, G, ncol, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
-template <int R0, int SPLIT>
+template <int R0>
 static int ring2px5_r(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
-  if (int rc = dft5_attr<R0, SPLIT>()) return rc;
+  if (int rc = dft5_attr<R0>()) return rc;
   const int rings = p.TR5 * (8 / R0);
-  dim3 grid((p.L + rings - 1) / rings, (C + p.R5 - 1) / p.R5), block(64 * D5_NW * SPLIT);
+  dim3 grid((p.L + rings - 1) / rings, (C + p.R5 - 1) / p.R5), block(128 * p.R5);
   if (ring_out) {
-    hipLaunchKernelGGL((k_ring2px5<R0, SPLIT, true>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
+    hipLaunchKernelGGL((k_ring2px5<R0, true>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
   } else {
-    hipLaunchKernelGGL((k_ring2px5<R0, SPLIT, false>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
+    hipLaunchKernelGGL((k_ring2px5<R0, false>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
   }
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
-#define PXM_D5_DISPATCH(FN, ...)                                                   \
-  const bool two = p.split5 == 2;                                                  \
-  switch (p.t5.r0) {                                                               \
-    case 8: return two ? FN<8, 2>(__VA_ARGS__) : FN<8, 1>(__VA_ARGS__);            \
-    case 4: return two ? FN<4, 2>(__VA_ARGS__) : FN<4, 1>(__VA_ARGS__);            \
-    case 2: return two ? FN<2, 2>(__VA_ARGS__) : FN<2, 1>(__VA_ARGS__);            \
-    default: return two ? FN<1, 2>(__VA_ARGS__) : FN<1, 1>(__VA_ARGS__);           \
+#define PXM_D5_DISPATCH(FN, ...)         \
+  switch (p.t5.r0) {                     \
+    case 8: return FN<8>(__VA_ARGS__);   \
+    case 4: return FN<4>(__VA_ARGS__);   \
+    case 2: return FN<2>(__VA_ARGS__);   \
+    default: return FN<1>(__VA_ARGS__);  \
   }
 
 int dft5_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
@@ -680,7 +683,7 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
   size_t lds = 0;
   for (int s : order) {
     const DftPlan& p = *plans[s];
-    if (!p.use5 || p.split5 != plans[order[0]]->split5) return 1;
+    if (!p.use5 || p.R5 != plans[order[0]]->R5) return 1;
     Dft5Group g;
     g.a = dft5_args(p);
     g.g_off = g_off[s];
@@ -690,7 +693,7 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
     g.nbx = (p.L + rings - 1) / rings;
     g.nby = (ncol / 2 + p.R5 - 1) / p.R5;
     g.b0 = b0;
-    b0 += g.nbx * g.nby;
+    b0 += round_up(g.nbx, 8) * g.nby;  // (padded so that every scale starts on an XCD-label boundary)
     lds = std::max(lds, p.lds5);
     out->px_elems += (double)p.L * p.n;
     v.push_back(g);
@@ -699,14 +702,12 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
   out->blocks = b0;
   out->lds = lds;
   out->five = true;
-  out->split = plans[order[0]]->split5;
+  out->threads = 128 * plans[order[0]]->R5;
   PXM_HIP(hipMalloc(&out->d, v.size() * sizeof(Dft5Group)));
   PXM_HIP(hipMemcpy(out->d, v.data(), v.size() * sizeof(Dft5Group), hipMemcpyHostToDevice));
   static bool attr = false;
   if (!attr) {
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     attr = true;
   }
@@ -719,13 +720,8 @@ int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut&
   const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
-  if (g.split == 2) {
-    hipExtLaunchKernelGGL(k_ring2px_group5<2>, dim3(g.blocks), dim3(64 * D5_NW * 2), g.lds, st, ev0, ev1, 0,
-                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C);
-  } else {
-    hipExtLaunchKernelGGL(k_ring2px_group5<1>, dim3(g.blocks), dim3(64 * D5_NW), g.lds, st, ev0, ev1, 0,
-                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C);
-  }
+  hipExtLaunchKernelGGL(k_ring2px_group5, dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
+                        reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }

@@ -186,7 +186,7 @@ struct DftPlan {
   // eight-points-per-lane path (dft5.hip): M = 2 Mh, two half-size convolutions per wave, every L <= 256 (default)
   bool use5 = false;
   Dft5Tables t5;
-  int R5 = 0, TR5 = 0, split5 = 2;  // split5: waves per ring set (2: one half-size convolution per wave)
+  int R5 = 0, TR5 = 0;
   size_t lds5 = 0;
   // two-wave path (dft3.hip, k_*4): M = 2048 for 256 < L <= 512
   bool use4 = false;
@@ -232,7 +232,7 @@ int dft3_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm)
 struct Dft3GroupList {
   void* d = nullptr;  // device array of per-scale descriptors
   bool five = false;  // descriptors of the eight-points-per-lane kernel (dft5.hip)
-  int split = 2;      // ... and its waves per ring set
+  int threads = 512;  // ... and its workgroup size
   int n = 0, blocks = 0;
   size_t lds = 0;
   double px_elems = 0;  // sum over scales of bl (2 bl - 1): coefficients per chain slot
@@ -245,8 +245,7 @@ int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut&
 // eight-points-per-lane path (dft5.hip)
 int dft5_r0(int n);  // Mh / 64 for ring length n, 0 = not covered (n > 512)
 int dft5_make_tables(int n, Dft5Tables* t);
-int dft5_split();  // PXM_DFT_SPLIT at the time of the call (plan creation)
-void dft5_geometry(int n, int split, int* R, int* TR, size_t* lds);
+void dft5_geometry(int n, int* R, int* TR, size_t* lds);
 int dft5_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft5_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
 int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,

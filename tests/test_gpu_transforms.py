@@ -153,10 +153,10 @@ def test_two_wave_dft_path_L_above_256(monkeypatch):
 
 @pytest.mark.parametrize("L", [4, 10, 33, 64, 100, 128, 200, 256])
 def test_dft_kernel_variants_agree_and_match_oracle(L, monkeypatch):
-    """The phi-DFT of every L <= 256 has three kernels: eight points per lane with one half-size convolution per
-    wave (default, csrc/dft5.hip), the same with both halves in one wave (PXM_DFT_SPLIT=1), and the 16-points-per-
-    lane wave path (PXM_DFT_NO_V=1, csrc/dft3.hip).  All four SHT operators through each of them match the oracle;
-    L covers every Mh = 64 ... 512 (1, 2, 4, 8 rings per wave) and lengths that are not powers of two."""
+    """The phi-DFT of every L <= 256 has two kernels: eight points per lane, one half-size convolution per wave
+    (default, csrc/dft5.hip; also with 2 chains per workgroup, PXM_DFT_R=2), and the 16-points-per-lane wave path
+    (PXM_DFT_NO_V=1, csrc/dft3.hip).  All four SHT operators through each of them match the oracle; L covers every
+    Mh = 64 ... 512 (8, 4, 2, 1 rings per wave pair) and lengths that are not powers of two."""
     from oracle import ssht
     from pxmcmc_amd import ops
 
@@ -171,7 +171,7 @@ def test_dft_kernel_variants_agree_and_match_oracle(L, monkeypatch):
         "forward": np.stack([T.forward(x) for x in f]),
         "inverse_adjoint": np.stack([T.inverse_adjoint(x) for x in f]),
     }
-    for env in ({}, {"PXM_DFT_SPLIT": "1"}, {"PXM_DFT_NO_V": "1"}):
+    for env in ({}, {"PXM_DFT_R": "2"}, {"PXM_DFT_NO_V": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         plan = ops.ShtPlan(L, spin, max_chains=C)
