@@ -204,6 +204,10 @@ int pxm_reduce_l1(const void* X, const double* w, double* out, double* scratch, 
 /* logpi's L2 = vdot(d, invcov d), d = data - preds (pxmcmc/mcmc.py:78-79): out[c] = (re, im) */
 int pxm_reduce_l2(const void* preds, const void* data, const void* invcov, int invcov_complex,
                   double* out, double* scratch, int64_t n, int C, int dtype, pxm_stream_t stream);
+/* np.vdot(a, b) per chain: out[c] = sum conj(a) b as (re, im) -- logpi's L2 = vdot(d, invcov @ d) when invcov is a
+ * full (sparse) matrix applied with pxm_csr_matvec (pxmcmc/forward.py:75-78, mcmc.py:78-79) */
+int pxm_reduce_vdot(const void* a, const void* b, double* out, double* scratch, int64_t n, int C, int dtype,
+                    pxm_stream_t stream);
 /* PxMALA.calc_logtransition, literal (pxmcmc/mcmc.py:281-289): out[c] = (re, im) */
 int pxm_logtransition(const void* X1, const void* X2, const void* proxf, const void* gradg,
                       const double* delta_dev, double delta, double lmda, double* out, double* scratch,

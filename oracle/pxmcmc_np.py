@@ -55,8 +55,20 @@ def mw_map_weights(L):
 
 
 # ---- pxmcmc/forward.py:74-88 -----------------------------------------------
+def apply_invcov(invcov, v):
+    """invcov @ v for the diagonal (1-D array) or full (2-D matrix, forward.py:75-78) inverse covariance"""
+    return invcov @ v if np.ndim(invcov) == 2 else invcov * v
+
+
 def invcov_diag(data, sig_d):
-    """Diagonal of the inverse covariance, incl. the complex-variance quirk (:81-82)."""
+    """Diagonal of the inverse covariance, incl. the complex-variance quirk (:81-82); a 2-D ``sig_d`` is the
+    covariance MATRIX and gives its inverse (:75-78 as intended: scipy rejects the dense input the reference
+    passes, see tests/golden/make_golden_r2.py)."""
+    if np.ndim(sig_d) == 2 or hasattr(sig_d, "toarray"):
+        cov = sig_d.toarray() if hasattr(sig_d, "toarray") else np.asarray(sig_d)
+        if cov.shape[0] != cov.shape[1]:
+            raise ValueError("Covariance matrix should be square")
+        return np.linalg.inv(cov)
     var = np.asarray(sig_d) ** 2
     if np.iscomplexobj(data) and not np.iscomplexobj(var):
         var = var / np.sqrt(2) * (1 + 1j)
@@ -168,7 +180,7 @@ class ForwardOperator:
         return self.measurement.forward(self.transform.inverse(X))
 
     def calc_gradg(self, preds):
-        g = self.measurement.adjoint(self.invcov * (preds - self.data))
+        g = self.measurement.adjoint(apply_invcov(self.invcov, preds - self.data))
         if self.setting == "analysis":
             return g
         return self.transform.inverse_adjoint(g)
@@ -259,7 +271,7 @@ class PathIntegral:
 # ---- pxmcmc/mcmc.py:71-82, 185-201, 277-289 ------------------------------------
 def logpi(X, preds, data, invcov, prior_fn, mu):
     diff = data - preds
-    L2 = np.vdot(diff, invcov * diff)
+    L2 = np.vdot(diff, apply_invcov(invcov, diff))
     prior = prior_fn(X)
     return -mu * prior - L2, L2, prior
 

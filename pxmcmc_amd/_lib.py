@@ -84,6 +84,7 @@ SIGNATURES = {
     "pxm_randn": (c_int, [c_vp, c_i64, c_int, c_int, c_u64, c_u64, c_u64, c_vp]),
     "pxm_reduce_l1": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_reduce_l2": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
+    "pxm_reduce_vdot": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_logtransition": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_pxmala_accept": (c_int, [c_vp, c_vp, c_u64, c_u64, c_u64, c_vp, c_vp, c_int, c_dbl, c_i64, c_int, c_vp]),
     "pxm_select_copy": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),

@@ -160,6 +160,25 @@ __global__ void k_l2_partial(const double* __restrict__ preds, const double* __r
   if (threadIdx.x == 0) reinterpret_cast<double2*>(part)[(int64_t)c * gridDim.x + blockIdx.x] = tot;
 }
 
+// vdot(a, b) = sum conj(a) * b per chain (logpi's L2 with a full inverse covariance: b = invcov @ a)
+template <bool CPLX>
+__global__ void k_vdot_partial(const double* __restrict__ A, const double* __restrict__ Bv, double* __restrict__ part, int64_t n) {
+  const int c = blockIdx.y;
+  const int64_t base = (int64_t)c * n;
+  double2 acc{0.0, 0.0};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    if (CPLX) {
+      const double2 a = reinterpret_cast<const double2*>(A)[base + i], b = reinterpret_cast<const double2*>(Bv)[base + i];
+      acc.x += a.x * b.x + a.y * b.y;
+      acc.y += a.x * b.y - a.y * b.x;
+    } else {
+      acc.x += A[base + i] * Bv[base + i];
+    }
+  }
+  double2 tot = block_sum2(acc);
+  if (threadIdx.x == 0) reinterpret_cast<double2*>(part)[(int64_t)c * gridDim.x + blockIdx.x] = tot;
+}
+
 // S = sum (X2 - X1 - (d/2) g)^2 with g = -((X1 - proxf)/l) - gradg; complex squares, no abs (literal)
 template <bool CPLX>
 __global__ void k_logtrans_partial(const double* __restrict__ X1, const double* __restrict__ X2,
@@ -390,6 +409,19 @@ int pxm_reduce_l2(const void* preds, const void* data, const void* invcov, int i
   else if (dtype) hipLaunchKernelGGL((k_l2_partial<true, false>), g, b, 0, st, p, d, ic, part, n);
   else hipLaunchKernelGGL((k_l2_partial<false, false>), g, b, 0, st, p, d, ic, part, n);
   hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, out, RED_SLICES, 0, (const double*)nullptr, 0.0);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_reduce_vdot(const void* a, const void* b, double* out, double* scratch, int64_t n, int C, int dtype,
+                    pxm_stream_t stream) {
+  PXM_REQUIRE(n >= 0 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_reduce_vdot: bad n / C / dtype");
+  PXM_REQUIRE(a && b && out && scratch, "pxm_reduce_vdot: null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(RED_SLICES, C), blk(256);
+  if (dtype) hipLaunchKernelGGL(k_vdot_partial<true>, g, blk, 0, st, (const double*)a, (const double*)b, scratch, n);
+  else hipLaunchKernelGGL(k_vdot_partial<false>, g, blk, 0, st, (const double*)a, (const double*)b, scratch, n);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, scratch, out, RED_SLICES, 0, (const double*)nullptr, 0.0);
   PXM_HIP(hipGetLastError());
   return 0;
 }

@@ -125,8 +125,12 @@ class PxMCMC:
         p = ops.as_device(preds)
         dt = self.forward._resid_dtype(p) if hasattr(self.forward, "_resid_dtype") else p.dtype
         data = ops.as_device(self.forward.data).reshape(-1).to(dt)
-        invcov = self.forward.invcov.diag if hasattr(self.forward.invcov, "diag") else ops.as_device(self.forward.invcov.diagonal())
-        L2 = ops.reduce_l2(p.to(dt), data, invcov)
+        if hasattr(self.forward.invcov, "matvec"):  # full inverse covariance (forward.py:75-78): vdot(d, invcov @ d)
+            d = ops.residual_grad(p.to(dt), data, self.forward.invcov.ones)  # preds - data: vdot(-d, W(-d)) = vdot(d, W d)
+            L2 = ops.reduce_vdot(d, self.forward.invcov.matvec(d))
+        else:
+            invcov = self.forward.invcov.diag if hasattr(self.forward.invcov, "diag") else ops.as_device(self.forward.invcov.diagonal())
+            L2 = ops.reduce_l2(p.to(dt), data, invcov)
         prior = self.prior.prior(X)
         if not isinstance(prior, torch.Tensor):
             prior = torch.as_tensor(np.atleast_1d(np.asarray(prior, dtype=float)), device=L2.device)
@@ -241,6 +245,7 @@ class MYULA(PxMCMC):
         f = self.forward
         return (
             getattr(f, "setting", None) == "synthesis"
+            and hasattr(getattr(f, "invcov", None), "diag")  # (a full covariance matrix goes through the generic kernels)
             and type(f).calc_gradg.__qualname__.startswith("ForwardOperator")
             and isinstance(getattr(f, "transform", None), SphericalWaveletTransform)
             and isinstance(getattr(f, "measurement", None), Identity)

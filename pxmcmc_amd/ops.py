@@ -202,6 +202,17 @@ def reduce_l2(preds, data, invcov):
     return out
 
 
+def reduce_vdot(a, b):
+    """np.vdot(a, b) per chain -> complex128 [C]"""
+    x, _ = _batched(as_device(a))
+    y, _ = _batched(as_device(b, x.dtype))
+    if x.shape != y.shape:
+        raise ValueError("vdot: shape mismatch")
+    out = torch.empty(x.shape[0], dtype=_CPLX, device=x.device)
+    check(lib.pxm_reduce_vdot(_p(x), _p(y), _p(out), _p(_red_scratch(x.shape[0], x.device)), x.shape[1], x.shape[0], _dt(x), _stream()))
+    return out
+
+
 def logtransition(X1, X2, proxf, gradg, delta, lmda):
     """PxMALA.calc_logtransition, literal (pxmcmc/mcmc.py:281-289) -> complex128 [C]."""
     x1, _ = _batched(as_device(X1))

@@ -97,37 +97,24 @@ class S2_Wavelets_L1_Power_Weights(S2_Wavelets_L1):
     def __init__(self, setting, fwd, adj, T, L, B, J_min, dirs=1, spin=0, eta=1):
         super().__init__(setting, fwd, adj, T, L, B, J_min, dirs, spin)
         self.eta = eta
-        if setting == "synthesis":
-            self._get_weights()
-        else:
+        if setting != "synthesis":
             raise NotImplementedError
+        self.map_weights = self._power_weight_map()
         self.T = self.T * self.map_weights
         self._weights_dev = ops.as_device(self.map_weights * self.map_weights, torch.float64)
 
-    def _get_weights(self):
-        s = self._calculate_scaling_weights().flatten()
-        w = np.concatenate([w.flatten() for w in self._calculate_wavelet_weights()])
-        self.map_weights = np.concatenate([s, w])
-
-    @staticmethod
-    def _grid_weights(effective_L, value):
-        weights = np.full((effective_L, 2 * effective_L - 1), value)
-        thetas, _ = sample_positions(effective_L)
-        return (weights.T * np.sin(thetas)).T
-
-    def _calculate_scaling_weights(self):
-        phi_l, _ = wavelet_tiling(self.B, self.L, self.dirs, self.J_min, self.spin)
-        scaling_power = np.vdot(phi_l, phi_l).real
-        effective_L = int(np.nonzero(phi_l)[0].max()) + 1
-        return self._grid_weights(effective_L, 2 * np.pi ** 2 / (scaling_power * mw_size(effective_L)))
-
-    def _calculate_wavelet_weights(self):
-        bls = _multires_bandlimits(self.L, self.B, self.J_min)
-        _, psi_lm = wavelet_tiling(self.B, self.L, self.dirs, self.J_min, self.spin)
-        wavelet_powers = np.array([np.vdot(lm, lm).real for lm in psi_lm.T])
+    def _power_weight_map(self):
+        """One weight per coefficient, block by block [scaling | j = J_min .. J_max]: every sample of a block
+        carries 2 pi^2 peak^eta / (power * nsamples) * sin(theta) with the block's own grid (pxmcmc/prior.py:113-149).
+        Rows of the table below: (grid bandlimit, harmonic power of the kernel, peak degree ** eta)."""
+        phi_l, psi_lm = wavelet_tiling(self.B, self.L, self.dirs, self.J_min, self.spin)
         el = np.arange(self.L)
-        peak_ls = np.array([np.argmax(psi[el * el + el]) for psi in psi_lm.T])
-        return [
-            self._grid_weights(int(Le), (2 * np.pi ** 2) * (peak_l ** self.eta) / (power * mw_size(int(Le))))
-            for Le, power, peak_l in zip(bls[1:], wavelet_powers, peak_ls)
-        ]
+        table = [(int(np.nonzero(phi_l)[0].max()) + 1, np.vdot(phi_l, phi_l).real, 1.0)]  # scaling: no peak factor
+        for bl, psi in zip(_multires_bandlimits(self.L, self.B, self.J_min)[1:], psi_lm.T):
+            table.append((int(bl), np.vdot(psi, psi).real, float(np.argmax(psi[el * el + el])) ** self.eta))
+        blocks = []
+        for bl, power, peak in table:
+            thetas, _ = sample_positions(bl)
+            ring = (2 * np.pi ** 2) * peak / (power * mw_size(bl)) * np.sin(thetas)
+            blocks.append(np.repeat(ring, 2 * bl - 1))
+        return np.concatenate(blocks)

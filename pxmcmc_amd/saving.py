@@ -40,25 +40,28 @@ def save_mcmc(mcmc, params, outpath, filename="outputs", **kwargs):
     Saves the MCMC run (pxmcmc/saving.py:5-36).  Any variable selected by the sampler's ``track`` option is a
     dataset; runtime parameters and ``**kwargs`` are attributes.  Returns the path written.
     """
-    data = {}
-    for attr, name, dtype in _DATASETS:
-        if hasattr(mcmc, attr):
-            arr = np.asarray(getattr(mcmc, attr))
-            data[name] = arr.astype(dtype) if dtype else arr
+    present = [(attr, name, dtype) for attr, name, dtype in _DATASETS if hasattr(mcmc, attr)]
     attrs = {k: getattr(params, k) for k in params.__dict__.keys()}
     attrs.update(kwargs)
     try:
         import h5py
     except ImportError:
         h5py = None
-    if h5py is not None:
+    if h5py is not None:  # the reference's calls, one for one (pinned by tests/golden/g13_save_mcmc_format.json)
         path = os.path.join(outpath, f"{filename}.hdf5")
         with h5py.File(path, "w") as f:
-            for name, arr in data.items():
-                f.create_dataset(name, data=arr)
+            for attr, name, dtype in present:
+                if dtype is None:
+                    f.create_dataset(name, data=getattr(mcmc, attr))
+                else:
+                    f.create_dataset(name, data=getattr(mcmc, attr), dtype=dtype)
             for k, v in attrs.items():
                 f.attrs[k] = v
         return path
+    data = {}
+    for attr, name, dtype in present:
+        arr = np.asarray(getattr(mcmc, attr))
+        data[name] = arr.astype(dtype) if dtype else arr
     path = os.path.join(outpath, f"{filename}.npz")
     np.savez(path, __attrs__=np.array(json.dumps({k: _attr_value(v) for k, v in attrs.items()})), **data)
     return path

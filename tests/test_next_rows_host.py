@@ -69,3 +69,60 @@ def test_build_mask_and_galactic_latitude():
     frac = 1 - mask.mean()
     assert 0.45 < frac < 0.75  # two 40-degree bands crossing at 60 degrees cover roughly 60 % of the sphere
     assert np.array_equal(build_mask(L, 0), np.ones((L, 2 * L - 1)))
+
+
+def test_g13_save_mcmc_issues_the_reference_h5py_calls(monkeypatch, tmp_path):
+    """h5py is absent from this image: the HDF5 branch of save_mcmc runs against the same recording stub of
+    h5py.File the fixture was captured with from the reference (tests/golden/make_golden_r2.py) and must issue the
+    identical create_dataset / attribute calls -- names, order, dtype arguments, data dtypes and shapes, attribute
+    names, types and values (pxmcmc/saving.py:18-36)."""
+    import json
+    import sys
+    import types
+
+    from conftest import GOLDEN
+    from pxmcmc_amd.mcmc import PxMCMCParams
+    from pxmcmc_amd.saving import save_mcmc
+
+    ref = json.load(open(os.path.join(GOLDEN, "g13_save_mcmc_format.json")))
+    calls = []
+
+    class _Attrs(dict):
+        def __setitem__(self, k, v):
+            calls.append(["attr", k, type(v).__name__, repr(v)])
+            super().__setitem__(k, v)
+
+    class _File:
+        def __init__(self, path, mode):
+            calls.append(["open", os.path.basename(path), mode])
+            self.attrs = _Attrs()
+
+        def create_dataset(self, name, data=None, dtype=None):
+            a = np.asarray(data)
+            calls.append(["dataset", name, None if dtype is None else str(dtype), str(a.dtype), list(a.shape)])
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    stub = types.ModuleType("h5py")
+    stub.File = _File
+    monkeypatch.setitem(sys.modules, "h5py", stub)
+
+    class Run:
+        pass
+
+    rng = np.random.default_rng(5)  # the generator's own sequence of draws
+    for kind in ("myula", "pxmala"):
+        calls.clear()
+        r = Run()
+        r.logPi, r.L2s, r.priors = rng.normal(size=7), rng.random(7), rng.random(7)
+        r.chain, r.preds = rng.normal(size=(7, 12)), rng.normal(size=(7, 5))
+        if kind == "pxmala":
+            r.acceptance_trace = [1, 0, 1, 1, 0, 1, 0, 1, 1]
+            r.deltas_trace = list(rng.random(10))
+        params = PxMCMCParams(lmda=1e-6, delta=5e-7, mu=2.0, nsamples=7, nburn=3, ngap=2, complex=False, verbosity=0)
+        save_mcmc(r, params, str(tmp_path), filename="run", L=16, setting="synthesis", time="0:00:01")
+        assert calls == ref[kind], kind

@@ -178,3 +178,24 @@ def test_g10_power_weights():
         np.testing.assert_allclose(pw.T, g[f"pw_T_{i}"], rtol=1e-12, atol=1e-22)
         np.testing.assert_allclose(pw.prior(X), g[f"pw_prior_{i}"], rtol=1e-13)
         np.testing.assert_allclose(pw.proxf(X), g[f"pw_prox_{i}"], rtol=1e-13, atol=1e-18)
+
+
+def test_g12_full_covariance_oracle():
+    """2-D covariance (pxmcmc/forward.py:75-78): the oracle's inverse-matrix path against the reference's own
+    calc_gradg / logpi evaluated with that matrix (the reference's constructor itself raises for a 2-D sig_d in its
+    pinned environment -- recorded in the fixture)."""
+    import json
+
+    from oracle import pxmcmc_np as ref
+
+    g = golden("g12_full_covariance.npz")
+    raised = json.loads(str(g["reference_2d_branch"]))
+    assert raised["ndarray"].startswith("TypeError") and raised["sparse"].startswith("TypeError")
+    cov, mu = g["cov"], float(g["mu"])
+    P = cov.shape[0]
+    for tag in ("r", "c"):
+        data, preds, X = g[f"data_{tag}"], g[f"preds_{tag}"], g[f"X_{tag}"]
+        op = ref.ForwardOperator(data, cov, "analysis", ref.IdentityTransform(), ref.Identity(P, P), P)
+        np.testing.assert_allclose(op.calc_gradg(preds), g[f"gradg_{tag}"], rtol=1e-11, atol=1e-12)
+        lp = ref.logpi(X, preds, data, op.invcov, ref.L1("analysis", None, None, 0.1).prior, mu)
+        np.testing.assert_allclose(np.array(lp), g[f"logpi_{tag}"], rtol=1e-11)
