@@ -172,6 +172,22 @@ int pxm_wav_ring_step(pxm_wav_plan_t plan, const void* X, double w_re, double w_
                       uint64_t seed, uint64_t chain0, uint64_t iter, void* X_out, int C, pxm_stream_t stream);
 int pxm_wav_ring_preds(pxm_wav_plan_t plan, void* preds, int C, pxm_stream_t stream);
 
+/* Weak-lensing measurement fused with the wavelet synthesis (BASELINE config 5; pxmcmc/forward.py:63-72 with
+ * transform = SphericalWaveletTransform (transforms.py:114-139) and measurement = WeakLensing
+ * (measurements.py:209-304)).  Between the synthesis and the measurement the reference runs an inverse SHT and
+ * a forward SHT of the same band-limited field at the same bandlimit -- the identity on harmonic coefficients
+ * (exact MW quadrature) -- so the harmonic kernel k_l is applied to the synthesised coefficients directly:
+ *   pxm_wav_wl_attach  : spin-2 tables; pix2data [L(2L-1)] maps a pixel to its index in the masked data vector
+ *                        (< 0 = masked; NULL = no mask, ndata = L(2L-1)); weight [ndata] = WeakLensing.inv_cov or
+ *                        NULL.  Both stay caller-owned and must outlive the plan's use of them.
+ *   pxm_wav_wl_forward : gamma [C][ndata] = WeakLensing.forward(transform.inverse(X))
+ *   pxm_wav_wl_adjoint : X_out [C][ncoefs] = transform.inverse_adjoint(WeakLensing.adjoint(g)), g = gamma, or the
+ *                        residual invcov .* (gamma - data) when data / invcov ([ndata]) are given (calc_gradg). */
+int pxm_wav_wl_attach(pxm_wav_plan_t plan, const int32_t* pix2data, const double* weight, int64_t ndata);
+int pxm_wav_wl_forward(pxm_wav_plan_t plan, const void* X, void* gamma, int C, pxm_stream_t stream);
+int pxm_wav_wl_adjoint(pxm_wav_plan_t plan, const void* gamma, const void* data, const void* invcov,
+                       int invcov_complex, void* X_out, int C, pxm_stream_t stream);
+
 /* ---- elementwise / reductions ---------------------------------------------------- */
 /* dtype: 0 = float64, 1 = complex128.  n = elements per chain. */
 /* utils.soft (pxmcmc/utils.py:55-67,84-88): T vector [n] (shared by chains) or NULL -> T_scalar */
@@ -219,6 +235,32 @@ int pxm_logtransition(const void* X1, const void* X2, const void* proxf, const v
 int pxm_pxmala_accept(const double* logalpha_terms, const double* u, uint64_t seed, uint64_t chain0,
                       uint64_t iter, int32_t* accept_out, double* delta_dev, int tune, double lmda,
                       int64_t it_index, int C, pxm_stream_t stream);
+/* One PxMALA iteration with every per-iteration quantity on the device (pxmcmc/mcmc.py:230-260).
+ *   pxm_pxmala_propose : X' = chain_step(X, proxf, gradg) with per-chain delta_dev [C]; proxf' = soft(X', T);
+ *                        logtrans_out[c] = calc_logtransition(X, X', proxf, gradg) as (re, im);
+ *                        prior_out[c] = sum |w X'| (w = prior_weights [n] or NULL) -- ONE pass over the state.
+ *                        iter_dev: optional caller-owned device counter added to iter (HIP-graph replay).
+ *                        scratch: 4 * pxm_reduce_scratch_doubles(C) doubles.
+ *   pxm_pxmala_accept2 : logalpha = Re(logtrans_pc + logpi' - logtrans_cp - logpi), logpi' = -mu prior' - L2';
+ *                        accept iff log(u) < logalpha (u injected [C] or the Philox uniform of (seed, chain, iteration));
+ *                        accepted chains take (logpi', L2', prior') into their state scalars (logpi_c, L2_c as (re, im),
+ *                        prior_c); delta_dev adapted when tune (:277-279) with the iteration number iter + *iter_dev;
+ *                        acc_trace / delta_trace: optional [chunk][C] ring buffers written at row iteration % chunk.
+ *   pxm_select_copy_many : up to 4 arrays per call, dst_a[c] = src_a[c] for accepted chains.
+ *   pxm_counter_add    : *counter += inc on the stream (after every reader of the iteration). */
+int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, const double* T, double T_scalar,
+                       const double* prior_weights, const double* delta_dev, double lmda, const void* noise,
+                       int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter, const uint64_t* iter_dev,
+                       void* X_prop, void* proxf_prop, double* logtrans_out, double* prior_out, double* scratch,
+                       int64_t n, int C, int dtype, pxm_stream_t stream);
+int pxm_pxmala_accept2(const double* logtrans_pc, const double* logtrans_cp, const double* prior_p, const double* L2_p,
+                       double mu, double* logpi_c, double* L2_c, double* prior_c, const double* u, uint64_t seed,
+                       uint64_t chain0, uint64_t iter, const uint64_t* iter_dev, int32_t* accept_out, double* delta_dev,
+                       int tune, double lmda, int32_t* acc_trace, double* delta_trace, int chunk, int C,
+                       pxm_stream_t stream);
+int pxm_select_copy_many(const int32_t* flag, int narrays, const void* const* src, void* const* dst, const int64_t* n,
+                         const int* esize, int C, pxm_stream_t stream);
+int pxm_counter_add(uint64_t* counter_dev, uint64_t inc, pxm_stream_t stream);
 /* per-chain conditional copy: dst[c] = src[c] where flag[c] != 0; n elements of esize bytes */
 int pxm_select_copy(const int32_t* flag, const void* src, void* dst, int64_t n, int esize, int C,
                     pxm_stream_t stream);

@@ -71,6 +71,9 @@ SIGNATURES = {
         [c_vp, c_vp, c_dbl, c_dbl, c_vp, c_dbl, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_int, c_vp],
     ),
     "pxm_wav_ring_preds": (c_int, [c_vp, c_vp, c_int, c_vp]),
+    "pxm_wav_wl_attach": (c_int, [c_vp, c_vp, c_vp, c_i64]),
+    "pxm_wav_wl_forward": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
+    "pxm_wav_wl_adjoint": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "pxm_soft": (c_int, [c_vp, c_vp, c_dbl, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_residual_grad": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_myula_step": (
@@ -87,6 +90,18 @@ SIGNATURES = {
     "pxm_reduce_vdot": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_logtransition": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_pxmala_accept": (c_int, [c_vp, c_vp, c_u64, c_u64, c_u64, c_vp, c_vp, c_int, c_dbl, c_i64, c_int, c_vp]),
+    "pxm_pxmala_propose": (
+        c_int,
+        [c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+         c_i64, c_int, c_int, c_vp],
+    ),
+    "pxm_pxmala_accept2": (
+        c_int,
+        [c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp, c_vp, c_vp, c_vp, c_u64, c_u64, c_u64, c_vp, c_vp, c_vp, c_int, c_dbl, c_vp, c_vp,
+         c_int, c_int, c_vp],
+    ),
+    "pxm_select_copy_many": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
+    "pxm_counter_add": (c_int, [c_vp, c_u64, c_vp]),
     "pxm_select_copy": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_wl_harmonic_mapping": (c_int, [c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
     "pxm_wl_mask_gather": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp]),

@@ -72,16 +72,7 @@ __global__ void k_px2ring(DftArgs a, PxIn in, double* __restrict__ G, int ncol, 
     double2 v{0.0, 0.0};
     if (j < n && c < C) {
       const int64_t e = in.ring0 + (int64_t)t * n + j;
-      v = reinterpret_cast<const double2*>(in.f)[(int64_t)c * in.chain_stride + e];
-      if (in.data) {  // residual invcov .* (preds - data)   (pxmcmc/forward.py:66-69)
-        const double2 d = reinterpret_cast<const double2*>(in.data)[e];
-        v = csub(v, d);
-        if (in.invcov_complex) v = cmul(reinterpret_cast<const double2*>(in.invcov)[e], v);
-        else {
-          const double w = in.invcov[e];
-          v = double2{w * v.x, w * v.y};
-        }
-      }
+      v = px_in_load(in, c, e);
       v = cmul(v, a.chirp[j]);
     }
     buf[idx] = v;
@@ -133,13 +124,14 @@ __global__ void k_ring2px(DftArgs a, const double* __restrict__ G, int ncol, PxO
     const int64_t e = out.ring0 + (int64_t)t * n + p;
     const int64_t ce = (int64_t)c * out.chain_stride + e;
     if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
-    const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
+      const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
       const double2 x = reinterpret_cast<const double2*>(out.X)[ce];
       const double T = out.T ? out.T[e] : out.T_scalar;
       const double2 w = out.noise ? px_noise_load(out, c, e) : px_noise_philox(out, c, e, it_eff);
-      y = px_update(out, x, T, y, w);
+      reinterpret_cast<double2*>(out.f)[ce] = px_update(out, x, T, y, w);
+    } else {
+      px_out_store(out, c, e, y);
     }
-    reinterpret_cast<double2*>(out.f)[ce] = y;
   }
 }
 

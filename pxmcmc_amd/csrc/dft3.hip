@@ -242,15 +242,7 @@ __device__ __forceinline__ void px2ring_body(const Dft3Args& a, const PxIn& in, 
     double2 v{0.0, 0.0};
     if (j < n && ch < C && tv) {
       const int64_t e = in.ring0 + (int64_t)t * n + j;
-      v = reinterpret_cast<const double2*>(in.f)[(int64_t)ch * in.chain_stride + e];
-      if (in.data) {  // residual invcov .* (preds - data)   (pxmcmc/forward.py:66-69)
-        v = csub(v, reinterpret_cast<const double2*>(in.data)[e]);
-        if (in.invcov_complex) v = cmul(reinterpret_cast<const double2*>(in.invcov)[e], v);
-        else {
-          const double w = in.invcov[e];
-          v = double2{w * v.x, w * v.y};
-        }
-      }
+      v = px_in_load(in, ch, e);
       v = cmul(v, a.chirp[j]);
     }
     z[p] = v;
@@ -376,7 +368,7 @@ __device__ __forceinline__ void ring2px_body(const Dft3Args& a, double* __restri
       if (p >= n) continue;
       double2 y = cmul(z[q], a.chirp[p]);
       y.y = -y.y;
-      reinterpret_cast<double2*>(out.f)[ce0 + (int64_t)q * N1] = y;
+      px_out_store(out, ch, e0 + (int64_t)q * N1, y);
       if (RING_OUT && out.rdata) {  // residual invcov .* (image - data) goes back to the rings
         const int64_t e = e0 + (int64_t)q * N1;
         y = csub(y, reinterpret_cast<const double2*>(out.rdata)[e]);
@@ -508,15 +500,7 @@ __global__ __launch_bounds__(256, 2) void k_px2ring4(Dft4Args a4, PxIn in, doubl
     double2 v{0.0, 0.0};
     if (j < n && ch < C) {
       const int64_t e = in.ring0 + (int64_t)t * n + j;
-      v = reinterpret_cast<const double2*>(in.f)[(int64_t)ch * in.chain_stride + e];
-      if (in.data) {  // residual invcov .* (preds - data)   (pxmcmc/forward.py:66-69)
-        v = csub(v, reinterpret_cast<const double2*>(in.data)[e]);
-        if (in.invcov_complex) v = cmul(reinterpret_cast<const double2*>(in.invcov)[e], v);
-        else {
-          const double wt = in.invcov[e];
-          v = double2{wt * v.x, wt * v.y};
-        }
-      }
+      v = px_in_load(in, ch, e);
       v = cmul(v, a.chirp[j]);
       if (w) v = cmul(v, a4.tw2[j]);
     }
@@ -594,9 +578,10 @@ __global__ __launch_bounds__(256, 2) void k_ring2px4(Dft4Args a4, const double* 
       if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
         double2 wv = wn[q];
         if (!out.noise) wv = px_noise_philox(out, ch, e0 + off, it_eff);
-        y = px_update(out, xs[q], Ts[q], y, wv);
+        reinterpret_cast<double2*>(out.f)[ce0 + off] = px_update(out, xs[q], Ts[q], y, wv);
+      } else {
+        px_out_store(out, ch, e0 + off, y);
       }
-      reinterpret_cast<double2*>(out.f)[ce0 + off] = y;
     }
   }
 }

@@ -352,15 +352,7 @@ __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in,
     double2 v{0.0, 0.0};
     if (j < n && ch < C && tv) {
       const int64_t e = in.ring0 + (int64_t)t * n + j;
-      v = reinterpret_cast<const double2*>(in.f)[(int64_t)ch * in.chain_stride + e];
-      if (in.data) {  // residual invcov .* (preds - data)   (pxmcmc/forward.py:66-69)
-        v = csub(v, reinterpret_cast<const double2*>(in.data)[e]);
-        if (in.invcov_complex) v = cmul(reinterpret_cast<const double2*>(in.invcov)[e], v);
-        else {
-          const double w = in.invcov[e];
-          v = double2{w * v.x, w * v.y};
-        }
-      }
+      v = px_in_load(in, ch, e);
     }
     x[p] = v;
   }
@@ -457,7 +449,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
       }
       const int64_t e = e0 + (int64_t)(8 * R0) * p;
       double2 y{x[p].x, -x[p].y};
-      reinterpret_cast<double2*>(out.f)[(int64_t)ch * out.chain_stride + e] = y;
+      px_out_store(out, ch, e, y);
       if (RING_OUT && out.rdata) {  // residual invcov .* (image - data) goes back to the rings
         y = csub(y, reinterpret_cast<const double2*>(out.rdata)[e]);
         if (out.rinvcov_complex) y = cmul(reinterpret_cast<const double2*>(out.rinvcov)[e], y);

@@ -5,6 +5,8 @@
 #include "common.h"
 #include "sht_core.h"
 
+#include <algorithm>
+
 namespace pxm {
 
 static inline dim3 ew_grid(int64_t n, int C) {
@@ -51,6 +53,7 @@ struct NoiseSrc {
   const double* noise;
   int noise_complex;
   uint64_t seed, chain0, iter;
+  const uint64_t* iter_dev = nullptr;  // optional device-resident addend to iter (caller-owned counter: graph replay)
 };
 
 template <bool CPLX>
@@ -59,7 +62,7 @@ __device__ inline double2 draw_noise(const NoiseSrc& ns, int c, int64_t n, int64
     if (CPLX && ns.noise_complex) return reinterpret_cast<const double2*>(ns.noise)[(int64_t)c * n + i];
     return double2{ns.noise[(int64_t)c * n + i], 0.0};
   }
-  const uint64_t it = ns.iter;
+  const uint64_t it = ns.iter + (ns.iter_dev ? *ns.iter_dev : 0);
   if (CPLX && ns.noise_complex) {
     NormalPair q = philox_normal_pair(ns.seed, ns.chain0 + c, (uint64_t)i, it);
     return double2{q.z0, q.z1};
@@ -226,6 +229,134 @@ __global__ void k_reduce_final(const double* __restrict__ part, double* __restri
     reinterpret_cast<double2*>(out)[c] = v;
   }
 }
+
+// ---- PxMALA proposal in one pass (pxmcmc/mcmc.py:231,234,236-238,242 for the proposal) -----------------------
+//   X' = chain_step(X, proxf, gradg)                                   (mcmc.py:185-201)
+//   P' = soft(X', T)                                                   (prior.py:49-50)
+//   S  = sum (X' - X - (d/2) g)^2,  g = -((X - proxf)/l) - gradg       (calc_logtransition(X, X', proxf, gradg), :281-289)
+//   A  = sum |w X'|                                                     (prior.prior(X'), prior.py:28-35,83-84)
+// partial sums per slice: (S.re, S.im, A, -)
+template <bool CPLX>
+__global__ void k_pxmala_propose(const double* __restrict__ X, const double* __restrict__ P, const double* __restrict__ G,
+                                 const double* __restrict__ T, double Ts, const double* __restrict__ wp,
+                                 const double* __restrict__ delta_dev, double lmda, NoiseSrc ns, double* __restrict__ Xp,
+                                 double* __restrict__ Pp, double* __restrict__ part, int64_t n) {
+  const int c = blockIdx.y;
+  const int64_t base = (int64_t)c * n;
+  const double d = delta_dev[c];
+  double2 acc{0.0, 0.0};
+  double accA = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double2 w = draw_noise<CPLX>(ns, c, n, i);
+    const double t = T ? T[i] : Ts;
+    const double wa = wp ? fabs(wp[i]) : 1.0;
+    if (CPLX) {
+      const double2 x = reinterpret_cast<const double2*>(X)[base + i], p = reinterpret_cast<const double2*>(P)[base + i];
+      const double2 g = reinterpret_cast<const double2*>(G)[base + i];
+      const double2 xn = chain_step_cplx(x, p, g, w, d, lmda);
+      reinterpret_cast<double2*>(Xp)[base + i] = xn;
+      reinterpret_cast<double2*>(Pp)[base + i] = soft_cplx(xn, t);
+      const double2 gl{-((x.x - p.x) / lmda) - g.x, -((x.y - p.y) / lmda) - g.y};
+      const double2 r{xn.x - x.x - (d / 2) * gl.x, xn.y - x.y - (d / 2) * gl.y};
+      acc.x += r.x * r.x - r.y * r.y;
+      acc.y += 2 * r.x * r.y;
+      accA += wa * sqrt(fma(xn.x, xn.x, xn.y * xn.y));
+    } else {
+      const double x = X[base + i], p = P[base + i], g = G[base + i];
+      const double xn = chain_step_real(x, p, g, w.x, d, lmda);
+      Xp[base + i] = xn;
+      Pp[base + i] = soft_real(xn, t);
+      const double gl = -((x - p) / lmda) - g;
+      const double r = xn - x - (d / 2) * gl;
+      acc.x += r * r;
+      accA += wa * fabs(xn);
+    }
+  }
+  const double2 tot = block_sum2(acc);
+  const double2 totA = block_sum2(double2{accA, 0.0});
+  if (threadIdx.x == 0) {
+    double* o = part + ((int64_t)c * gridDim.x + blockIdx.x) * 4;
+    o[0] = tot.x;
+    o[1] = tot.y;
+    o[2] = totA.x;
+    o[3] = 0.0;
+  }
+}
+
+// lt[c] = -(d/2) S^2 (complex, literal: (1/2*d) == d/2 and the sum is squared again), prior[c] = A
+__global__ void k_pxmala_propose_final(const double* __restrict__ part, double* __restrict__ lt, double* __restrict__ prior,
+                                       int slices, const double* __restrict__ delta_dev) {
+  const int c = blockIdx.x;
+  double2 v{0.0, 0.0};
+  double a = 0.0;
+  if ((int)threadIdx.x < slices) {
+    const double* o = part + ((int64_t)c * slices + threadIdx.x) * 4;
+    v = double2{o[0], o[1]};
+    a = o[2];
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    v.x += __shfl_down(v.x, off);
+    v.y += __shfl_down(v.y, off);
+    a += __shfl_down(a, off);
+  }
+  if (threadIdx.x == 0) {
+    const double d = delta_dev[c];
+    const double2 s2 = cmul(v, v);
+    reinterpret_cast<double2*>(lt)[c] = double2{-(1.0 / 2 * d) * s2.x, -(1.0 / 2 * d) * s2.y};
+    prior[c] = a;
+  }
+}
+
+// Metropolis test, state bookkeeping, delta adaptation and traces of one PxMALA iteration, one thread per chain
+// (pxmcmc/mcmc.py:244-260,277-279).  logpi' = -mu prior' - L2' (mcmc.py:81); only real parts enter logalpha.
+__global__ void k_pxmala_accept2(const double2* __restrict__ lt_pc, const double2* __restrict__ lt_cp,
+                                 const double* __restrict__ prior_p, const double2* __restrict__ L2_p, double mu,
+                                 double2* __restrict__ logpi_c, double2* __restrict__ L2_c, double* __restrict__ prior_c,
+                                 const double* __restrict__ u, uint64_t seed, uint64_t chain0, uint64_t iter,
+                                 const uint64_t* __restrict__ iter_dev, int32_t* __restrict__ accept,
+                                 double* __restrict__ delta_dev, int tune, double lmda, int32_t* __restrict__ acc_trace,
+                                 double* __restrict__ delta_trace, int chunk, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const uint64_t it = iter + (iter_dev ? *iter_dev : 0);
+  const double2 lpp{-mu * prior_p[c] - L2_p[c].x, -L2_p[c].y};
+  const double logalpha = lt_pc[c].x + lpp.x - lt_cp[c].x - logpi_c[c].x;
+  const double uu = u ? u[c] : philox_uniform(seed, chain0 + c, it);
+  const int acc = log(uu) < logalpha ? 1 : 0;
+  accept[c] = acc;
+  if (acc) {
+    logpi_c[c] = lpp;
+    L2_c[c] = L2_p[c];
+    prior_c[c] = prior_p[c];
+  }
+  double d = delta_dev[c];
+  if (tune) {  // pxmcmc/mcmc.py:277-279
+    d = d * (1 + (acc - 0.5) / pow((double)(it + 1), 0.75));
+    d = fmin(fmax(d, lmda * 1e-8), lmda / 2);
+    delta_dev[c] = d;
+  }
+  if (acc_trace) {
+    const int64_t k = (int64_t)(it % (uint64_t)chunk);
+    acc_trace[k * C + c] = acc;
+    delta_trace[k * C + c] = d;
+  }
+}
+
+struct CopySet {
+  const uint64_t* src[4];
+  uint64_t* dst[4];
+  int64_t nwords[4];
+};
+__global__ void k_select_copy_many(const int32_t* __restrict__ flag, CopySet cs) {
+  const int c = blockIdx.y, a = blockIdx.z;
+  if (!flag[c]) return;
+  const int64_t nw = cs.nwords[a];
+  const uint64_t* s = cs.src[a] + (int64_t)c * nw;
+  uint64_t* d = cs.dst[a] + (int64_t)c * nw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nw; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+}
+
+__global__ void k_counter_add(uint64_t* c, uint64_t inc) { *c += inc; }
 
 // Reductions run in two deterministic stages through a CALLER-OWNED scratch of pxm_reduce_scratch_doubles(C)
 // doubles (partial sums of every slice, then the per-chain totals): no library-owned buffer is shared between
@@ -441,6 +572,72 @@ int pxm_logtransition(const void* X1, const void* X2, const void* proxf, const v
     hipLaunchKernelGGL(k_logtrans_partial<false>, g, b, 0, st, (const double*)X1, (const double*)X2,
                        (const double*)proxf, (const double*)gradg, delta_dev, delta, lmda, part, n);
   hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, out, RED_SLICES, 1, delta_dev, delta);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, const double* T, double T_scalar,
+                       const double* prior_weights, const double* delta_dev, double lmda, const void* noise,
+                       int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter, const uint64_t* iter_dev,
+                       void* X_prop, void* proxf_prop, double* logtrans_out, double* prior_out, double* scratch,
+                       int64_t n, int C, int dtype, pxm_stream_t stream) {
+  PXM_REQUIRE(n >= 1 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_pxmala_propose: bad n / C / dtype");
+  PXM_REQUIRE(X && proxf && gradg && delta_dev && X_prop && proxf_prop && logtrans_out && prior_out && scratch,
+              "pxm_pxmala_propose: null buffer");
+  PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_pxmala_propose: complex noise needs a complex state");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 g(RED_SLICES, C), b(256);
+  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, iter_dev};
+  if (dtype)
+    hipLaunchKernelGGL(k_pxmala_propose<true>, g, b, 0, st, (const double*)X, (const double*)proxf, (const double*)gradg, T,
+                       T_scalar, prior_weights, delta_dev, lmda, ns, (double*)X_prop, (double*)proxf_prop, scratch, n);
+  else
+    hipLaunchKernelGGL(k_pxmala_propose<false>, g, b, 0, st, (const double*)X, (const double*)proxf, (const double*)gradg, T,
+                       T_scalar, prior_weights, delta_dev, lmda, ns, (double*)X_prop, (double*)proxf_prop, scratch, n);
+  hipLaunchKernelGGL(k_pxmala_propose_final, dim3(C), dim3(64), 0, st, scratch, logtrans_out, prior_out, RED_SLICES, delta_dev);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_pxmala_accept2(const double* logtrans_pc, const double* logtrans_cp, const double* prior_p, const double* L2_p,
+                       double mu, double* logpi_c, double* L2_c, double* prior_c, const double* u, uint64_t seed,
+                       uint64_t chain0, uint64_t iter, const uint64_t* iter_dev, int32_t* accept_out, double* delta_dev,
+                       int tune, double lmda, int32_t* acc_trace, double* delta_trace, int chunk, int C,
+                       pxm_stream_t stream) {
+  PXM_REQUIRE(C >= 1 && logtrans_pc && logtrans_cp && prior_p && L2_p && logpi_c && L2_c && prior_c && accept_out && delta_dev,
+              "pxm_pxmala_accept2: null buffer");
+  PXM_REQUIRE((acc_trace == nullptr) == (delta_trace == nullptr) && (!acc_trace || chunk >= 1), "pxm_pxmala_accept2: bad trace buffers");
+  hipLaunchKernelGGL(k_pxmala_accept2, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double2*)logtrans_pc,
+                     (const double2*)logtrans_cp, prior_p, (const double2*)L2_p, mu, (double2*)logpi_c, (double2*)L2_c, prior_c, u,
+                     seed, chain0, iter, iter_dev, accept_out, delta_dev, tune, lmda, acc_trace, delta_trace, chunk, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_select_copy_many(const int32_t* flag, int narrays, const void* const* src, void* const* dst, const int64_t* n,
+                         const int* esize, int C, pxm_stream_t stream) {
+  PXM_REQUIRE(C >= 1 && flag && narrays >= 1 && narrays <= 4 && src && dst && n && esize, "pxm_select_copy_many: bad arguments");
+  CopySet cs;
+  int64_t most = 0;
+  for (int a = 0; a < 4; ++a) {
+    const int k = a < narrays ? a : 0;
+    PXM_REQUIRE(src[k] && dst[k] && n[k] >= 0 && esize[k] > 0 && esize[k] % 8 == 0, "pxm_select_copy_many: bad array");
+    cs.src[a] = (const uint64_t*)src[k];
+    cs.dst[a] = (uint64_t*)dst[k];
+    cs.nwords[a] = n[k] * (esize[k] / 8);
+    most = std::max(most, cs.nwords[a]);
+  }
+  if (most == 0) return 0;
+  dim3 g = ew_grid(most, C);
+  g.z = narrays;
+  hipLaunchKernelGGL(k_select_copy_many, g, dim3(256), 0, (hipStream_t)stream, flag, cs);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_counter_add(uint64_t* counter_dev, uint64_t inc, pxm_stream_t stream) {
+  PXM_REQUIRE(counter_dev, "pxm_counter_add: null counter");
+  hipLaunchKernelGGL(k_counter_add, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, inc);
   PXM_HIP(hipGetLastError());
   return 0;
 }

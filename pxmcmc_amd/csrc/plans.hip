@@ -340,6 +340,14 @@ struct pxm_wav_plan_s {
   int nside = 2;
   std::vector<int> lane_of;  // per scale: -1 = caller's stream, else side stream index
   Dft3GroupList dft_group;   // every scale's rings -> X' -> rings kernel in one grid (ring-space step)
+  // weak-lensing attachment (pxm_wav_wl_attach): spin-2 ring tables at L, their ring array, the harmonic kernel
+  ShtTables* T2 = nullptr;
+  int64_t offG2 = 0;
+  double* d_wlk = nullptr;             // [Rp] k_l = -sqrt((l+2)(l-1)/((l+1)l)), zero for l < 2 (measurements.py:151-171)
+  TaskList wl_inv, wl_invadj;          // class buffers --k_l B2--> G2 ; G2 --B2^T, k_l--> H_L
+  const int32_t* wl_gidx = nullptr;    // [P] pixel -> data index (caller-owned), null = no mask
+  const double* wl_gw = nullptr;       // [ndata] covariance weight (caller-owned) or null
+  int64_t wl_ndata = 0;
   std::vector<ShtTables*> held;  // table-cache entries this plan retains (each once)
   uint64_t* iter_dev = nullptr;  // device-resident Philox iteration counter of THIS plan (pxm_wav_set_iter_counter)
   Profiler prof;                 // live kernel timing of THIS plan (pxm_wav_profile_*)
@@ -414,6 +422,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
     p->offG.push_back(w); w += arr_size(p->bl[s], p->ncol);
     p->offH.push_back(w); w += arr_size(p->bl[s], p->ncol);
   }
+  p->offG2 = w; w += arr_size(L, p->ncol);  // (spin-2 rings of the weak-lensing attachment: 1/8 or so of the workspace)
   p->offS = w; w += (int64_t)p->Rp * p->ncol;
   PXM_HIP(hipMalloc(&p->ws, (size_t)w * sizeof(double)));
   PXM_HIP(hipMemset(p->ws, 0, (size_t)w * sizeof(double)));
@@ -575,9 +584,10 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   deferred_free(p->ws);
   deferred_free(p->d_kc_syn);
   deferred_free(p->d_kc_ana);
+  deferred_free(p->d_wlk);
   // (side streams / events belong to the per-device pool)
   TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj, &p->adj_invadj_R, &p->gram, &p->adj_invadj_D,
-                     &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj};
+                     &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj, &p->wl_inv, &p->wl_invadj};
   for (TaskList* t : tls) free_tasks(t);
   profiler_release(&p->prof);
   for (ShtTables* T : p->held) release_tables(T);
@@ -1018,6 +1028,88 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
   }
   if ((rc = wav_rings_to_blocks(p, out, C, st))) return rc;
   return wav_coeffs_to_rings(p, X_out, C, st);
+}
+
+// ---- weak-lensing measurement fused with the wavelet synthesis (BASELINE config 5) ------------------------
+// forward  = WeakLensing.forward(transform.inverse(X))   (pxmcmc/forward.py:63-64, measurements.py:221-230)
+//          = mask / weight( SHT2^-1( k_l .* SHT0( SHT0^-1( f_lm ) ) ) ),  f_lm = sum_j c_j kappa_j W^j_lm.
+// SHT0 o SHT0^-1 is the identity on band-limited coefficients (MW sampling theorem: exact quadrature), so the
+// inverse transform at L of the synthesis and the forward transform of the measurement are never executed: the
+// harmonic kernel is applied to f_lm directly while the spin-2 inverse GEMM stages its operand.  The adjoint
+// collapses the same way (SHT0^-1 adjoint o SHT0 adjoint = identity).  Results equal the composed operators to
+// round-off; 4 ring GEMMs and 4 DFT stages per forward + adjoint pair instead of 8 and 8.
+int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* weight, int64_t ndata) {
+  PXM_REQUIRE(p, "pxm_wav_wl_attach: null plan");
+  PXM_REQUIRE(p->fused_combine, "pxm_wav_wl_attach: needs the fused wavelet combine (PXM_NO_FUSED_COMBINE is set)");
+  PXM_REQUIRE(p->L >= 3, "pxm_wav_wl_attach: Bandlimit must be at least 3 for a spin-2 field");
+  const int64_t P = (int64_t)p->L * (2 * p->L - 1);
+  PXM_REQUIRE(ndata >= 0 && ndata <= P && (pix2data || ndata == P), "pxm_wav_wl_attach: bad mask description");
+  int rc;
+  if (!p->T2) {
+    if ((rc = get_tables(p->L, 2, (1u << TAB_INV) | (1u << TAB_INV_ADJ), &p->T2))) { p->T2 = nullptr; return rc; }
+    wav_hold(p, p->T2);
+    std::vector<double> k((size_t)p->Rp, 0.0);
+    for (int el = 2; el < p->L; ++el) k[el] = -std::sqrt(((el + 2.0) * (el - 1.0)) / ((el + 1.0) * el));
+    PXM_HIP(hipMalloc(&p->d_wlk, k.size() * sizeof(double)));
+    PXM_HIP(hipMemcpy(p->d_wlk, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<GemmTask> v;
+    GemmFuse sum2;
+    sum2.x2_base = p->offHB;
+    append_gemm_tasks(*p->T2, TAB_INV, p->ncol, p->offHA, p->L, p->Rp, p->offG2, p->L, p->Rp, p->d_wlk, p->offS, p->ws, v, 0, sum2);
+    if ((rc = upload_tasks(v, false, &p->wl_inv, {p->L}))) return rc;
+    v.clear();
+    GemmFuse rs;
+    rs.rscale = p->d_wlk;
+    append_gemm_tasks(*p->T2, TAB_INV_ADJ, p->ncol, p->offG2, p->L, p->Rp, p->offHL, p->L, p->Rp, nullptr, p->offS, p->ws, v, 0, rs);
+    if ((rc = upload_tasks(v, false, &p->wl_invadj, {p->L}))) return rc;
+  }
+  p->wl_gidx = pix2data;
+  p->wl_gw = weight;
+  p->wl_ndata = ndata;
+  return 0;
+}
+
+int pxm_wav_wl_forward(pxm_wav_plan_t p, const void* X, void* gamma, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, X, gamma, C, "pxm_wav_wl_forward");
+  if (rc) return rc;
+  PXM_REQUIRE(p->T2, "pxm_wav_wl_forward: call pxm_wav_wl_attach first");
+  hipStream_t st = (hipStream_t)stream;
+  if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
+  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;      // f_lm (class buffers)
+  if ((rc = run_tasks(p->wl_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;       // rings of the shear
+  PxOut out;
+  out.f = (double*)gamma;
+  out.chain_stride = p->wl_gidx ? p->wl_ndata : (int64_t)p->L * (2 * p->L - 1);
+  out.gidx = p->wl_gidx;
+  out.gw = p->wl_gidx ? p->wl_gw : nullptr;
+  PXM_REQUIRE(p->wl_gidx || !p->wl_gw, "pxm_wav_wl_forward: a covariance weight needs the pixel -> data map");
+  return launch_ring2px(p->dftL, p->ws + p->offG2, p->ncol, out, C, st);
+}
+
+// X_out = transform.inverse_adjoint(WeakLensing.adjoint(g)),  g = gamma  or, with data / invcov given, the
+// residual invcov .* (gamma - data) of ForwardOperator._gradg_analysis (pxmcmc/forward.py:66-72)
+int pxm_wav_wl_adjoint(pxm_wav_plan_t p, const void* gamma, const void* data, const void* invcov, int invcov_complex,
+                       void* X_out, int C, pxm_stream_t stream) {
+  int rc = wav_check(p, gamma, X_out, C, "pxm_wav_wl_adjoint");
+  if (rc) return rc;
+  PXM_REQUIRE(p->T2, "pxm_wav_wl_adjoint: call pxm_wav_wl_attach first");
+  PXM_REQUIRE((data == nullptr) == (invcov == nullptr), "pxm_wav_wl_adjoint: data and invcov come together");
+  PXM_REQUIRE(p->wl_gidx || !p->wl_gw, "pxm_wav_wl_adjoint: a covariance weight needs the pixel -> data map");
+  hipStream_t st = (hipStream_t)stream;
+  PxIn in;
+  in.f = (const double*)gamma;
+  in.chain_stride = p->wl_gidx ? p->wl_ndata : (int64_t)p->L * (2 * p->L - 1);
+  in.data = (const double*)data;
+  in.invcov = (const double*)invcov;
+  in.invcov_complex = invcov_complex;
+  in.gidx = p->wl_gidx;
+  in.gw = p->wl_gidx ? p->wl_gw : nullptr;
+  if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offG2, p->ncol, C, st))) return rc;
+  if ((rc = run_tasks(p->wl_invadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;    // k_l B2^T -> H_L
+  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;   // -> rings of every scale
+  PxOut out;
+  out.f = (double*)X_out;
+  return wav_rings_to_blocks(p, out, C, st);
 }
 
 int pxm_wav_analysis(pxm_wav_plan_t p, const void* f, void* X, int C, pxm_stream_t stream) {

@@ -205,6 +205,10 @@ struct PxIn {  // px2ring input: plain image, or residual invcov .* (preds - dat
   const double* invcov = nullptr;  // [P] real or complex
   int invcov_complex = 0;
   uint64_t* bump = nullptr;  // optional: workgroup 0 adds 1 to this counter (the Philox iteration counter)
+  // scatter mode (weak-lensing mask, pxmcmc/measurements.py:263-280,295-304): f / data / invcov are DATA-space
+  // arrays [ndata]; pixel e reads entry gidx[e] (masked pixels, gidx < 0, read zero) times the weight gw
+  const int32_t* gidx = nullptr;  // [P] pixel -> data index, < 0 = masked
+  const double* gw = nullptr;     // [ndata] covariance weight or null
 };
 struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a coefficient block
   double* f = nullptr;
@@ -223,6 +227,10 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
   const double* rdata = nullptr;    // [P] complex, shared by all chains
   const double* rinvcov = nullptr;  // [P] real or complex
   int rinvcov_complex = 0;
+  // gather mode (weak-lensing mask, pxmcmc/measurements.py:242-261,295-304; plain output only): f is a DATA-space
+  // array [C][chain_stride = ndata]; pixel e is written to entry gidx[e] times the weight gw, masked pixels are dropped
+  const int32_t* gidx = nullptr;
+  const double* gw = nullptr;
 };
 
 // device tables of the wave paths for a square (or M = 2 x square) Bluestein size: the filter transform in

@@ -16,6 +16,46 @@ namespace pxm {
 
 enum { PXM_MODE_REAL_NOISE = 0, PXM_MODE_CPLX_NOISE = 1, PXM_MODE_REAL_PAIRS = 2 };
 
+// input element e of chain ch of a px2ring kernel: plain image, residual invcov .* (preds - data)
+// (pxmcmc/forward.py:66-69), and / or the scatter of a masked data vector into the image (mask_adjoint + cov_weight)
+__device__ __forceinline__ double2 px_in_load(const PxIn& in, int ch, int64_t e) {
+  int64_t src = e;
+  if (in.gidx) {
+    const int idx = in.gidx[e];
+    if (idx < 0) return double2{0.0, 0.0};
+    src = idx;
+  }
+  double2 v = reinterpret_cast<const double2*>(in.f)[(int64_t)ch * in.chain_stride + src];
+  if (in.data) {
+    v = csub(v, reinterpret_cast<const double2*>(in.data)[src]);
+    if (in.invcov_complex) v = cmul(reinterpret_cast<const double2*>(in.invcov)[src], v);
+    else {
+      const double w = in.invcov[src];
+      v = double2{w * v.x, w * v.y};
+    }
+  }
+  if (in.gw) {
+    const double w = in.gw[src];
+    v = double2{w * v.x, w * v.y};
+  }
+  return v;
+}
+
+// plain output element e of chain ch of a ring2px kernel: the image, or its masked + weighted data vector
+__device__ __forceinline__ void px_out_store(const PxOut& out, int ch, int64_t e, double2 y) {
+  if (out.gidx) {
+    const int idx = out.gidx[e];
+    if (idx < 0) return;
+    if (out.gw) {
+      const double w = out.gw[idx];
+      y = double2{w * y.x, w * y.y};
+    }
+    reinterpret_cast<double2*>(out.f)[(int64_t)ch * out.chain_stride + idx] = y;
+    return;
+  }
+  reinterpret_cast<double2*>(out.f)[(int64_t)ch * out.chain_stride + e] = y;
+}
+
 // injected noise of (slot c, element e); real-pair noise is a real [2 * slots][chain_stride] array
 __device__ __forceinline__ double2 px_noise_load(const PxOut& o, int c, int64_t e) {
   if (o.mode == PXM_MODE_CPLX_NOISE) return reinterpret_cast<const double2*>(o.noise)[(int64_t)c * o.chain_stride + e];

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .measurements import Identity, PathIntegral
+from .measurements import Identity, PathIntegral, WeakLensing
 from .transforms import SphericalWaveletTransform
 from .utils import mw_size, to_like
 
@@ -119,7 +119,24 @@ class ForwardOperator:
         return self.measurement.forward(X)
 
     def _forward_synthesis(self, X):
+        plan = self._wl_plan()
+        if plan is not None:  # WeakLensing.forward(transform.inverse(X)) without the SHT0^-1 / SHT0 pair (pxm_wav_wl_forward)
+            return to_like(plan.wl_forward(X), X)
         return self.measurement.forward(self.transform.inverse(X))
+
+    def _wl_plan(self):
+        """the wavelet plan with the weak-lensing measurement attached, when transform and measurement are the stock
+        SphericalWaveletTransform / WeakLensing at one bandlimit (BASELINE config 5); None otherwise"""
+        tr, ms = getattr(self, "transform", None), getattr(self, "measurement", None)
+        if type(tr) is not SphericalWaveletTransform or type(ms) is not WeakLensing or tr.L != ms.L or tr.L < 3:
+            return None
+        if not getattr(self, "fuse_weaklensing", True):
+            return None
+        plan = tr._plan
+        if getattr(plan, "_wl_owner", None) is not ms:
+            plan.wl_attach(ms._pix2data, ms._w, ms.ndata)
+            plan._wl_owner = ms
+        return plan
 
     def _residual(self, preds):
         """invcov @ (preds - data) on the GPU (the dense->CSR round trip of forward.py:68 is not reproduced)."""
@@ -133,6 +150,10 @@ class ForwardOperator:
         return to_like(ops.as_device(self.measurement.adjoint(self._residual(preds))), preds)
 
     def _gradg_synthesis(self, preds):
+        plan = self._wl_plan()
+        if plan is not None and hasattr(self.invcov, "diag"):  # residual + mask scatter fused into the transform's read
+            p = ops.as_device(preds, torch.complex128)
+            return to_like(plan.wl_adjoint(p, self.data_dev_c128, self.invcov.diag), preds)
         g = self.transform.inverse_adjoint(self.measurement.adjoint(self._residual(preds)))
         return to_like(ops.as_device(g), preds)
 

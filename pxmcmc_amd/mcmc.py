@@ -579,8 +579,30 @@ class PxMALA(MYULA):
         super().__init__(forward, prox, mcmcparams, **kwargs)
         self.tune_delta = tune_delta
 
+    def _l2_dev(self, preds):
+        """L2 = vdot(d, invcov @ d) of a [C, ndata] prediction batch -> complex128 [C] (pxmcmc/mcmc.py:78-79)"""
+        p = ops.as_device(preds)
+        dt = self.forward._resid_dtype(p) if hasattr(self.forward, "_resid_dtype") else p.dtype
+        cache = getattr(self, "_l2_data", None)
+        if cache is None or cache[0] is not self.forward.data or cache[1].dtype != dt:  # (no host copy per iteration)
+            src = getattr(self.forward, "data_dev", None)
+            src = ops.as_device(self.forward.data) if src is None else src
+            self._l2_data = cache = (self.forward.data, src.reshape(-1).to(dt).contiguous())
+        data = cache[1]
+        if hasattr(self.forward.invcov, "matvec"):
+            d = ops.residual_grad(p.to(dt), data, self.forward.invcov.ones)
+            return ops.reduce_vdot(d, self.forward.invcov.matvec(d))
+        invcov = self.forward.invcov.diag if hasattr(self.forward.invcov, "diag") else ops.as_device(self.forward.invcov.diagonal())
+        return ops.reduce_l2(p.to(dt), data, invcov)
+
     def run(self, start_point=None):
-        """Run the algorithm (pxmcmc/mcmc.py:218-275); every chain carries its own delta and accept flag."""
+        """Run the algorithm (pxmcmc/mcmc.py:218-275); every chain carries its own delta and accept flag.
+
+        One iteration is a fixed sequence of device operations on static buffers -- proposal + prox + forward
+        transition + prior in one pass (pxm_pxmala_propose), forward model, gradient, L2, reverse transition,
+        Metropolis test / delta adaptation / traces on the device (pxm_pxmala_accept2), one conditional copy of the
+        accepted states -- and, with the device Philox stream, is replayed from a captured HIP graph between
+        observable events (save candidates, progress prints, trace flushes)."""
         self._prepare()
         self._fused_wav = False  # PxMALA needs gradg and proxf of the proposal separately
         C = self.nchains
@@ -590,43 +612,92 @@ class PxMALA(MYULA):
         delta_buf = torch.zeros((self._CHUNK, C), dtype=torch.float64, device=dev)
         delta_dev = torch.full((C,), float(self.delta), dtype=torch.float64, device=dev)
         delta0 = float(self.delta)
-        i = 0
         j = np.zeros(C, dtype=int)
         X_curr, curr_preds = self._initial_sample(start_point)
         dt = X_curr.dtype
-        gradg_curr = ops.as_device(self.forward.calc_gradg(curr_preds), dt)
-        proxf_curr = ops.as_device(self.prior.proxf(X_curr), dt)
+        X_curr = X_curr.contiguous()
+        curr_preds = ops.as_device(curr_preds).clone()
+        gradg_curr = ops.as_device(self.forward.calc_gradg(curr_preds), dt).clone()
+        proxf_curr = ops.as_device(self.prior.proxf(X_curr), dt).clone()
         logpiXc, L2Xc, priorXc = self._logpi_dev(X_curr, curr_preds)
+        logpiXc, L2Xc = logpiXc.to(torch.complex128).contiguous(), L2Xc.to(torch.complex128).contiguous()
+        priorXc = priorXc.to(torch.float64).contiguous()
+        # stock prior (library L1 / S2 soft threshold + weighted L1 norm): the fused proposal kernel applies
+        stock = _is_stock_l1(self.prior) and type(self.prior).prior is L1.prior and type(self).chain_step is MYULA.chain_step
+        T_dev = self.prior.T_dev if stock else None
+        w_prior = getattr(self.prior, "_weights_dev", None) if stock else None
+        X_prop, proxf_prop = torch.empty_like(X_curr), torch.empty_like(X_curr)
+        lt_cp = torch.empty(C, dtype=torch.complex128, device=dev)
+        prior_p = torch.empty(C, dtype=torch.float64, device=dev)
+        accept = torch.zeros(C, dtype=torch.int32, device=dev)
+        it_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # device-resident iteration number (graph replay)
+        host_rng = self.rng == "numpy"
+
+        def iteration(i_host, counter):
+            """one PxMALA iteration; Philox / adaptation use iteration number i_host + *counter"""
+            kw = dict(seed=self.seed, chain0=self.chain_offset, it=i_host)
+            noise = self._host_noise(X_curr) if host_rng else None
+            if stock:
+                ops.pxmala_propose(X_curr, proxf_curr, gradg_curr, T_dev, w_prior, delta_dev, self.lmda, X_prop, proxf_prop,
+                                   lt_cp, prior_p, noise=noise, noise_complex=bool(self.complex), iter_dev=counter, **kw)
+                Xp, pxp, ltc, prp = X_prop, proxf_prop, lt_cp, prior_p
+            else:  # user-supplied prior / chain_step: the reference's own sequence of calls (mcmc.py:231-242)
+                if type(self).chain_step is MYULA.chain_step:
+                    Xp = ops.chain_step(X_curr, proxf_curr, gradg_curr, delta_dev, self.lmda, noise=noise,
+                                        noise_complex=bool(self.complex), **kw)
+                else:
+                    Xp = ops.as_device(self.chain_step(X_curr, proxf_curr, gradg_curr), dt)
+                pxp = ops.as_device(self.prior.proxf(Xp), dt)
+                ltc = ops.logtransition(X_curr, Xp, proxf_curr, gradg_curr, delta_dev, self.lmda)
+                prp = self.prior.prior(Xp)
+                if not isinstance(prp, torch.Tensor):
+                    prp = torch.as_tensor(np.atleast_1d(np.asarray(prp, dtype=float)), device=dev)
+                prp = prp.to(torch.float64).contiguous()
+            pp = ops.as_device(self.forward.forward(Xp))
+            gp = ops.as_device(self.forward.calc_gradg(pp), dt)
+            L2p = self._l2_dev(pp)
+            ltp = ops.logtransition(Xp, X_curr, pxp, gp, delta_dev, self.lmda)
+            u = np.array([np.random.rand() for _ in range(C)]) if host_rng else None
+            ops.pxmala_accept2(ltp, ltc, prp, L2p, self.mu, logpiXc, L2Xc, priorXc, accept, delta_dev, self.tune_delta,
+                               self.lmda, u=u, iter_dev=counter, acc_trace=acc_buf, delta_trace=delta_buf, **kw)
+            ops.select_copy_many(accept, [(Xp, X_curr), (pp.to(curr_preds.dtype), curr_preds), (gp, gradg_curr), (pxp, proxf_curr)])
+
+        # HIP graph of one iteration (device Philox stream only; any operator that synchronises or cannot be
+        # captured falls back to eager stepping -- same results)
+        graph = None
+        self.graph_error = None
+        if self.use_graph and not host_rng and stock:
+            snap = [t.clone() for t in (X_curr, curr_preds, gradg_curr, proxf_curr, logpiXc, L2Xc, priorXc, delta_dev)]
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    iteration(0, it_dev)  # warm-up outside capture (lazy allocations, attributes)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                for t, s_ in zip((X_curr, curr_preds, gradg_curr, proxf_curr, logpiXc, L2Xc, priorXc, delta_dev), snap):
+                    t.copy_(s_)
+                g = torch.cuda.CUDAGraph()
+                with ops.capture_scope(), torch.cuda.graph(g):
+                    iteration(0, it_dev)
+                    ops.counter_add(it_dev, 1)
+                graph = g
+            except Exception as exc:
+                graph = None
+                self.graph_error = repr(exc)
+                for t, s_ in zip((X_curr, curr_preds, gradg_curr, proxf_curr, logpiXc, L2Xc, priorXc, delta_dev), snap):
+                    t.copy_(s_)
+            it_dev.zero_()
+        self.used_graph = graph is not None
+
+        i = 0
         n_acc = 0
         while j.min() < self.nsamples:
-            noise = self._host_noise(X_curr) if self.rng == "numpy" else None
-            X_prop = ops.chain_step(
-                X_curr, proxf_curr, gradg_curr, delta_dev, self.lmda, noise=noise, noise_complex=bool(self.complex),
-                seed=self.seed, chain0=self.chain_offset, it=i,
-            )
-            prop_preds = ops.as_device(self.forward.forward(X_prop))
-            gradg_prop = ops.as_device(self.forward.calc_gradg(prop_preds), dt)
-            proxf_prop = ops.as_device(self.prior.proxf(X_prop), dt)
-
-            logtransXcXp = ops.logtransition(X_curr, X_prop, proxf_curr, gradg_curr, delta_dev, self.lmda)
-            logtransXpXc = ops.logtransition(X_prop, X_curr, proxf_prop, gradg_prop, delta_dev, self.lmda)
-            logpiXp, L2Xp, priorXp = self._logpi_dev(X_prop, prop_preds)
-
-            terms = torch.stack((logtransXpXc.real, logpiXp.real, logtransXcXp.real, logpiXc.real), dim=1).contiguous()
-            u = np.array([np.random.rand() for _ in range(C)]) if self.rng == "numpy" else None
-            accept = ops.pxmala_accept(
-                terms, delta_dev, self.tune_delta, self.lmda, i, u=u, seed=self.seed, chain0=self.chain_offset, it=i
-            )
-            for src, dst in ((X_prop, X_curr), (prop_preds, curr_preds), (gradg_prop, gradg_curr), (proxf_prop, proxf_curr)):
-                ops.select_copy(accept, src, dst)
-            a = accept.bool()
-            logpiXc = torch.where(a, logpiXp, logpiXc)
-            L2Xc = torch.where(a, L2Xp, L2Xc)
-            priorXc = torch.where(a, priorXp, priorXc)
-
+            if graph is not None:
+                graph.replay()
+            else:
+                iteration(i, None)
             k = i % self._CHUNK
-            acc_buf[k].copy_(accept)
-            delta_buf[k].copy_(delta_dev)
             if k == self._CHUNK - 1:
                 acc_chunks.append(acc_buf.cpu().numpy().copy())
                 delta_chunks.append(delta_buf.cpu().numpy().copy())

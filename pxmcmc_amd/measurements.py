@@ -144,6 +144,9 @@ class WeakLensing(WeakLensingHarmonic):
         self.ndata = int(self.mask.sum())
         self.max_chains = max_chains
         self._idx = ops.as_device(np.flatnonzero(self.mask.reshape(-1)).astype(np.int64)).to(torch.int64)
+        p2d = np.full(self.npix, -1, dtype=np.int32)  # pixel -> index in the masked data vector (fused path)
+        p2d[np.flatnonzero(self.mask.reshape(-1))] = np.arange(self.ndata, dtype=np.int32)
+        self._pix2data = torch.from_numpy(p2d)
         self._w = ops.as_device(np.asarray(self.inv_cov, dtype=float), torch.float64)
         self._sht0 = ops.ShtPlan(L, 0, max_chains=max_chains)
         self._sht2 = ops.ShtPlan(L, 2, max_chains=max_chains)

@@ -235,6 +235,57 @@ def pxmala_accept(terms, delta_dev, tune, lmda, it_index, u=None, seed=0, chain0
     return acc
 
 
+def pxmala_propose(X, proxf, gradg, T, prior_weights, delta_dev, lmda, Xp, proxf_p, lt_out, prior_out, noise=None,
+                   noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None):
+    """chain_step + soft + calc_logtransition(X, X') + prior(X') in one pass; writes into the given buffers
+    (Xp, proxf_p [C, n]; lt_out complex128 [C]; prior_out float64 [C])."""
+    x, _ = _batched(X)
+    Tv, Ts = _vecT(T, x.shape[1], x.device)
+    w, wc = _noise_args(noise, x, noise_complex)
+    wp = None if prior_weights is None else as_device(prior_weights, _REAL).reshape(-1)
+    scratch = torch.empty(4 * int(lib.pxm_reduce_scratch_doubles(x.shape[0])), dtype=_REAL, device=x.device)
+    check(
+        lib.pxm_pxmala_propose(
+            _p(x), _p(proxf), _p(gradg), _p(Tv), Ts, _p(wp), _p(delta_dev), float(lmda), _p(w), wc, seed, chain0, int(it),
+            _p(iter_dev), _p(Xp), _p(proxf_p), _p(lt_out), _p(prior_out), _p(scratch), x.shape[1], x.shape[0], _dt(x), _stream(),
+        )
+    )
+
+
+def pxmala_accept2(lt_pc, lt_cp, prior_p, L2_p, mu, logpi_c, L2_c, prior_c, accept, delta_dev, tune, lmda, u=None, seed=0,
+                   chain0=0, it=0, iter_dev=None, acc_trace=None, delta_trace=None):
+    """Metropolis test + state scalars + delta adaptation + traces on the device (pxmcmc/mcmc.py:244-260,277-279)."""
+    C_ = accept.shape[0]
+    uu = None if u is None else as_device(u, _REAL).reshape(-1)
+    chunk = 0 if acc_trace is None else acc_trace.shape[0]
+    check(
+        lib.pxm_pxmala_accept2(
+            _p(lt_pc), _p(lt_cp), _p(prior_p), _p(L2_p), float(mu), _p(logpi_c), _p(L2_c), _p(prior_c), _p(uu), seed, chain0,
+            int(it), _p(iter_dev), _p(accept), _p(delta_dev), int(bool(tune)), float(lmda), _p(acc_trace), _p(delta_trace),
+            int(chunk), C_, _stream(),
+        )
+    )
+
+
+def select_copy_many(flag, pairs):
+    """dst[c] = src[c] for chains with flag[c] != 0, for up to four (src, dst) pairs in one launch."""
+    k = len(pairs)
+    if not 1 <= k <= 4:
+        raise ValueError("select_copy_many takes 1 to 4 array pairs")
+    srcs = (C.c_void_p * k)(*[p[0].data_ptr() for p in pairs])
+    dsts = (C.c_void_p * k)(*[p[1].data_ptr() for p in pairs])
+    ns = (C.c_int64 * k)(*[p[0][0].numel() if p[0].dim() == 2 else p[0].numel() for p in pairs])
+    es = (C.c_int * k)(*[p[0].element_size() for p in pairs])
+    for s_, d_ in pairs:
+        if s_.shape != d_.shape or s_.dtype != d_.dtype or not s_.is_contiguous() or not d_.is_contiguous():
+            raise ValueError("select_copy_many: shape / dtype / layout mismatch")
+    check(lib.pxm_select_copy_many(_p(flag), k, srcs, dsts, ns, es, flag.shape[0], _stream()))
+
+
+def counter_add(counter, inc=1):
+    check(lib.pxm_counter_add(_p(counter), int(inc), _stream()))
+
+
 def select_copy(flag, src, dst):
     """dst[c] = src[c] for chains with flag[c] != 0 (in place on dst)."""
     s, _ = _batched(src)
@@ -474,6 +525,48 @@ class WavPlan:
 
     def table_bytes(self, op):
         return int(lib.pxm_wav_table_bytes(self._h, op))
+
+    # ---- weak-lensing measurement fused with the synthesis (pxm_wav_wl_*) ----
+    def wl_attach(self, pix2data, weight, ndata):
+        """pix2data: int32 [npix] pixel -> index in the masked data vector (< 0 masked) or None; weight: float64
+        [ndata] (WeakLensing.inv_cov) or None.  The plan keeps the tensors alive."""
+        if pix2data is not None:
+            pix2data = pix2data.to(device=device(), dtype=torch.int32).contiguous()
+            if pix2data.numel() != self.npix:
+                raise ValueError("pix2data must have one entry per pixel")
+        if weight is not None:
+            weight = as_device(weight, _REAL).reshape(-1)
+            if weight.numel() != int(ndata):
+                raise ValueError("weight must have one entry per datum")
+        self._wl = (pix2data, weight, int(ndata))
+        check(lib.pxm_wav_wl_attach(self._h, _p(pix2data), _p(weight), int(ndata)))
+
+    def wl_forward(self, X, out=None):
+        x, squeeze = _batched(as_device(X, _CPLX))
+        if x.shape[1] != self.ncoefs or x.shape[0] > self.max_chains:
+            raise AssertionError("wl_forward: shape mismatch")
+        nd = self._wl[2]
+        if out is None:
+            out = torch.empty((x.shape[0], nd), dtype=_CPLX, device=x.device)
+        check(lib.pxm_wav_wl_forward(self._h, _p(x), _p(out), x.shape[0], _stream()))
+        return out[0] if squeeze else out
+
+    def wl_adjoint(self, gamma, data=None, invcov=None, out=None):
+        g, squeeze = _batched(as_device(gamma, _CPLX))
+        nd = self._wl[2]
+        if g.shape[1] != nd or g.shape[0] > self.max_chains:
+            raise AssertionError("wl_adjoint: shape mismatch")
+        d = ic = None
+        if data is not None:
+            d = as_device(data, _CPLX).reshape(-1)
+            ic = as_device(invcov).reshape(-1)
+            if d.numel() != nd or ic.numel() != nd:
+                raise ValueError("data / invcov length mismatch")
+        if out is None:
+            out = torch.empty((g.shape[0], self.ncoefs), dtype=_CPLX, device=g.device)
+        check(lib.pxm_wav_wl_adjoint(self._h, _p(g), _p(d), _p(ic), int(ic.is_complex()) if ic is not None else 0, _p(out),
+                                     g.shape[0], _stream()))
+        return out[0] if squeeze else out
 
     def workspace_nonfinite(self):
         """test aid: non-finite values anywhere in the plan's workspace (padding chains' columns included)"""

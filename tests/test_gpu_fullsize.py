@@ -306,3 +306,49 @@ def test_config5_L512_weaklensing_pxmala_properties():
     n1 = min(len(s1.acceptance_trace), s.acceptance_trace.shape[0])
     assert list(s1.acceptance_trace[:n1]) == list(s.acceptance_trace[:n1, 1])
     np.testing.assert_allclose(s1.chain[0], s.chain[1, 0], rtol=1e-9, atol=1e-12 * np.abs(s.chain).max())
+
+
+@pytest.mark.parametrize("L,masked", [(12, True), (24, False), (144, True), (272, True)])
+def test_weaklensing_wavelet_operator_fused_matches_composition_and_oracle(L, masked):
+    """ForwardOperator(transform = SphericalWaveletTransform, measurement = WeakLensing): forward() and calc_gradg()
+    (pxmcmc/forward.py:63-72) through the fused plan (harmonic kernel applied to the synthesised coefficients, no
+    SHT0^-1 / SHT0 pair, mask + weight + residual in the DFT kernels) against the composed operators and against the
+    oracle.  L = 272 takes the two-wave DFT kernels and unpaired spin-2 tables (the config-5 kernel path)."""
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    B, J_min, C = 2, 2, 2
+    rng = np.random.default_rng(L)
+    mask = ngal = None
+    if masked:
+        theta = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+        mask = np.ones((L, 2 * L - 1), dtype=int)
+        mask[np.abs(90 - np.degrees(theta)) < 15] = 0
+        mask[:, L // 3 : L // 2] = 0
+        ngal = rng.integers(1, 40, size=mask.shape).astype(float)
+    wl = WeakLensing(L, mask=mask, ngal=ngal, max_chains=C)
+    tr = SphericalWaveletTransform(L, B, J_min, max_chains=C)
+    data = rng.normal(size=wl.ndata) + 1j * rng.normal(size=wl.ndata)
+    sig_d = 1 / wl.inv_cov if masked else 0.3
+    op = ForwardOperator(data, sig_d, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+    X = rng.normal(size=(C, tr.ncoefs)) + 1j * rng.normal(size=(C, tr.ncoefs))
+    assert op._wl_plan() is not None
+    f_fused, g_fused = op.forward(X), op.calc_gradg(op.forward(X))
+    op.fuse_weaklensing = False
+    assert op._wl_plan() is None
+    f_comp = op.forward(X)
+    g_comp = op.calc_gradg(f_comp)
+    assert np.abs(f_fused - f_comp).max() < 1e-11 * np.abs(f_comp).max()
+    assert np.abs(g_fused - g_comp).max() < 1e-10 * np.abs(g_comp).max()
+    # single chain (1-D in, 1-D out) and the oracle
+    op.fuse_weaklensing = True
+    f1 = op.forward(X[1])
+    assert f1.shape == (wl.ndata,) and np.abs(f1 - f_fused[1]).max() <= 1e-13 * np.abs(f1).max()
+    T = ref.SphericalWaveletTransform(L, B, J_min)
+    oop = ref.ForwardOperator(data, sig_d, "synthesis", T, ref.WeakLensing(L, mask=mask, ngal=ngal), T.ncoefs)
+    fo = oop.forward(X[0])
+    go = oop.calc_gradg(fo)
+    assert np.abs(f_fused[0] - fo).max() < 1e-10 * np.abs(fo).max()
+    assert np.abs(g_fused[0] - go).max() < 1e-9 * np.abs(go).max()
