@@ -238,7 +238,20 @@ def main():
     eng["graph"], eng["graph_long"] = graphs
     torch.cuda.synchronize()
     (gms, gnl, gnb, gnf), (dms_, dnl_, dnb_) = plan.profile_read()
+    # launch classes of the ring GEMM (Gram / forward-adjoint group / forward group): the same steps once more
+    plan.profile_enable(3 * n_prof + 8)
+    eng["graph"] = eng["graph_long"] = None
+    sampler._engine_advance(n_prof)
+    eng["graph"], eng["graph_long"] = graphs
+    torch.cuda.synchronize()
+    l_ms, l_bytes = plan.profile_read_launches(3 * n_prof + 8)
     plan.profile_enable(0)
+    gemm_classes = []
+    for nbytes in sorted(set(np.round(l_bytes).tolist())):
+        sel = np.round(l_bytes) == nbytes
+        us = float(l_ms[sel].mean() * 1e3)
+        gemm_classes.append({"alg_MB": nbytes / 1e6, "launches": int(sel.sum()), "avg_us": us,
+                             "GBs": nbytes / us / 1e3, "frac": nbytes / us / 1e3 / HBM_PEAK_GBS})
 
     class _V:  # (keeps the field names of the report below)
         def __init__(self, v):
@@ -318,6 +331,7 @@ def main():
                 "traffic_source": traffic_src,
                 "avg_launch_us": gemm_avg_us,
                 "launches": int(nl.value),
+                "launch_classes": gemm_classes,
                 "alg_bytes_per_launch": nb.value / max(nl.value, 1),
                 # the same launches against the matrix pipe (v_mfma_f64_16x16x4_f64: 78.6 TFLOP/s dense spec,
                 # 47 TFLOP/s sustained by an MFMA-only loop on this part): the kernel is co-limited
@@ -329,8 +343,8 @@ def main():
             # second kernel of the iteration, the larger share of its time: the grouped phi-DFT + prox + update + Philox
             # kernel is bound by fp64 VALU issue (Bluestein butterflies), not by HBM -- reported for completeness
             out["dft_kernel"] = {
-                "kernel": "k_ring2px_group (rings -> X' -> rings of every wavelet scale, one grid)",
-                "bound": "fp64 VALU issue (2 waves per SIMD by registers)",
+                "kernel": "k_ring2px_group5 (rings -> X' -> rings of every wavelet scale, one grid)",
+                "bound": "fp64 VALU issue + LDS transposes (4 waves per SIMD)",
                 "avg_launch_us": dms.value * 1e3 / dnl.value,
                 "launches": int(dnl.value),
                 "alg_bytes_per_launch": dnb.value / dnl.value,

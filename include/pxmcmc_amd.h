@@ -112,6 +112,10 @@ int pxm_wav_profile_enable(pxm_wav_plan_t plan, int max_launches);
 int pxm_wav_profile_read(pxm_wav_plan_t plan, double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes,
                          double* gemm_flops);
 int pxm_wav_profile_read_dft(pxm_wav_plan_t plan, double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes);
+/* per-launch form of pxm_wav_profile_read (instead of it): kernel time (ms) and algorithmic bytes of each of the
+ * first `cap` ring-GEMM launches, in launch order; *launches = how many were bracketed; then resets */
+int pxm_wav_profile_read_launches(pxm_wav_plan_t plan, double* launch_ms, double* launch_alg_bytes, int64_t cap,
+                                  int64_t* launches);
 /* test aid: number of non-finite doubles in the plan's workspace (ring / harmonic arrays incl. the padding
  * chains' columns); synchronises the stream */
 int64_t pxm_wav_workspace_nonfinite(pxm_wav_plan_t plan, pxm_stream_t stream);

@@ -624,6 +624,11 @@ int pxm_wav_profile_read(pxm_wav_plan_t p, double* gemm_ms, int64_t* gemm_launch
   PXM_REQUIRE(p, "pxm_wav_profile_read: null plan");
   return profiler_read(&p->prof.gemm, gemm_ms, gemm_launches, gemm_alg_bytes, gemm_flops);
 }
+int pxm_wav_profile_read_launches(pxm_wav_plan_t p, double* launch_ms, double* launch_alg_bytes, int64_t cap,
+                                  int64_t* launches) {
+  PXM_REQUIRE(p && launch_ms && launch_alg_bytes && cap >= 0, "pxm_wav_profile_read_launches: bad arguments");
+  return profiler_read(&p->prof.gemm, nullptr, launches, nullptr, nullptr, launch_ms, launch_alg_bytes, cap);
+}
 int pxm_wav_profile_read_dft(pxm_wav_plan_t p, double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes) {
   PXM_REQUIRE(p, "pxm_wav_profile_read_dft: null plan");
   return profiler_read(&p->prof.dft, dft_ms, dft_launches, dft_alg_bytes, nullptr);

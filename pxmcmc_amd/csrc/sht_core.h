@@ -63,6 +63,7 @@ struct Profiler {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
     double bytes = 0, flops = 0;
+    std::vector<double> launch_bytes;  // algorithmic bytes of every bracketed launch (launch classes of bench.py)
   };
   bool on = false;
   Pool gemm, dft;
@@ -73,11 +74,13 @@ struct Profiler {
     *stop = p.ev[p.used].second;
     p.bytes += alg_bytes;
     p.flops += flops;
+    p.launch_bytes.push_back(alg_bytes);
     ++p.used;
   }
 };
 int profiler_enable(Profiler* pr, int max_launches);  // 0 = off (events are released)
-int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* bytes, double* flops);
+int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* bytes, double* flops,
+                  double* per_launch_ms = nullptr, double* per_launch_bytes = nullptr, int64_t cap = 0);
 void profiler_release(Profiler* pr);
 
 // extras of append_gemm_tasks for the fused wavelet combine

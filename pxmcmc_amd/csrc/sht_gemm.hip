@@ -32,14 +32,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // * one barrier per 16-k chunk (32 MFMAs per wave between barriers).
 // ---------------------------------------------------------------------------------------
 constexpr int KC = 16;  // contraction rows per staged chunk
-#ifndef PXM_GEMM_NSET
-#define PXM_GEMM_NSET 2  // table register sets: the table stream runs NSET-1 chunks (of 16 k) ahead.  2 sets = 64 VGPR at 32
-                         // columns = 8 waves per SIMD = 4 workgroups per CU: occupancy beats prefetch depth (3 sets: 76 VGPR, 3
-                         // workgroups, 8 % slower; 4 and 6 sets slower still)
-#endif
-
 // NW waves per workgroup, RT row tiles of 16 rows per wave: a task covers NW*RT row tiles.
-template <int CT, int NSLAB, int NW, int RT>
+// NSET: register sets of the table AND operand streams, i.e. both run NSET-1 chunks (of 16 k) ahead.  2 everywhere:
+// occupancy hides the load latency (60 VGPR at 16 columns, 4 workgroups per CU); 3 / 4 sets measured 10-15 % slower
+// on the grouped launches, and 4 % / 16 % slower on the Gram launch too (PXM_GEMM_GRAM_NSET=3|4 for A/B runs: its
+// short tasks re-read their last chunk in the deeper prologue, its long chains are not what bounds it).
+template <int CT, int NSLAB, int NW, int RT, int NSET>
 __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict__ tasks,
                                                       const double* __restrict__ X, double* __restrict__ Y,
                                                       int ncol, int col0, GemmAffine aff) {
@@ -82,18 +80,21 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     sk[i] = tasks[blockIdx.x].ks_off[slab >> 1];
   }
   const bool two = t.x2_off[0] != 0;  // second operand summed in while staging (fused wavelet combine)
-  double2 st[IT], st2[IT];
-#define PXM_STAGE_LOAD(CH)                                                                          \
-  _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i]) {                                 \
-      st[i] = *reinterpret_cast<const double2*>(sp[i] + (int64_t)(CH) * KC * ncol);                 \
-      if (two) st2[i] = *reinterpret_cast<const double2*>(sp[i] + sd[i] + (int64_t)(CH) * KC * ncol); \
+  double2 st[NSET - 1][IT], st2[NSET - 1][IT];  // operand chunks in flight (register sets, compile-time indices)
+#define PXM_STAGE_LOAD(SET, CH)                                                                     \
+  {                                                                                                 \
+    const int cs = min((CH), nch - 1);                                                              \
+    _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i]) {                               \
+      st[SET][i] = *reinterpret_cast<const double2*>(sp[i] + (int64_t)cs * KC * ncol);              \
+      if (two) st2[SET][i] = *reinterpret_cast<const double2*>(sp[i] + sd[i] + (int64_t)cs * KC * ncol); \
+    }                                                                                               \
   }
-#define PXM_STAGE_STORE(CH, BUF)                                                                    \
+#define PXM_STAGE_STORE(SET, CH, BUF)                                                               \
   _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i]) {                                 \
-    double2 v = st[i];                                                                              \
+    double2 v = st[SET][i];                                                                         \
     if (two) {                                                                                      \
-      v.x += st2[i].x;                                                                              \
-      v.y += st2[i].y;                                                                              \
+      v.x += st2[SET][i].x;                                                                         \
+      v.y += st2[SET][i].y;                                                                         \
     }                                                                                               \
     if (sk[i]) {                                                                                    \
       const double sc = (X + sk[i])[t.k_beg + (CH) * KC + so[i] / PITCH];                           \
@@ -113,7 +114,6 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   const bool v0 = n_my > 0;
   // NSET register sets used round-robin with compile-time indices (no register rotation: a copy of an
   // in-flight load would force a full vmcnt(0) drain every chunk); the table runs NSET-1 chunks ahead
-  constexpr int NSET = PXM_GEMM_NSET;
   double2 A[NSET][RT][2];
 #define PXM_TAB_LOAD(SET, CH)                                                 \
   {                                                                           \
@@ -130,17 +130,23 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
 #pragma unroll
     for (int c = 0; c < NCT; ++c) acc[r][c] = d4{0, 0, 0, 0};
 
-  PXM_STAGE_LOAD(0)
+  // operand set of chunk ch: ch % (NSET-1); table set: ch % NSET.  Both streams run NSET-1 chunks ahead; the loop
+  // is unrolled over NSET (NSET-1) = LCM-free pattern by making the period NSET * (NSET - 1) explicit below.
 #pragma unroll
-  for (int u = 0; u < NSET - 1; ++u) PXM_TAB_LOAD(u, u)
-  for (int ch0 = 0; ch0 < nch; ch0 += NSET) {
+  for (int u = 0; u < NSET - 1; ++u) {
+    PXM_STAGE_LOAD(u, u)
+    PXM_TAB_LOAD(u, u)
+  }
+  constexpr int PER = NSET * (NSET - 1);
+  for (int ch0 = 0; ch0 < nch; ch0 += PER) {
 #pragma unroll
-    for (int u = 0; u < NSET; ++u) {
-      const int ch = ch0 + u;
+    for (int pv = 0; pv < PER; ++pv) {
+      const int ch = ch0 + pv;
+      const int u = pv % NSET;
       if (ch < nch) {
         const int buf = ch & 1;
-        PXM_STAGE_STORE(ch, buf)
-        if (ch + 1 < nch) { PXM_STAGE_LOAD(ch + 1) }
+        PXM_STAGE_STORE(pv % (NSET - 1), ch, buf)
+        PXM_STAGE_LOAD(pv % (NSET - 1), ch + NSET - 1)   // (the set just stored is free again; clamped past the end)
         PXM_TAB_LOAD((u + NSET - 1) % NSET, ch + NSET - 1)
         __syncthreads();
         if (v0) {
@@ -223,15 +229,21 @@ void profiler_release(Profiler* pr) {
     p->ev.clear();
     p->used = 0;
     p->bytes = p->flops = 0;
+    p->launch_bytes.clear();
   }
 }
-int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* bytes, double* flops) {
+int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* bytes, double* flops, double* per_launch_ms,
+                  double* per_launch_bytes, int64_t cap) {
   double tot = 0;
   for (size_t i = 0; i < p->used; ++i) {
     PXM_HIP(hipEventSynchronize(p->ev[i].second));
     float t = 0;
     PXM_HIP(hipEventElapsedTime(&t, p->ev[i].first, p->ev[i].second));
     tot += t;
+    if ((int64_t)i < cap) {
+      if (per_launch_ms) per_launch_ms[i] = t;
+      if (per_launch_bytes) per_launch_bytes[i] = p->launch_bytes[i];
+    }
   }
   if (ms) *ms = tot;
   if (launches) *launches = (int64_t)p->used;
@@ -239,6 +251,7 @@ int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* byte
   if (flops) *flops = p->flops;
   p->used = 0;
   p->bytes = p->flops = 0;
+  p->launch_bytes.clear();
   return 0;
 }
 
@@ -270,10 +283,19 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->gemm, &ev0, &ev1, alg_bytes, flops);
 #define PXM_GEMM_LAUNCH(A, B)                                                                                         \
-  if (geom == 81) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 8, 1>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
-  else if (geom == 41) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 1>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
-  else hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
-  if (nslab == 4) {
+  if (geom == 81) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 8, 1, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
+  else if (geom == 41) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 1, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
+  else hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 2, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
+  static const int gram_nset = getenv("PXM_GEMM_GRAM_NSET") ? atoi(getenv("PXM_GEMM_GRAM_NSET")) : 2;
+  if (aff.on && geom == 81 && nslab == 2 && gram_nset != 2) {  // Gram launch: few workgroups, long chains -> deep look-ahead
+    if (gram_nset == 3) {
+      if (ct == 1) hipExtLaunchKernelGGL((k_sht_gemm<1, 2, 8, 1, 3>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
+      else hipExtLaunchKernelGGL((k_sht_gemm<2, 2, 8, 1, 3>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
+    } else {
+      if (ct == 1) hipExtLaunchKernelGGL((k_sht_gemm<1, 2, 8, 1, 4>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
+      else hipExtLaunchKernelGGL((k_sht_gemm<2, 2, 8, 1, 4>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
+    }
+  } else if (nslab == 4) {
     if (ct == 1) { PXM_GEMM_LAUNCH(1, 4) } else { PXM_GEMM_LAUNCH(2, 4) }
   } else if (nslab == 2) {
     if (ct == 1) { PXM_GEMM_LAUNCH(1, 2) } else { PXM_GEMM_LAUNCH(2, 2) }

@@ -576,6 +576,15 @@ class WavPlan:
     def profile_enable(self, max_launches):
         check(lib.pxm_wav_profile_enable(self._h, int(max_launches)))
 
+    def profile_read_launches(self, cap):
+        """per-launch (ms, algorithmic bytes) of the bracketed ring-GEMM launches, in launch order"""
+        import numpy as np
+
+        ms, nb, n = np.zeros(cap), np.zeros(cap), C.c_int64()
+        check(lib.pxm_wav_profile_read_launches(self._h, ms.ctypes.data, nb.ctypes.data, int(cap), C.byref(n)))
+        k = min(int(n.value), cap)
+        return ms[:k], nb[:k]
+
     def profile_read(self):
         """(gemm: ms, launches, algorithmic bytes, flops), (grouped phi-DFT: ms, launches, algorithmic bytes)"""
         ms, nl, nb, nf = C.c_double(), C.c_int64(), C.c_double(), C.c_double()

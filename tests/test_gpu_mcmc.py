@@ -654,3 +654,43 @@ def test_single_chain_long_run_keeps_padding_columns_finite():
     assert bool(torch.isfinite(Xc.real).all())
     assert op.transform._plan.workspace_nonfinite() == 0  # padding columns included
     s._engine_stop()
+
+
+@pytest.mark.parametrize("measurement", ["identity", "weaklensing"])
+def test_pxmala_graph_replay_equals_eager(measurement):
+    """PxMALA's iteration replayed from a captured HIP graph (device-resident iteration number, device-side accept /
+    delta adaptation / traces) reproduces eager stepping bit for bit: acceptance and delta traces, saved chain,
+    log posterior -- with the wavelet operator alone and with the fused weak-lensing measurement."""
+    from pxmcmc_amd.forward import ForwardOperator, SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    L, B, J_min, C = 16, 2, 2, 3
+    rng = np.random.default_rng(8)
+    if measurement == "identity":
+        data = rng.normal(size=L * (2 * L - 1))
+        op = SphericalWaveletTransformOperator(data, 0.3, "synthesis", L, B, J_min, max_chains=C)
+        tr = op.transform
+    else:
+        mask = np.ones((L, 2 * L - 1), dtype=int)
+        mask[L // 2 - 1 : L // 2 + 1] = 0
+        wl = WeakLensing(L, mask, ngal=np.full(mask.shape, 30.0), max_chains=C)
+        tr = SphericalWaveletTransform(L, B, J_min, max_chains=C)
+        data = rng.normal(size=wl.ndata) + 1j * rng.normal(size=wl.ndata)
+        op = ForwardOperator(data, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+    p = PxMCMCParams(nsamples=4, nburn=6, ngap=1, delta=1e-6, lmda=1e-4, verbosity=0)
+    reg = S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, p.lmda * p.mu, L=L, B=B, J_min=J_min)
+    runs = []
+    for use_graph in (True, False):
+        s = PxMALA(op, reg, p, tune_delta=True, nchains=C, seed=4, use_graph=use_graph)
+        _quiet(s.run, start_point=np.zeros(tr.ncoefs))
+        assert s.used_graph is use_graph, s.graph_error
+        runs.append(s)
+    a, b = runs
+    assert a.niter == b.niter and a.acceptance_trace.sum() > 0
+    np.testing.assert_array_equal(a.acceptance_trace, b.acceptance_trace)
+    np.testing.assert_array_equal(a.deltas_trace, b.deltas_trace)
+    np.testing.assert_array_equal(a.chain, b.chain)
+    np.testing.assert_array_equal(a.logPi, b.logPi)
