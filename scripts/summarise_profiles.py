@@ -18,6 +18,8 @@ import shutil
 import sys
 
 tag, name = sys.argv[1], sys.argv[2]
+sq_tag = sys.argv[3] if len(sys.argv) > 3 else None   # gpurun_out/<sq_tag>/{a,b,c}: SQ counter passes (collect_pmc_sq.sh)
+c5_tag = sys.argv[4] if len(sys.argv) > 4 else None   # gpurun_out/<c5_tag>: kernel trace of scripts/time_config5.py
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
@@ -81,6 +83,45 @@ for k in sorted(fetch):
             summary["k_sht_gemm_write_bytes"] = wr
             summary["kernel"] = k.strip()
             summary["launches_sampled"] = len(fetch[k])
+if bench.get("roofline", {}).get("launch_classes"):
+    out.append("\n## k_sht_gemm launch classes from the bench line (live HIP events, algorithmic bytes per launch)\n\n| alg MB | launches | avg us | TB/s | of 8 TB/s |\n|---|---|---|---|---|")
+    for c in bench["roofline"]["launch_classes"]:
+        out.append(f"| {c['alg_MB']:.1f} | {c['launches']} | {c['avg_us']:.1f} | {c['GBs']/1e3:.2f} | {c['frac']:.2f} |")
+if sq_tag:
+    out.append("\n## SQ counters per launch (rocprofv3 --pmc, three passes; sums over the chip)\n")
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for sub in "abc":
+        f = sorted(glob.glob(os.path.join(root, "gpurun_out", sq_tag, sub, "*", "*_counter_collection.csv")))
+        if not f:
+            continue
+        for r in csv.DictReader(open(f[-1])):
+            k = r["Kernel_Name"].split("(")[0]
+            if "k_ring2px_group" in k:
+                acc[k.strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            elif "k_sht_gemm<1, 2" in k:
+                acc[k.strip() + f" grid {r['Grid_Size']}"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, d in sorted(acc.items()):
+        m = {c: sum(v) / len(v) for c, v in d.items()}
+        out.append(f"* `{k}`: " + ", ".join(f"{c} {v:,.0f}" for c, v in sorted(m.items())))
+        if "SQ_BUSY_CYCLES" in m and "SQ_INSTS_VALU" in m and "SQ_WAVES" in m:
+            cyc = m["SQ_BUSY_CYCLES"] / 32  # summed over 8 XCDs x 4 shader engines
+            out.append(f"  - kernel = {cyc:,.0f} cycles; VALU issue = {m['SQ_INSTS_VALU'] * 4 / 1024:,.0f} cycles per SIMD = "
+                       f"{m['SQ_INSTS_VALU'] * 4 / 1024 / cyc:.2f} of the kernel; {m['SQ_INSTS_VALU'] / m['SQ_WAVES']:,.0f} VALU instructions per wave"
+                       + (f"; waves wait (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES) {m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES']:.2f} of their cycles"
+                          if "SQ_WAVE_CYCLES" in m else "")
+                       + (f"; LDS busy {m['SQ_LDS_IDX_ACTIVE'] / 256 / cyc:.2f} of the kernel per CU, bank-conflict cycles "
+                          f"{m['SQ_LDS_BANK_CONFLICT'] / max(m['SQ_LDS_IDX_ACTIVE'], 1):.3f} of them" if "SQ_LDS_IDX_ACTIVE" in m else ""))
+if c5_tag:
+    f = sorted(glob.glob(os.path.join(root, "gpurun_out", c5_tag, "*", "*_kernel_stats.csv")))
+    if f:
+        shutil.copy(f[-1], os.path.join(dst, f"{name}_L512_kernel_stats.csv"))
+        rows5 = list(csv.DictReader(open(f[-1])))
+        log = [l.strip() for l in open(os.path.join(root, "gpurun_out", c5_tag + ".log")) if l.startswith("C=")]
+        o5 = [f"# rocprofv3 --kernel-trace --stats of scripts/time_config5.py (BASELINE config 5 sizes: L=512 weak lensing, PxMALA, 2 chains)\n",
+              *[f"    {l}" for l in log], "\n| kernel | calls | avg us | % |\n|---|---|---|---|"]
+        for r in rows5[:24]:
+            o5.append(f"| `{r['Name'][:72]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")
+        open(os.path.join(dst, f"{name}_L512_summary.md"), "w").write("\n".join(o5) + "\n")
 open(os.path.join(dst, f"{name}_summary.md"), "w").write("\n".join(out) + "\n")
 if summary:
     summary["source"] = f"profiles/{name}_summary.md"
