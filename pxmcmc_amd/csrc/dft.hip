@@ -162,6 +162,11 @@ int make_dft_plan(int L, DftPlan* p) {
     dft5_geometry(b.n, &p->R5, &p->TR5, &p->lds5);
     p->use5 = true;
   }
+  if (b.n > 512 && b.n <= 1023 && !getenv("PXM_DFT_NO_Q") && !getenv("PXM_DFT_NO_W") && !getenv("PXM_DFT_NO_W2")) {
+    int rc = dft6_make_tables(b.n, &p->t6);  // 256 < L <= 512: four waves per ring, 8 points per lane
+    if (rc) return rc;
+    p->use6 = true;
+  }
   const int M3 = getenv("PXM_DFT_NO_W") ? 0 : dft3_size(b.n);
   if (M3) {  // wave path: square size, its own filter transform and twiddle matrix
     BluesteinTables b3 = (M3 == b.M) ? b : make_bluestein(b.n, M3);
@@ -229,6 +234,7 @@ static DftArgs make_args(const DftPlan& p) {
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream) {
   if (p.use5) return dft5_px2ring(p, in, G, ncol, C, stream);
   if (p.use3) return dft3_px2ring(p, in, G, ncol, C, stream);
+  if (p.use6) return dft6_px2ring(p, in, G, ncol, C, stream);
   if (p.use4) return dft4_px2ring(p, in, G, ncol, C, stream);
   const int Cp = ncol / 2;
   dim3 grid(p.L, (Cp + p.R - 1) / p.R), block(p.threads);
@@ -246,6 +252,7 @@ int launch_ring2px2ring(const DftPlan& p, double* G, int ncol, const PxOut& out,
 int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
   if (p.use5) return dft5_ring2px(p, G, ncol, out, C, stream);
   if (p.use3) return dft3_ring2px(p, G, ncol, out, C, stream);
+  if (p.use6) return dft6_ring2px(p, G, ncol, out, C, stream);
   if (p.use4) return dft4_ring2px(p, G, ncol, out, C, stream);
   dim3 grid(p.L, (C + p.R - 1) / p.R), block(p.threads);
   hipLaunchKernelGGL(k_ring2px, grid, block, p.lds, stream, make_args(p), G, ncol, out, C);

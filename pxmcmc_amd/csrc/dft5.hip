@@ -345,18 +345,24 @@ template <int R0>
 __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in, double* __restrict__ G, int ncol, int C,
                                               int bx, int by, double2* lds5) {
   PXM_D5_GEOMETRY
+  // each wave of the pair fetches half of the ring set (its four p) and the two share it through the stage
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int j = jb + 8 * R0 * (pb + u);
+    if (j < n) {
+      double2 v{0.0, 0.0};
+      if (ch < C && tv) v = px_in_load(in, ch, in.ring0 + (int64_t)t * n + j);
+      stage[PXM_D5_SLOT(trs, j, r)] = v;
+    }
+  }
+  __syncthreads();  // (also: the LDS copy of the twiddles is complete)
   double2 x[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int j = jb + 8 * R0 * p;
-    double2 v{0.0, 0.0};
-    if (j < n && ch < C && tv) {
-      const int64_t e = in.ring0 + (int64_t)t * n + j;
-      v = px_in_load(in, ch, e);
-    }
-    x[p] = v;
+    x[p] = j < n ? stage[PXM_D5_SLOT(trs, j, r)] : double2{0.0, 0.0};
   }
-  __syncthreads();  // the LDS copy of the twiddles is complete
+  __syncthreads();  // the stage is dead: the planes may be written
   PXM_D5_TRANSFORM(0)
   PXM_D5_TO_STAGE
   PXM_D5_STORE_RINGS
@@ -513,6 +519,204 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5G
     case 4: ring2px_body5<4, true>(a, G, ncol, out, C, bx, by, lds5); break;
     case 2: ring2px_body5<2, true>(a, G, ncol, out, C, bx, by, lds5); break;
     default: ring2px_body5<1, true>(a, G, ncol, out, C, bx, by, lds5); break;
+  }
+}
+
+// =============================================================================================================
+// Four waves per ring: 512 < n <= 1023 (256 < L <= 512), M = 2048 = 4 x 512.  The chirped input is zero above
+// n < 1024 = 2 x 512, so the first radix-4 (DIF) stage needs two inputs per output: wave w takes the bins 4k'+w as
+// the 512-point transform of
+//     b_w[j'] = (a[j'] + (-i)^w a[j'+512]) W_2048^(j' w),        j' < 512,
+// runs the same 8-points-per-lane convolution core as above on them (d5_conv<8>), and
+//     conv[j' + 512 q] = sum_w i^(q w) W_2048^(-j' w) y_w[j'],   q = 0, 1.
+// The four waves reduce their weighted shares in two pair exchanges through LDS (w <-> w^1, then w <-> w^2); each
+// wave finishes 4 of the 16 elements a lane position covers: p in {pb, pb+1}, pb = 4 (w & 1) + 2 (w >> 1), both
+// halves q.  Tables (zero-padded, no j < n tests on the transform path): cA_w = c W^(j'w), cB_w = (-i)^w c[.+512]
+// W^(j'w) on input, dA_w = c W^(-j'w), dB_w = i^w c[.+512] W^(-j'w) on output.  scripts/proto_dft5.py: dft_quad.
+// =============================================================================================================
+struct Dft6Args {
+  int L, n, Rp;
+  int lgR;                           // log2 of the chains per workgroup (4 waves each)
+  const double2 *cA, *cB, *dA, *dB;  // [4][512]
+  const double2 *tw1, *wt;           // pass twiddles of the 512-point transform ([8][64], [8][8])
+  const double2* bQ;                 // [4][8][64] FFT_2048(filter)/2048 at the bins 4k'+w, pass-3 order
+};
+
+#define PXM_D6_GEOMETRY                                                                      \
+  const int lgR = a.lgR, R = 1 << lgR, n = a.n;                                              \
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                                \
+  const int w = wave & 3, r = wave >> 2;            /* bin class of the wave, chain of the workgroup */ \
+  const D5Lane q{lane & 7, lane >> 3};                                                       \
+  const int t = bx, c0 = by * R, ch = c0 + r;                                                \
+  const int Cp = ncol >> 1;                                                                  \
+  const int rsh = 4 - lgR;                                                                   \
+  const int wa = w & 1, wb = w >> 1;                                                         \
+  const int pb = 4 * wa + 2 * wb;                   /* the wave finishes p = pb, pb + 1 (both halves) */ \
+  double2* stage = lds5;                                                                     \
+  double2* plane = lds5 + wave * D5_PLANE;                                                   \
+  const double2* pp1 = lds5 + (wave ^ 1) * D5_PLANE;                                         \
+  const double2* pp2 = lds5 + (wave ^ 2) * D5_PLANE;                                         \
+  const double2* tw = lds5 + 4 * R * D5_PLANE;                                               \
+  for (int i = threadIdx.x; i < D5_TW; i += blockDim.x) lds5[4 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : a.wt[i - 448];
+#define PXM_D6_SLOT(K, CH) (((K) << lgR) + (((CH) + ((K) >> rsh)) & (R - 1)))
+
+// xl[p] = element lane + 64 p, xh[p] = element lane + 64 p + 512 of the ring (zeros past n) -> fo[ii][q]: the
+// transform at j = lane + 64 (pb + ii) + 512 q.  Three workgroup barriers inside.
+__device__ __forceinline__ void d6_transform(double2 (&xl)[8], const double2 (&xh)[8], double2 (&fo)[2][2], double2* plane,
+                                             const double2* pp1, const double2* pp2, const double2* tw, int lane,
+                                             const D5Lane& q, int w, const Dft6Args& a) {
+  const int wa = w & 1, wb = w >> 1;
+  const double2* __restrict__ cA = a.cA + w * 512 + lane;
+  const double2* __restrict__ cB = a.cB + w * 512 + lane;
+  const double2* __restrict__ dA = a.dA + w * 512 + lane;
+  const double2* __restrict__ dB = a.dB + w * 512 + lane;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) xl[p] = cadd(cmul(xl[p], cA[64 * p]), cmul(xh[p], cB[64 * p]));
+  d5_conv<8>(xl, plane, lane, q, tw, a.bQ + w * 512);
+  // ---- pair exchange 1 (w <-> w ^ 1): keep p in [4 wa, 4 wa + 4), send the shares of the other four
+  double2 su[4], sv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double2 yk = d5_sel(wa, xl[4 + i], xl[i]), ys = d5_sel(wa, xl[i], xl[4 + i]);
+    const int pk = 64 * (4 * wa + i), ps = 64 * (4 * (1 - wa) + i);
+    su[i] = cmul(yk, dA[pk]);
+    sv[i] = cmul(yk, dB[pk]);
+    plane[64 * i + lane] = cmul(ys, dA[ps]);
+    plane[256 + 64 * i + lane] = cmul(ys, dB[ps]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    su[i] = cadd(su[i], pp1[64 * i + lane]);
+    sv[i] = cadd(sv[i], pp1[256 + 64 * i + lane]);
+  }
+  __syncthreads();  // every read of exchange 1 is done before the planes take exchange 2
+  // ---- pair exchange 2 (w <-> w ^ 2): keep i in {2 wb, 2 wb + 1}
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    plane[64 * ii + lane] = d5_sel(wb, su[ii], su[2 + ii]);
+    plane[128 + 64 * ii + lane] = d5_sel(wb, sv[ii], sv[2 + ii]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii) {
+    fo[ii][0] = cadd(d5_sel(wb, su[2 + ii], su[ii]), pp2[64 * ii + lane]);
+    fo[ii][1] = cadd(d5_sel(wb, sv[2 + ii], sv[ii]), pp2[128 + 64 * ii + lane]);
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double* __restrict__ G, int ncol, int C) {
+  extern __shared__ double2 lds5[];
+  if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
+  const int bx = blockIdx.x, by = blockIdx.y;
+  PXM_D6_GEOMETRY
+  // every wave fetches a quarter of the ring (its two p, both halves) and the four share it through the stage
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+      const int j = lane + 64 * (2 * w + ii) + 512 * hq;
+      if (j < n) {
+        const int64_t e = in.ring0 + (int64_t)t * n + j;
+        stage[PXM_D6_SLOT(j, r)] = (ch < C) ? px_in_load(in, ch, e) : double2{0.0, 0.0};
+      }
+    }
+  __syncthreads();  // (also: the LDS copy of the twiddles is complete)
+  double2 xl[8], xh[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int j = lane + 64 * p;
+    xl[p] = stage[PXM_D6_SLOT(j, r)];
+    xh[p] = (j + 512 < n) ? stage[PXM_D6_SLOT(j + 512, r)] : double2{0.0, 0.0};
+  }
+  __syncthreads();  // the stage is dead: the planes may be written
+  double2 fo[2][2];
+  d6_transform(xl, xh, fo, plane, pp1, pp2, tw, lane, q, w, a);
+  __syncthreads();  // the planes are dead; the same LDS is the [k][chain] layout-transpose stage
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int hq = 0; hq < 2; ++hq) {
+      const int j = lane + 64 * (pb + ii) + 512 * hq;
+      if (j < n) stage[PXM_D6_SLOT(j, r)] = fo[ii][hq];
+    }
+  __syncthreads();
+  {
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;
+    const int mstride = a.Rp * Cp;
+    double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;
+    if (c0 + rr < Cp)
+      for (int k = kq; k < n; k += kstep) Gc[((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + t * Cp] = stage[PXM_D6_SLOT(k, rr)];
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void k_ring2px6(Dft6Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
+  extern __shared__ double2 lds5[];
+  const int bx = blockIdx.x, by = blockIdx.y;
+  if ((by << a.lgR) >= C) return;
+  PXM_D6_GEOMETRY
+  {  // the ring of the workgroup's chains -> stage (conjugated: inverse DFT by conjugation)
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;
+    const int mstride = a.Rp * Cp;
+    const double2* Gc = reinterpret_cast<const double2*>(G) + c0 + rr;
+    const bool cv = c0 + rr < Cp;
+    constexpr int NB = 4;
+    for (int kb = kq; kb < n; kb += NB * kstep) {
+      double2 v[NB];
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int k = kb + u * kstep;
+        v[u] = double2{0.0, 0.0};
+        if (cv && k < n) v[u] = Gc[((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + t * Cp];
+      }
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int k = kb + u * kstep;
+        if (k < n) stage[PXM_D6_SLOT(k, rr)] = double2{v[u].x, -v[u].y};
+      }
+    }
+  }
+  __syncthreads();
+  double2 xl[8], xh[8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    const int j = lane + 64 * p;
+    xl[p] = stage[PXM_D6_SLOT(j, r)];
+    xh[p] = (j + 512 < n) ? stage[PXM_D6_SLOT(j + 512, r)] : double2{0.0, 0.0};
+  }
+  __syncthreads();
+  double2 fo[2][2];
+  d6_transform(xl, xh, fo, plane, pp1, pp2, tw, lane, q, w, a);
+  if (ch >= C) return;
+  const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
+  const int64_t e0 = out.ring0 + (int64_t)t * n + lane + 64 * pb;
+  const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
+  // the four elements of the lane: loads first (independent), then the arithmetic
+  double2 xs[4], wn[4];
+  double Ts[4];
+  bool ok[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int ii = u >> 1, hq = u & 1;
+    const int64_t off = 64 * ii + 512 * hq;
+    ok[u] = lane + 64 * (pb + ii) + 512 * hq < n;
+    xs[u] = (ok[u] && out.X) ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
+    Ts[u] = (ok[u] && out.X && out.T) ? out.T[e0 + off] : out.T_scalar;
+    wn[u] = (ok[u] && out.X && out.noise) ? px_noise_load(out, ch, e0 + off) : double2{0.0, 0.0};
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (!ok[u]) continue;
+    const int ii = u >> 1, hq = u & 1;
+    const int64_t off = 64 * ii + 512 * hq;
+    const double2 y{fo[ii][hq].x, -fo[ii][hq].y};
+    if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+      double2 wv = wn[u];
+      if (!out.noise) wv = px_noise_philox(out, ch, e0 + off, it_eff);
+      reinterpret_cast<double2*>(out.f)[ce0 + off] = px_update(out, xs[u], Ts[u], y, wv);
+    } else {
+      px_out_store(out, ch, e0 + off, y);
+    }
   }
 }
 
@@ -714,6 +918,107 @@ int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut&
   if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
   hipExtLaunchKernelGGL(k_ring2px_group5, dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
                         reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// ---- four waves per ring (512 < n <= 1023) --------------------------------------------------------------------------
+int dft6_make_tables(int n, Dft6Tables* t) {
+  typedef std::complex<long double> cld;
+  const long double PI_L = 3.141592653589793238462643383279502884L;
+  const int M = 2048;
+  auto ang = [&](long double num, long double den) { return cld(cosl(-PI_L * num / den), sinl(-PI_L * num / den)); };
+  std::vector<cld> chirp(1024, cld(0, 0)), filt(M, cld(0, 0));
+  for (int j = 0; j < n; ++j) chirp[j] = ang((long double)(((long long)j * j) % (2LL * n)), n);
+  for (int j = 0; j < n; ++j) {
+    filt[j] = std::conj(chirp[j]);
+    if (j) filt[M - j] = std::conj(chirp[j]);
+  }
+  int logM = 0;
+  while ((1 << logM) < M) ++logM;
+  for (int s = M / 2; s >= 1; s >>= 1)
+    for (int g = 0; g < M; g += 2 * s)
+      for (int p = 0; p < s; ++p) {
+        const cld w = ang(2.0L * p * (M / (2 * s)), M);
+        const cld u = filt[g + p], v = filt[g + p + s];
+        filt[g + p] = u + v;
+        filt[g + p + s] = (u - v) * w;
+      }
+  std::vector<cld> bhat(M);
+  for (int i = 0; i < M; ++i) {
+    int r = 0;
+    for (int bit = 0; bit < logM; ++bit) r |= ((i >> bit) & 1) << (logM - 1 - bit);
+    bhat[r] = filt[i] / (long double)M;
+  }
+  std::vector<double> h;
+  auto put = [&](const cld& v) {
+    h.push_back((double)v.real());
+    h.push_back((double)v.imag());
+  };
+  const cld mi(0, -1), pi(0, 1);
+  auto ipow = [](cld b, int e) { cld r(1, 0); for (int i = 0; i < e; ++i) r *= b; return r; };
+  size_t o[4];
+  for (int tab = 0; tab < 4; ++tab) {  // cA, cB, dA, dB: [4][512]
+    o[tab] = h.size();
+    for (int w = 0; w < 4; ++w)
+      for (int j = 0; j < 512; ++j) {
+        const cld W = ang(2.0L * ((j * w) % M), M);
+        if (tab == 0) put(chirp[j] * W);
+        else if (tab == 1) put(ipow(mi, w) * chirp[j + 512] * W);
+        else if (tab == 2) put(chirp[j] * std::conj(W));
+        else put(ipow(pi, w) * chirp[j + 512] * std::conj(W));
+      }
+  }
+  const size_t o_tw1 = h.size();
+  for (int k = 0; k < 8; ++k)
+    for (int lane = 0; lane < 64; ++lane) put(ang(2.0L * ((lane * k) % 512), 512));
+  const size_t o_wt = h.size();
+  for (int x = 0; x < 8; ++x)
+    for (int y = 0; y < 8; ++y) put(ang(2.0L * ((x * y) % 64), 64));
+  const size_t o_bq = h.size();
+  for (int w = 0; w < 4; ++w)
+    for (int k0 = 0; k0 < 8; ++k0)
+      for (int lane = 0; lane < 64; ++lane) put(bhat[4 * ((lane >> 3) + 8 * (lane & 7) + 64 * k0) + w]);
+  PXM_HIP(hipMalloc(&t->d_all, h.size() * sizeof(double)));
+  PXM_HIP(hipMemcpy(t->d_all, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  t->cA = t->d_all + o[0];
+  t->cB = t->d_all + o[1];
+  t->dA = t->d_all + o[2];
+  t->dB = t->d_all + o[3];
+  t->tw1 = t->d_all + o_tw1;
+  t->wt = t->d_all + o_wt;
+  t->bQ = t->d_all + o_bq;
+  return 0;
+}
+
+static Dft6Args dft6_args(const DftPlan& p) {
+  const Dft6Tables& t = p.t6;
+  auto c = [](const double* x) { return reinterpret_cast<const double2*>(x); };
+  return Dft6Args{p.L, p.n, p.Rp, 1, c(t.cA), c(t.cB), c(t.dA), c(t.dB), c(t.tw1), c(t.wt), c(t.bQ)};
+}
+static constexpr int D6_R = 2;  // chains per workgroup: 8 waves, 2 workgroups per CU (4 waves per SIMD)
+static size_t dft6_lds() { return (size_t)4 * D6_R * D5_PLANE * 16 + (size_t)D5_TW * 16; }  // (>= the stage: n R 16 B)
+static int dft6_attr() {
+  static bool done = false;
+  if (!done) {
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  return 0;
+}
+int dft6_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
+  if (int rc = dft6_attr()) return rc;
+  dim3 grid(p.L, (ncol / 2 + D6_R - 1) / D6_R), block(256 * D6_R);
+  hipLaunchKernelGGL(k_px2ring6, grid, block, dft6_lds(), st, dft6_args(p), in, G, ncol, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+int dft6_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st) {
+  if (int rc = dft6_attr()) return rc;
+  dim3 grid(p.L, (C + D6_R - 1) / D6_R), block(256 * D6_R);
+  hipLaunchKernelGGL(k_ring2px6, grid, block, dft6_lds(), st, dft6_args(p), G, ncol, out, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }

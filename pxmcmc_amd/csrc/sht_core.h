@@ -175,6 +175,12 @@ struct Dft5Tables {
   const double *cE = nullptr, *cO = nullptr, *dO = nullptr, *tw1 = nullptr, *wt = nullptr, *bE = nullptr, *bO = nullptr;
 };
 
+// tables of the four-waves-per-ring kernels (512 < n <= 1023, dft5.hip k_*6)
+struct Dft6Tables {
+  double* d_all = nullptr;
+  const double *cA = nullptr, *cB = nullptr, *dA = nullptr, *dB = nullptr, *tw1 = nullptr, *wt = nullptr, *bQ = nullptr;
+};
+
 struct DftPlan {
   int L = 0, n = 0, M = 0, logM = 0, Rp = 0;
   int R = 0;        // chains per workgroup
@@ -191,6 +197,9 @@ struct DftPlan {
   Dft5Tables t5;
   int R5 = 0, TR5 = 0;
   size_t lds5 = 0;
+  // four waves per ring (dft5.hip, k_*6): M = 2048 = 4 x 512 for 256 < L <= 512 (default there)
+  bool use6 = false;
+  Dft6Tables t6;
   // two-wave path (dft3.hip, k_*4): M = 2048 for 256 < L <= 512
   bool use4 = false;
   double *d_bhatn4 = nullptr, *d_twm4 = nullptr;  // FFT_2048(filter)/2048 natural order; 32 x 32 W_1024 table
@@ -263,6 +272,9 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
                       const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available
 int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
                       Profiler* prof = nullptr);
+int dft6_make_tables(int n, Dft6Tables* t);
+int dft6_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
+int dft6_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
 int dft4_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft4_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
 int dft3_size(int n);  // square Bluestein size of the wave path for ring length n, 0 = none

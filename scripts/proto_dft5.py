@@ -150,3 +150,49 @@ if __name__ == "__main__":
         ref = np.fft.fft(rings, axis=1)
         print(f"L={L:4d} n={n:4d} Mh={t['Mh']:4d} RPW={t['RPW']}  max err {np.abs(got - ref).max():.2e}")
         assert np.abs(got - ref).max() < 1e-10 * np.abs(ref).max()
+
+
+# ---- four waves per ring: 512 < n <= 1023, M = 2048 = 4 x 512 (csrc/dft5.hip, k_*6) ---------------------------
+def dft_quad(x):
+    """radix-4 split of the Bluestein transform: wave w runs the 512-point convolution of the bins 4k'+w.
+    x: [n] complex, 512 < n <= 1023.  Returns DFT(x) computed the way the kernel does."""
+    n = x.size
+    M = 2048
+    j = np.arange(n)
+    c = np.exp(-1j * np.pi * ((j * j) % (2 * n)) / n)
+    cp = np.zeros(1024, complex)
+    cp[:n] = c
+    filt = np.zeros(M, complex)
+    filt[:n] = np.conj(c)
+    filt[M - j[1:]] = np.conj(c[1:])
+    bhat = np.fft.fft(filt) / M
+    xp = np.zeros(1024, complex)
+    xp[:n] = x
+    jp = np.arange(512)
+    out_lo = np.zeros(512, complex)
+    out_hi = np.zeros(512, complex)
+    t512 = tables(511)  # the Mh = 512 transform machinery (r0 = 8)
+    for w in range(4):
+        W = np.exp(-2j * np.pi * jp * w / M)
+        cA, cB = cp[:512] * W, (-1j) ** w * cp[512:] * W
+        dA, dB = cp[:512] * np.conj(W), cp[512:] * (1j) ** w * np.conj(W)
+        b = xp[:512] * cA + xp[512:] * cB
+        # lane layout: element j' = lane + 64 p
+        z = b.reshape(8, 64)
+        lane = np.arange(64)
+        k1, k2 = lane & 7, lane >> 3
+        bw = np.stack([bhat[4 * (k2 + 8 * k1 + 64 * k0) + w] for k0 in range(8)])
+        y = fft_inv(fft_fwd(z, t512) * bw, t512).reshape(512)
+        out_lo += dA * y
+        out_hi += dB * y
+    return np.concatenate([out_lo, out_hi])[:n]
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(1)
+    for L in (257, 300, 400, 512):
+        n = 2 * L - 1
+        x = rng.normal(size=n) + 1j * rng.normal(size=n)
+        got, ref = dft_quad(x), np.fft.fft(x)
+        print(f"quad L={L} n={n} max err {np.abs(got - ref).max():.2e}")
+        assert np.abs(got - ref).max() < 1e-10 * np.abs(ref).max()

@@ -112,8 +112,9 @@ def test_full_size_properties_L256():
 
 
 def test_two_wave_dft_path_L_above_256(monkeypatch):
-    """256 < L <= 512: the phi-DFT runs as two waves per ring (M = 2048 = 2 x 1024).  Same results as the radix-2
-    in-LDS fallback kernel, exact round trip, adjoint dot tests, and the fused residual / MYULA epilogues."""
+    """256 < L <= 512: the phi-DFT runs as four waves per ring (M = 2048 = 4 x 512, 8 points per lane; default) or as
+    two waves per ring (M = 2048 = 2 x 1024, PXM_DFT_NO_Q=1).  Same results as the radix-2 in-LDS fallback kernel,
+    exact round trip, adjoint dot tests, and the fused residual / MYULA epilogues."""
     import torch
 
     from pxmcmc_amd import ops
@@ -123,12 +124,16 @@ def test_two_wave_dft_path_L_above_256(monkeypatch):
     flm = torch.randn(C, L * L, dtype=torch.complex128, generator=g)
     x = torch.randn(C, L * (2 * L - 1), dtype=torch.complex128, generator=g)
     fast = ops.ShtPlan(L, 0, max_chains=C)
+    monkeypatch.setenv("PXM_DFT_NO_Q", "1")
+    two = ops.ShtPlan(L, 0, max_chains=C)
+    monkeypatch.delenv("PXM_DFT_NO_Q")
     monkeypatch.setenv("PXM_DFT_NO_W2", "1")
     slow = ops.ShtPlan(L, 0, max_chains=C)
     monkeypatch.delenv("PXM_DFT_NO_W2")
     for name, arg in (("inverse", flm), ("forward_adjoint", flm), ("forward", x), ("inverse_adjoint", x)):
-        a, b = getattr(fast, name)(arg), getattr(slow, name)(arg)
+        a, a2, b = getattr(fast, name)(arg), getattr(two, name)(arg), getattr(slow, name)(arg)
         assert float((a - b).abs().max()) < 1e-11 * float(b.abs().max()), name
+        assert float((a2 - b).abs().max()) < 1e-11 * float(b.abs().max()), name
     f = fast.inverse(flm)
     assert float((fast.forward(f).cpu() - flm).abs().max()) < 1e-10 * float(flm.abs().max())
     for fwd, adj, a, b in ((fast.inverse, fast.inverse_adjoint, flm, x), (fast.forward, fast.forward_adjoint, x, flm)):
