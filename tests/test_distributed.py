@@ -6,6 +6,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -62,3 +63,63 @@ def test_two_process_gloo_run(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "OK 0 3" in res.stdout
+
+
+HIP_WORKER = textwrap.dedent(
+    """
+    import contextlib, io, os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["PXM_ROOT"])
+    import torch
+    from pxmcmc_amd import distributed as D
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    rank, local_rank, world = D.init(backend="gloo")   # both ranks share the one GPU of the test box (RCCL refuses that)
+    torch.cuda.set_device(0)
+    L, B, J_min, TOTAL = 16, 2, 2, 6
+    data = np.random.default_rng(3).normal(size=L * (2 * L - 1))     # same problem on every rank
+    first, count = D.shard_chains(TOTAL, rank, world)
+    op = SphericalWaveletTransformOperator(data, 0.2, "synthesis", L, B, J_min, max_chains=count)
+    reg = S2_Wavelets_L1("synthesis", None, None, 1e-3, L=L, B=B, J_min=J_min)
+    p = PxMCMCParams(lmda=1e-3, delta=5e-4, nsamples=3, nburn=4, ngap=2, verbosity=0)
+    s = MYULA(op, reg, p, nchains=count, seed=21, chain_offset=first)   # Philox keyed by the GLOBAL chain id
+    with contextlib.redirect_stdout(io.StringIO()):
+        s.run(start_point=np.zeros(op.nparams))
+    assert s.used_graph
+    mine = s.chain if count > 1 else s.chain[None]
+    D.barrier()
+    allc = D.gather_summaries(mine).numpy()
+    t = D.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        op1 = SphericalWaveletTransformOperator(data, 0.2, "synthesis", L, B, J_min, max_chains=TOTAL)
+        one = MYULA(op1, reg, p, nchains=TOTAL, seed=21)
+        with contextlib.redirect_stdout(io.StringIO()):
+            one.run(start_point=np.zeros(op1.nparams))
+        assert allc.shape == one.chain.shape, (allc.shape, one.chain.shape)
+        err = np.abs(allc - one.chain).max() / np.abs(one.chain).max()
+        assert err < 1e-12, err      # sharded over 2 processes == one batch of 6 chains
+        assert t == 2.0
+        print("HIP-OK", first, count, flush=True)
+    D.barrier()
+    """
+)
+
+
+@pytest.mark.gpu
+def test_two_rank_hip_chain_sharding(tmp_path):
+    """SURVEY.md row (e) on the HIP path: two processes (torchrun, gloo rendezvous, both on the box's one GPU) each
+    run the fused HIP MYULA engine on their shard of 6 chains; gathered, the chains equal a single-process batch of
+    6 -- the Philox stream is keyed by the global chain id, nothing else crosses the process boundary."""
+    script = tmp_path / "hip_worker.py"
+    script.write_text(HIP_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PXM_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "HIP-OK 0 3" in res.stdout
