@@ -637,6 +637,11 @@ class capture_scope:
         return False
 
 
+def tables_trim():
+    """free every cached ring table no live plan holds (the cache is per device and shared by plans); MiB released"""
+    return int(check(lib.pxm_tables_trim()))
+
+
 # ---- host helpers ------------------------------------------------------------------------
 def j_max(L, B):
     return int(check(lib.pxm_j_max(int(L), float(B))))

@@ -185,3 +185,30 @@ def test_dft_kernel_variants_agree_and_match_oracle(L, monkeypatch):
         for name, ref in refs.items():
             got = getattr(plan, name)(flm if name in ("inverse", "forward_adjoint") else f).cpu().numpy()
             assert _rel(got, ref) < TOL, (env, name, _rel(got, ref))
+
+
+def test_table_cache_is_reference_counted_and_trimmable():
+    """The ring tables are cached per device and shared by plans; a plan retains the entries it uses, and
+    pxm_tables_trim frees exactly the entries no live plan holds (include/pxmcmc_amd.h)."""
+    import gc
+
+    import torch
+
+    from pxmcmc_amd import ops
+
+    L = 37  # a bandlimit no other test uses: its tables are ours alone
+    a = ops.ShtPlan(L, 0, max_chains=1)
+    b = ops.ShtPlan(L, 0, max_chains=2)  # shares a's tables
+    flm = torch.randn(L * L, dtype=torch.complex128)
+    ref = a.inverse(flm).cpu()
+    ops.tables_trim()  # both plans alive: nothing of theirs may go
+    assert float((b.inverse(flm).cpu() - ref).abs().max()) == 0.0
+    del a
+    gc.collect()
+    ops.tables_trim()  # b still holds the entry
+    assert float((b.inverse(flm).cpu() - ref).abs().max()) == 0.0
+    del b
+    gc.collect()
+    assert ops.tables_trim() >= 0  # the entry is released now (four tables of 37^2 x 19 doubles: < 1 MiB, so 0 is fine)
+    c = ops.ShtPlan(L, 0, max_chains=1)  # rebuilt from scratch
+    assert float((c.inverse(flm).cpu() - ref).abs().max()) == 0.0
