@@ -6,6 +6,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
 #include <memory>
 
 namespace pxm {
@@ -28,15 +31,63 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
   out->bls = bls;
   los.resize(bls.size(), 0);
   out->los = los;
-  // Static balance.  Workgroups are placed round-robin over the CUs in launch order, and for these
-  // launches (almost) all of them are resident at once, so the order IS the schedule: assign tasks to
-  // one bin per CU by the LPT rule (longest first, always into the lightest bin), then emit round by
-  // round -- workgroup r*nbins + b is the r-th task of bin b.  A plain descending order would give
-  // CU i the tasks i and i + nbins: heaviest + median on one CU, median + lightest on another.
-  auto work = [](const GemmTask& a) { return (int64_t)(a.k_end - a.k_beg) * a.n_rt; };
+  // Static balance and operand locality.  The dispatcher deals workgroup i to XCD i % 8 and, inside an XCD,
+  // to whichever CU has a free slot, in id order: the ids congruent to x (mod 8) are XCD x's queue, served
+  // longest-first if the queue is in descending order (greedy LPT over its 32 CUs x 4 slots).  Tasks that read
+  // the same operand slab (same x_off: the row groups of one m, and for the harmonic-side lists every scale of
+  // that m) form a unit that stays together in ONE queue, back to back, so the slab is fetched into that XCD's
+  // L2 once (PMC at L=512: 1.27x -> see DESIGN.md section 9).  Units go to the lightest queue, longest first;
+  // queues are padded to equal length with empty tasks (n_rt = 0: the workgroup exits at once).
+  // PXM_GEMM_ORDER=xcd|bins|plain forces one order (bins: LPT over one bin per CU, emitted round by round --
+  // workgroup r*256 + b lands on XCD b % 8, CU (b / 8) % 32; plain: descending).
+  // Which of the two applies depends on the regime: up to ~2 workgroups per slot (256 CUs x 4) the launch is
+  // (almost) resident at once and the per-CU bins win (L=256: 24.5 vs 26.5 us Gram, 31.4 vs 32.1 us groups); with
+  // many rounds per slot the queues win (L=512: 200 vs 218 us, 218 vs 231 us).
+  const char* order_env = getenv("PXM_GEMM_ORDER");
+  const std::string order = getenv("PXM_GEMM_PLAIN_ORDER") ? "plain" : (order_env ? order_env : (v.size() > 2048 ? "xcd" : "bins"));
+  const int64_t fixed = order == "xcd" ? 32 : 0;  // start-up / drain of a task in contraction steps
+  auto work = [fixed](const GemmTask& a) { return (int64_t)(a.k_end - a.k_beg + fixed) * a.n_rt; };
   std::stable_sort(v.begin(), v.end(), [&](const GemmTask& a, const GemmTask& b) { return work(a) > work(b); });
-  int nbins = 256;
-  if (!getenv("PXM_GEMM_PLAIN_ORDER") && (int)v.size() > nbins) {
+  if (order == "xcd" && !v.empty()) {
+    constexpr int NQ = 8;  // XCDs of gfx950
+    std::map<int64_t, int> unit_of;
+    std::vector<std::vector<GemmTask>> units;
+    for (const GemmTask& t : v) {  // (v is in descending order: so is every unit)
+      auto it = unit_of.find(t.x_off[0]);
+      if (it == unit_of.end()) {
+        it = unit_of.emplace(t.x_off[0], (int)units.size()).first;
+        units.emplace_back();
+      }
+      units[it->second].push_back(t);
+    }
+    std::vector<int64_t> uw(units.size(), 0);
+    std::vector<int> idx(units.size());
+    for (size_t u = 0; u < units.size(); ++u) {
+      idx[u] = (int)u;
+      for (const GemmTask& t : units[u]) uw[u] += work(t);
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return uw[a] > uw[b]; });
+    std::vector<std::vector<GemmTask>> q(NQ);
+    int64_t load[NQ] = {0};
+    for (int u : idx) {
+      int best = 0;
+      for (int x = 1; x < NQ; ++x)
+        if (load[x] < load[best] || (load[x] == load[best] && q[x].size() < q[best].size())) best = x;
+      q[best].insert(q[best].end(), units[u].begin(), units[u].end());
+      load[best] += uw[u];
+    }
+    size_t len = 0;
+    for (int x = 0; x < NQ; ++x) len = std::max(len, q[x].size());
+    GemmTask empty;
+    memset(&empty, 0, sizeof(empty));
+    std::vector<GemmTask> ordered;
+    ordered.reserve(len * NQ);
+    for (size_t r = 0; r < len; ++r)
+      for (int x = 0; x < NQ; ++x) ordered.push_back(r < q[x].size() ? q[x][r] : empty);
+    while (!ordered.empty() && ordered.back().n_rt == 0) ordered.pop_back();  // (trailing padding is not needed)
+    v.swap(ordered);
+  } else if (order == "bins" && (int)v.size() > 256) {
+    int nbins = 256;
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   const GemmTask t = tasks[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63;
   if (aff.bump && blockIdx.x == 0 && tid == 0) *aff.bump += 1;  // Philox iteration counter of the ring-space step
+  if (t.n_rt == 0) return;  // padding entry of the XCD-queue order (plans.hip: upload_tasks)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the row-tile tests scalar
   const int kq = lane >> 4, cl = lane & 15;
   const int n_my = min(RT, max(0, t.n_rt - RT * wave));       // row tiles of this wave

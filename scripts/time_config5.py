@@ -40,3 +40,18 @@ for C in (2, 1):
             dt = time.time() - t0
             print(f"C={C} fused_wl={fuse} graph={s.used_graph} ({s.graph_error}): {s.niter} iterations in {dt:.2f} s = "
                   f"{dt / s.niter * 1e3:.3f} ms/iter, acc={np.mean(s.acceptance_trace):.2f}, finite={np.isfinite(s.chain).all()}", flush=True)
+            if os.environ.get("PROFILE"):  # ring-GEMM launch classes of one forward + gradient (HIP events per launch)
+                plan = op._wl_plan() if fuse else tr._plan
+                nrep = 20
+                Xd = torch.randn(C, tr.ncoefs, dtype=torch.float64, generator=g).cuda() * 1e-3
+                plan.profile_enable(8 * nrep)
+                for _ in range(nrep):
+                    op.calc_gradg(op.forward(Xd))
+                torch.cuda.synchronize()
+                l_ms, l_bytes = plan.profile_read_launches(8 * nrep)
+                plan.profile_enable(0)
+                for nbytes in sorted(set(np.round(l_bytes).tolist())):
+                    sel = np.round(l_bytes) == nbytes
+                    us = float(l_ms[sel].mean() * 1e3)
+                    print(f"    k_sht_gemm class {nbytes / 1e6:8.1f} MB algorithmic: {int(sel.sum())} launches, {us:7.1f} us avg = "
+                          f"{nbytes / us / 1e6:.2f} TB/s = {nbytes / us / 1e6 / 8:.2f} of 8 TB/s", flush=True)

@@ -212,3 +212,31 @@ def test_table_cache_is_reference_counted_and_trimmable():
     assert ops.tables_trim() >= 0  # the entry is released now (four tables of 37^2 x 19 doubles: < 1 MiB, so 0 is fine)
     c = ops.ShtPlan(L, 0, max_chains=1)  # rebuilt from scratch
     assert float((c.inverse(flm).cpu() - ref).abs().max()) == 0.0
+
+
+def test_gemm_task_orders_are_bit_identical(monkeypatch):
+    """The ring-GEMM task lists are scheduled per regime (csrc/plans.hip upload_tasks): per-CU bins for launches that
+    are resident at once, per-XCD queues of operand-sharing units (padded with empty tasks) for long lists.  The
+    order is a schedule only: every order gives bit-identical transforms, here through a wavelet plan (grouped
+    lists over scales, Gram step) and a spin-2 plan (unpaired tables)."""
+    import torch
+
+    from pxmcmc_amd import ops
+
+    L, B, J_min, C = 40, 2, 2, 3
+    g = torch.Generator().manual_seed(7)
+    outs = {}
+    for order in ("bins", "xcd", "plain"):
+        monkeypatch.setenv("PXM_GEMM_ORDER", order)
+        wav = ops.WavPlan(L, B, J_min, max_chains=C)
+        sht = ops.ShtPlan(L, 2, max_chains=C)
+        monkeypatch.delenv("PXM_GEMM_ORDER")
+        g.manual_seed(7)
+        X = torch.randn(C, wav.ncoefs, dtype=torch.float64, generator=g).cuda()
+        f = torch.randn(C, wav.npix, dtype=torch.complex128, generator=g).cuda()
+        flm = torch.randn(C, L * L, dtype=torch.complex128, generator=g).cuda()
+        outs[order] = [wav.synthesis(X).cpu(), wav.synthesis_adjoint(f).cpu(), sht.inverse(flm).cpu(),
+                       sht.forward(f).cpu(), sht.inverse_adjoint(f).cpu(), sht.forward_adjoint(flm).cpu()]
+    for order in ("xcd", "plain"):
+        for a, b in zip(outs["bins"], outs[order]):
+            assert torch.equal(torch.view_as_real(a) if a.is_complex() else a, torch.view_as_real(b) if b.is_complex() else b), order
