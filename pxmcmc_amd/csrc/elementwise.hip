@@ -120,7 +120,13 @@ __device__ inline double2 block_sum2(double2 v) {
   return tot;
 }
 
-constexpr int RED_SLICES = 64;
+// Two-stage reductions: `slices` workgroups per chain write one partial each, a second kernel adds the partials
+// in a fixed order.  The slice count depends on the vector length only (never on the number of chains, so a
+// chain's sums do not depend on its batch): >= 2048 elements per workgroup, 64 ... RED_SLICES_MAX slices.
+constexpr int RED_SLICES_MIN = 64, RED_SLICES_MAX = 1024;
+static inline int red_slices(int64_t n) {
+  return (int)std::min<int64_t>(RED_SLICES_MAX, std::max<int64_t>(RED_SLICES_MIN, (n + 2047) / 2048));
+}
 
 template <bool CPLX>
 __global__ void k_l1_partial(const double* __restrict__ X, const double* __restrict__ w, double* __restrict__ part,
@@ -215,7 +221,7 @@ __global__ void k_reduce_final(const double* __restrict__ part, double* __restri
                                const double* __restrict__ delta_dev, double delta) {
   const int c = blockIdx.x;
   double2 v{0.0, 0.0};
-  if ((int)threadIdx.x < slices) v = reinterpret_cast<const double2*>(part)[(int64_t)c * slices + threadIdx.x];
+  for (int sl = threadIdx.x; sl < slices; sl += 64) v = cadd(v, reinterpret_cast<const double2*>(part)[(int64_t)c * slices + sl]);
   for (int off = 32; off > 0; off >>= 1) {
     v.x += __shfl_down(v.x, off);
     v.y += __shfl_down(v.y, off);
@@ -289,10 +295,10 @@ __global__ void k_pxmala_propose_final(const double* __restrict__ part, double* 
   const int c = blockIdx.x;
   double2 v{0.0, 0.0};
   double a = 0.0;
-  if ((int)threadIdx.x < slices) {
-    const double* o = part + ((int64_t)c * slices + threadIdx.x) * 4;
-    v = double2{o[0], o[1]};
-    a = o[2];
+  for (int sl = threadIdx.x; sl < slices; sl += 64) {
+    const double* o = part + ((int64_t)c * slices + sl) * 4;
+    v = cadd(v, double2{o[0], o[1]});
+    a += o[2];
   }
   for (int off = 32; off > 0; off >>= 1) {
     v.x += __shfl_down(v.x, off);
@@ -361,7 +367,7 @@ __global__ void k_counter_add(uint64_t* c, uint64_t inc) { *c += inc; }
 // Reductions run in two deterministic stages through a CALLER-OWNED scratch of pxm_reduce_scratch_doubles(C)
 // doubles (partial sums of every slice, then the per-chain totals): no library-owned buffer is shared between
 // calls, streams or plans.
-static inline size_t red_scratch_doubles(int C) { return (size_t)(C + 1) * RED_SLICES * 2; }
+static inline size_t red_scratch_doubles(int C) { return (size_t)(C + 1) * RED_SLICES_MAX * 2; }  // (pxm_pxmala_propose: 4x this)
 
 __global__ void k_l1_store(const double* __restrict__ red, double* __restrict__ out, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -516,12 +522,13 @@ int pxm_reduce_l1(const void* X, const double* w, double* out, double* scratch, 
   hipStream_t st = (hipStream_t)stream;
   PXM_REQUIRE(X && out && scratch, "pxm_reduce_l1: null buffer");
   double* part = scratch;
-  dim3 g(RED_SLICES, C), b(256);
+  const int RS = red_slices(n);
+  dim3 g(RS, C), b(256);
   if (dtype) hipLaunchKernelGGL(k_l1_partial<true>, g, b, 0, st, (const double*)X, w, part, n);
   else hipLaunchKernelGGL(k_l1_partial<false>, g, b, 0, st, (const double*)X, w, part, n);
-  double* red = part + (size_t)C * RED_SLICES * 2;
+  double* red = part + (size_t)C * RS * 2;
   // final sums land in the tail of the scratch, then the real parts are compacted to out[C]
-  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, red, RED_SLICES, 0, (const double*)nullptr, 0.0);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, red, RS, 0, (const double*)nullptr, 0.0);
   hipLaunchKernelGGL(k_l1_store, dim3((C + 63) / 64), dim3(64), 0, st, red, out, C);
   PXM_HIP(hipGetLastError());
   return 0;
@@ -534,12 +541,13 @@ int pxm_reduce_l2(const void* preds, const void* data, const void* invcov, int i
   hipStream_t st = (hipStream_t)stream;
   PXM_REQUIRE(preds && data && invcov && out && scratch, "pxm_reduce_l2: null buffer");
   double* part = scratch;
-  dim3 g(RED_SLICES, C), b(256);
+  const int RS = red_slices(n);
+  dim3 g(RS, C), b(256);
   const double *p = (const double*)preds, *d = (const double*)data, *ic = (const double*)invcov;
   if (dtype && invcov_complex) hipLaunchKernelGGL((k_l2_partial<true, true>), g, b, 0, st, p, d, ic, part, n);
   else if (dtype) hipLaunchKernelGGL((k_l2_partial<true, false>), g, b, 0, st, p, d, ic, part, n);
   else hipLaunchKernelGGL((k_l2_partial<false, false>), g, b, 0, st, p, d, ic, part, n);
-  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, out, RED_SLICES, 0, (const double*)nullptr, 0.0);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, out, RS, 0, (const double*)nullptr, 0.0);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -549,10 +557,11 @@ int pxm_reduce_vdot(const void* a, const void* b, double* out, double* scratch, 
   PXM_REQUIRE(n >= 0 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_reduce_vdot: bad n / C / dtype");
   PXM_REQUIRE(a && b && out && scratch, "pxm_reduce_vdot: null buffer");
   hipStream_t st = (hipStream_t)stream;
-  dim3 g(RED_SLICES, C), blk(256);
+  const int RS = red_slices(n);
+  dim3 g(RS, C), blk(256);
   if (dtype) hipLaunchKernelGGL(k_vdot_partial<true>, g, blk, 0, st, (const double*)a, (const double*)b, scratch, n);
   else hipLaunchKernelGGL(k_vdot_partial<false>, g, blk, 0, st, (const double*)a, (const double*)b, scratch, n);
-  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, scratch, out, RED_SLICES, 0, (const double*)nullptr, 0.0);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, scratch, out, RS, 0, (const double*)nullptr, 0.0);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -564,14 +573,15 @@ int pxm_logtransition(const void* X1, const void* X2, const void* proxf, const v
   hipStream_t st = (hipStream_t)stream;
   PXM_REQUIRE(X1 && X2 && proxf && gradg && out && scratch, "pxm_logtransition: null buffer");
   double* part = scratch;
-  dim3 g(RED_SLICES, C), b(256);
+  const int RS = red_slices(n);
+  dim3 g(RS, C), b(256);
   if (dtype)
     hipLaunchKernelGGL(k_logtrans_partial<true>, g, b, 0, st, (const double*)X1, (const double*)X2, (const double*)proxf,
                        (const double*)gradg, delta_dev, delta, lmda, part, n);
   else
     hipLaunchKernelGGL(k_logtrans_partial<false>, g, b, 0, st, (const double*)X1, (const double*)X2,
                        (const double*)proxf, (const double*)gradg, delta_dev, delta, lmda, part, n);
-  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, out, RED_SLICES, 1, delta_dev, delta);
+  hipLaunchKernelGGL(k_reduce_final, dim3(C), dim3(64), 0, st, part, out, RS, 1, delta_dev, delta);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -586,7 +596,8 @@ int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, cons
               "pxm_pxmala_propose: null buffer");
   PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_pxmala_propose: complex noise needs a complex state");
   hipStream_t st = (hipStream_t)stream;
-  dim3 g(RED_SLICES, C), b(256);
+  const int RS = red_slices(n);
+  dim3 g(RS, C), b(256);
   NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, iter_dev};
   if (dtype)
     hipLaunchKernelGGL(k_pxmala_propose<true>, g, b, 0, st, (const double*)X, (const double*)proxf, (const double*)gradg, T,
@@ -594,7 +605,7 @@ int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, cons
   else
     hipLaunchKernelGGL(k_pxmala_propose<false>, g, b, 0, st, (const double*)X, (const double*)proxf, (const double*)gradg, T,
                        T_scalar, prior_weights, delta_dev, lmda, ns, (double*)X_prop, (double*)proxf_prop, scratch, n);
-  hipLaunchKernelGGL(k_pxmala_propose_final, dim3(C), dim3(64), 0, st, scratch, logtrans_out, prior_out, RED_SLICES, delta_dev);
+  hipLaunchKernelGGL(k_pxmala_propose_final, dim3(C), dim3(64), 0, st, scratch, logtrans_out, prior_out, RS, delta_dev);
   PXM_HIP(hipGetLastError());
   return 0;
 }
