@@ -310,19 +310,24 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
   for (int i = threadIdx.x; i < D5_TW; i += blockDim.x) lds5[2 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : a.wt[i - 448];
 #define PXM_D5_SLOT(RING, K, CH) ((((RING)*n + (K)) << lgR) + (((CH) + ((K) >> rsh)) & (R - 1)))
 
-// stage -> G rows of every ring of the workgroup
-#define PXM_D5_STORE_RINGS                                                                                     \
+// stage -> G rows of every ring of the workgroup.  ZFILL (pixels -> rings): chain groups without a live chain do
+// not run at all, and the last live group also writes zeros into the padding slots of its (m, ring) lines -- the
+// ring arrays keep zero padding columns and every 128-B line is written whole.
+#define PXM_D5_STORE_RINGS(ZFILL)                                                                              \
   {                                                                                                            \
     const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;                 \
     const int mstride = a.Rp * Cp; /* complex elements between consecutive m */                                \
     double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;                                                     \
+    const bool zf = (ZFILL) && c0 + R >= C;                                                                    \
     if (c0 + rr < Cp) {                                                                                        \
       _Pragma("nounroll") for (int trr = 0; trr < TRS; ++trr) {                                                \
         const int tt = bx * TRS + trr;                                                                         \
         if (tt >= a.L) break;                                                                                  \
         for (int k = kq; k < n; k += kstep) {                                                                  \
           const int mi = (k < a.L) ? k + a.L - 1 : k - a.L; /* m + L - 1 */                                    \
-          Gc[mi * mstride + tt * Cp] = stage[PXM_D5_SLOT(trr, k, rr)];                                         \
+          double2* line = Gc + mi * mstride + tt * Cp;                                                         \
+          *line = stage[PXM_D5_SLOT(trr, k, rr)];                                                              \
+          if (zf) for (int z = R; c0 + rr + z < Cp; z += R) line[z] = double2{0.0, 0.0};                       \
         }                                                                                                      \
       }                                                                                                        \
     }                                                                                                          \
@@ -344,6 +349,7 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 template <int R0>
 __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in, double* __restrict__ G, int ncol, int C,
                                               int bx, int by, double2* lds5) {
+  if ((by << a.lgR) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
   PXM_D5_GEOMETRY
   // each wave of the pair fetches half of the ring set (its four p) and the two share it through the stage
 #pragma unroll
@@ -365,7 +371,7 @@ __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in,
   __syncthreads();  // the stage is dead: the planes may be written
   PXM_D5_TRANSFORM(0)
   PXM_D5_TO_STAGE
-  PXM_D5_STORE_RINGS
+  PXM_D5_STORE_RINGS(true)
 }
 
 // rings -> pixels (inverse DFT by conjugation) with out's epilogue; RING_OUT: the written ring is transformed
@@ -476,7 +482,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
   __syncthreads();                                    // ... and every exchange read is done before the planes are reused
   PXM_D5_TRANSFORM(0)
   PXM_D5_TO_STAGE
-  PXM_D5_STORE_RINGS
+  PXM_D5_STORE_RINGS(false)
 }
 
 template <int R0>
@@ -609,6 +615,7 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
   extern __shared__ double2 lds5[];
   if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
   const int bx = blockIdx.x, by = blockIdx.y;
+  if ((by << a.lgR) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
   PXM_D6_GEOMETRY
   // every wave fetches a quarter of the ring (its two p, both halves) and the four share it through the stage
 #pragma unroll
@@ -618,7 +625,11 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
       const int j = lane + 64 * (2 * w + ii) + 512 * hq;
       if (j < n) {
         const int64_t e = in.ring0 + (int64_t)t * n + j;
+#if PXM_D5_ABLATE & 16
+        stage[PXM_D6_SLOT(j, r)] = double2{1.0 + (double)(e & 7), 0.5};
+#else
         stage[PXM_D6_SLOT(j, r)] = (ch < C) ? px_in_load(in, ch, e) : double2{0.0, 0.0};
+#endif
       }
     }
   __syncthreads();  // (also: the LDS copy of the twiddles is complete)
@@ -645,8 +656,20 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
     const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;
     const int mstride = a.Rp * Cp;
     double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;
+#if PXM_D5_ABLATE & 8
+    double2 sink{0.0, 0.0};
     if (c0 + rr < Cp)
-      for (int k = kq; k < n; k += kstep) Gc[((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + t * Cp] = stage[PXM_D6_SLOT(k, rr)];
+      for (int k = kq; k < n; k += kstep) sink = cadd(sink, stage[PXM_D6_SLOT(k, rr)]);
+    if (sink.x == 1.2345e300) Gc[t * Cp] = sink;
+#else
+    const bool zf = c0 + R >= C;  // last live chain group: the padding slots of the line are zeroed (whole 128-B lines)
+    if (c0 + rr < Cp)
+      for (int k = kq; k < n; k += kstep) {
+        double2* line = Gc + ((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + t * Cp;
+        *line = stage[PXM_D6_SLOT(k, rr)];
+        if (zf) for (int z = R; c0 + rr + z < Cp; z += R) line[z] = double2{0.0, 0.0};
+      }
+#endif
   }
 }
 
