@@ -259,7 +259,8 @@ def main():
 
     ms, nl, nb, nf, dms, dnl, dnb = _V(gms), _V(gnl), _V(gnb), _V(gnf), _V(dms_), _V(dnl_), _V(dnb_)
     X, preds = sampler._engine_state()
-    assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
+    if not os.environ.get("PXM_BENCH_ABLATION"):  # (timing-only ablation builds of the library compute garbage)
+        assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
 
     dt = D.max_over_ranks(dt)
     used_graph = eng["graph"] is not None

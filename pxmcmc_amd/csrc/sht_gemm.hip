@@ -37,6 +37,16 @@ constexpr int KC = 16;  // contraction rows per staged chunk
 // occupancy hides the load latency (60 VGPR at 16 columns, 4 workgroups per CU); 3 / 4 sets measured 10-15 % slower
 // on the grouped launches, and 4 % / 16 % slower on the Gram launch too (PXM_GEMM_GRAM_NSET=3|4 for A/B runs: its
 // short tasks re-read their last chunk in the deeper prologue, its long chains are not what bounds it).
+// timing-only ablations (development; results are wrong): PXM_GEMM_ABLATE & 1 no MFMA, & 2 no table loads,
+// & 4 no operand staging (loads, LDS stores and the per-chunk barrier)
+#ifndef PXM_GEMM_ABLATE
+#define PXM_GEMM_ABLATE 0
+#endif
+#if PXM_GEMM_ABLATE & 1
+#define PXM_GEMM_MFMA(ACC, A, B) ACC[0] += (A) * (B);
+#else
+#define PXM_GEMM_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B, ACC, 0, 0, 0);
+#endif
 template <int CT, int NSLAB, int NW, int RT, int NSET>
 __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict__ tasks,
                                                       const double* __restrict__ X, double* __restrict__ Y,
@@ -146,10 +156,16 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
       const int u = pv % NSET;
       if (ch < nch) {
         const int buf = ch & 1;
+#if !(PXM_GEMM_ABLATE & 4)
         PXM_STAGE_STORE(pv % (NSET - 1), ch, buf)
         PXM_STAGE_LOAD(pv % (NSET - 1), ch + NSET - 1)   // (the set just stored is free again; clamped past the end)
+#endif
+#if !(PXM_GEMM_ABLATE & 2)
         PXM_TAB_LOAD((u + NSET - 1) % NSET, ch + NSET - 1)
+#endif
+#if !(PXM_GEMM_ABLATE & 4)
         __syncthreads();
+#endif
         if (v0) {
 #define PXM_MFMA_CHUNK(NC)                                                                                     \
   _Pragma("unroll") for (int h4 = 0; h4 < 4; ++h4) {                                                           \
@@ -158,7 +174,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     _Pragma("unroll") for (int r = 0; r < RT; ++r) {                                                           \
       const double av = (h4 & 1) ? A[u][r][h4 >> 1].y : A[u][r][h4 >> 1].x;                                    \
       _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                           \
-          acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b[c], acc[r][c], 0, 0, 0);                      \
+          PXM_GEMM_MFMA(acc[r][c], av, b[c])                                                                   \
     }                                                                                                          \
   }
           if (live4) { PXM_MFMA_CHUNK(NCT) } else { PXM_MFMA_CHUNK((NSLAB == 4 ? NCT / 2 : NCT)) }
