@@ -212,6 +212,18 @@ int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const do
                    double delta, double lmda, const void* noise, int noise_complex, uint64_t seed,
                    uint64_t chain0, uint64_t iter, void* X_out, int64_t n, int C, int dtype,
                    pxm_stream_t stream);
+/* The same two steps with a caller-owned device iteration counter: the Philox iteration is iter + *iter_dev, read
+ * when the kernel runs (NULL: iter alone), so a HIP graph of an iteration replays with fresh noise once the
+ * captured sequence ends with pxm_counter_add.  (MYULA's generic-operator stepping engine, pxmcmc/mcmc.py:157-164.) */
+int pxm_myula_step_it(const void* X, const void* gradg, const double* T, double T_scalar,
+                      const double* delta_dev, double delta, double lmda, const void* noise,
+                      int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter,
+                      const uint64_t* iter_dev, void* X_out, int64_t n, int C, int dtype,
+                      pxm_stream_t stream);
+int pxm_chain_step_it(const void* X, const void* proxf, const void* gradg, const double* delta_dev,
+                      double delta, double lmda, const void* noise, int noise_complex, uint64_t seed,
+                      uint64_t chain0, uint64_t iter, const uint64_t* iter_dev, void* X_out, int64_t n,
+                      int C, int dtype, pxm_stream_t stream);
 /* N(0,1) draws of the Philox4x32-10 stream keyed (seed, chain0+c, iter): out [C][n] (f64 or c128) */
 int pxm_randn(void* out, int64_t n, int C, int dtype, uint64_t seed, uint64_t chain0, uint64_t iter,
               pxm_stream_t stream);

@@ -85,6 +85,14 @@ SIGNATURES = {
         c_int,
         [c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_i64, c_int, c_int, c_vp],
     ),
+    "pxm_myula_step_it": (
+        c_int,
+        [c_vp, c_vp, c_vp, c_dbl, c_vp, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
+    ),
+    "pxm_chain_step_it": (
+        c_int,
+        [c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
+    ),
     "pxm_randn": (c_int, [c_vp, c_i64, c_int, c_int, c_u64, c_u64, c_u64, c_vp]),
     "pxm_reduce_l1": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_reduce_l2": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),

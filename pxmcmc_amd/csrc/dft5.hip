@@ -500,31 +500,52 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px5(Dft5Args a, doubl
   ring2px_body5<R0, RING_OUT>(a, G, ncol, out, C, blockIdx.x, blockIdx.y, lds5);
 }
 
-// Grouped launch of the ring-space step: the rings -> X' -> rings bodies of EVERY scale of a wavelet plan in one
-// grid, largest scales first (their workgroups are the long ones; the small scales fill the tail).
+// block id -> (scale entry, bx, by).  XCD-aware order inside a scale: the chain groups (by) of one ring set share
+// the 128-B lines of the ring arrays (8 chain slots per (m, ring)), so they are given block ids that differ by 8 --
+// same XCD (same L2) under the round-robin placement of blocks, dispatched back to back: the second one finds its
+// half-lines in L2 and their half-line stores merge there.  (b0 and the per-scale block counts are multiples of 8.)
+#define PXM_D5_GROUP_DECODE                                              \
+  int e = 0;                                                             \
+  while (e + 1 < nent && (int)blockIdx.x >= ents[e + 1].b0) ++e;         \
+  const Dft5Group g = ents[e];                                           \
+  const int local = blockIdx.x - g.b0;                                   \
+  const int rest = local >> 3;                                           \
+  const int by = rest % g.nby, bx = (rest / g.nby) * 8 + (local & 7);    \
+  if (bx >= g.nbx) return;                                               \
+  double* G = ws + g.g_off;                                              \
+  const Dft5Args a = g.a;
+
+// Grouped launch of the ring-space step: the rings -> X' -> rings bodies (RING_OUT) of EVERY scale of a wavelet plan
+// in one grid, largest scales first (their workgroups are the long ones; the small scales fill the tail); without
+// RING_OUT the plain rings -> pixels transform of every member scale (generic synthesis / adjoint operators).
+template <bool RING_OUT>
 __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5Group* __restrict__ ents, int nent,
                                                                                        double* __restrict__ ws, int ncol, PxOut out,
                                                                                        int C) {
   extern __shared__ double2 lds5[];
-  int e = 0;
-  while (e + 1 < nent && (int)blockIdx.x >= ents[e + 1].b0) ++e;
-  const Dft5Group g = ents[e];
-  // XCD-aware order inside a scale: the chain groups (by) of one ring set share the 128-B lines of the ring arrays
-  // (8 chain slots per (m, ring)), so they are given block ids that differ by 8 -- same XCD (same L2) under the
-  // round-robin placement of blocks, dispatched back to back: the second one finds its half-lines in L2 and their
-  // half-line stores merge there.  (b0 and the per-scale block counts are multiples of 8.)
-  const int local = blockIdx.x - g.b0;
-  const int rest = local >> 3;
-  const int by = rest % g.nby, bx = (rest / g.nby) * 8 + (local & 7);
-  if (bx >= g.nbx) return;
+  PXM_D5_GROUP_DECODE
   out.ring0 = g.ring0;
-  double* G = ws + g.g_off;
-  const Dft5Args a = g.a;
   switch (g.r0) {
-    case 8: ring2px_body5<8, true>(a, G, ncol, out, C, bx, by, lds5); break;
-    case 4: ring2px_body5<4, true>(a, G, ncol, out, C, bx, by, lds5); break;
-    case 2: ring2px_body5<2, true>(a, G, ncol, out, C, bx, by, lds5); break;
-    default: ring2px_body5<1, true>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 8: ring2px_body5<8, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 4: ring2px_body5<4, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 2: ring2px_body5<2, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
+    default: ring2px_body5<1, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
+  }
+}
+
+// pixels -> rings of every member scale in one grid
+__global__ __launch_bounds__(128 * D5_RMAX, 4) void k_px2ring_group5(const Dft5Group* __restrict__ ents, int nent,
+                                                                                       double* __restrict__ ws, int ncol, PxIn in,
+                                                                                       int C) {
+  extern __shared__ double2 lds5[];
+  if (in.bump && blockIdx.x == 0 && threadIdx.x == 0) *in.bump += 1;
+  PXM_D5_GROUP_DECODE
+  in.ring0 = g.ring0;
+  switch (g.r0) {
+    case 8: px2ring_body5<8>(a, in, G, ncol, C, bx, by, lds5); break;
+    case 4: px2ring_body5<4>(a, in, G, ncol, C, bx, by, lds5); break;
+    case 2: px2ring_body5<2>(a, in, G, ncol, C, bx, by, lds5); break;
+    default: px2ring_body5<1>(a, in, G, ncol, C, bx, by, lds5); break;
   }
 }
 
@@ -893,16 +914,20 @@ int dft5_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, 
 // ---- grouped launch (wavelet plan: every scale in one grid) -----------------------------------------------------
 int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
                       const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out) {
-  // longest workgroups first: full-size scales, then the smaller ones in descending size (they fill the tail)
-  std::vector<int> order(plans.size());
-  for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+  // members: the scales on the eight-points-per-lane path that share the workgroup shape of the largest of them
+  // (the others keep their own launches); longest workgroups first, the smaller scales fill the tail
+  std::vector<int> order;
+  for (size_t i = 0; i < plans.size(); ++i)
+    if (plans[i]->use5) order.push_back((int)i);
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return plans[x]->L > plans[y]->L; });
+  if (order.size() < 2) return 1;
   std::vector<Dft5Group> v;
+  out->member.assign(plans.size(), 0);
   int b0 = 0;
   size_t lds = 0;
   for (int s : order) {
     const DftPlan& p = *plans[s];
-    if (!p.use5 || p.R5 != plans[order[0]]->R5) return 1;
+    if (p.R5 != plans[order[0]]->R5) continue;
     Dft5Group g;
     g.a = dft5_args(p);
     g.g_off = g_off[s];
@@ -915,9 +940,16 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
     b0 += round_up(g.nbx, 8) * g.nby;  // (padded so that every scale starts on an XCD-label boundary)
     lds = std::max(lds, p.lds5);
     out->px_elems += (double)p.L * p.n;
+    out->member[s] = 1;
     v.push_back(g);
   }
+  if (v.size() < 2) {
+    out->member.clear();
+    out->px_elems = 0;
+    return 1;
+  }
   out->n = (int)v.size();
+  out->all = v.size() == plans.size();
   out->blocks = b0;
   out->lds = lds;
   out->five = true;
@@ -926,8 +958,9 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
   PXM_HIP(hipMemcpy(out->d, v.data(), v.size() * sizeof(Dft5Group), hipMemcpyHostToDevice));
   static bool attr = false;
   if (!attr) {
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring_group5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
   return 0;
@@ -939,8 +972,22 @@ int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut&
   const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
-  hipExtLaunchKernelGGL(k_ring2px_group5, dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
+  hipExtLaunchKernelGGL(k_ring2px_group5<true>, dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
                         reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int dft5_group_px2ring(const Dft3GroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_px2ring_group5, dim3(g.blocks), dim3(g.threads), g.lds, st, reinterpret_cast<const Dft5Group*>(g.d), g.n,
+                     ws, ncol, in, C);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int dft5_group_ring2px(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
+  hipLaunchKernelGGL(k_ring2px_group5<false>, dim3(g.blocks), dim3(g.threads), g.lds, st, reinterpret_cast<const Dft5Group*>(g.d),
+                     g.n, ws, ncol, out, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }

@@ -468,14 +468,15 @@ int pxm_residual_grad(const void* preds, const void* data, const void* invcov, i
   return 0;
 }
 
-int pxm_myula_step(const void* X, const void* gradg, const double* T, double T_scalar, const double* delta_dev,
-                   double delta, double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0,
-                   uint64_t iter, void* X_out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+int pxm_myula_step_it(const void* X, const void* gradg, const double* T, double T_scalar, const double* delta_dev,
+                      double delta, double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0,
+                      uint64_t iter, const uint64_t* iter_dev, void* X_out, int64_t n, int C, int dtype,
+                      pxm_stream_t stream) {
   CHECK_ARGS("pxm_myula_step");
   PXM_REQUIRE(X && gradg && X_out, "pxm_myula_step: null buffer");
   PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_myula_step: complex noise needs a complex state");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter};
+  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, iter_dev};
   if (dtype)
     hipLaunchKernelGGL((k_chain_step<true, true>), g, b, 0, st, (const double*)X, (const double*)nullptr,
                        (const double*)gradg, T, T_scalar, delta_dev, delta, lmda, ns, (double*)X_out, n);
@@ -486,14 +487,21 @@ int pxm_myula_step(const void* X, const void* gradg, const double* T, double T_s
   return 0;
 }
 
-int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const double* delta_dev, double delta,
-                   double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter,
-                   void* X_out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+int pxm_myula_step(const void* X, const void* gradg, const double* T, double T_scalar, const double* delta_dev,
+                   double delta, double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0,
+                   uint64_t iter, void* X_out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+  return pxm_myula_step_it(X, gradg, T, T_scalar, delta_dev, delta, lmda, noise, noise_complex, seed, chain0, iter, nullptr,
+                           X_out, n, C, dtype, stream);
+}
+
+int pxm_chain_step_it(const void* X, const void* proxf, const void* gradg, const double* delta_dev, double delta,
+                      double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter,
+                      const uint64_t* iter_dev, void* X_out, int64_t n, int C, int dtype, pxm_stream_t stream) {
   CHECK_ARGS("pxm_chain_step");
   PXM_REQUIRE(X && proxf && gradg && X_out, "pxm_chain_step: null buffer");
   PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_chain_step: complex noise needs a complex state");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter};
+  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, iter_dev};
   if (dtype)
     hipLaunchKernelGGL((k_chain_step<true, false>), g, b, 0, st, (const double*)X, (const double*)proxf,
                        (const double*)gradg, (const double*)nullptr, 0.0, delta_dev, delta, lmda, ns, (double*)X_out, n);
@@ -502,6 +510,13 @@ int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const do
                        (const double*)gradg, (const double*)nullptr, 0.0, delta_dev, delta, lmda, ns, (double*)X_out, n);
   PXM_HIP(hipGetLastError());
   return 0;
+}
+
+int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const double* delta_dev, double delta,
+                   double lmda, const void* noise, int noise_complex, uint64_t seed, uint64_t chain0, uint64_t iter,
+                   void* X_out, int64_t n, int C, int dtype, pxm_stream_t stream) {
+  return pxm_chain_step_it(X, proxf, gradg, delta_dev, delta, lmda, noise, noise_complex, seed, chain0, iter, nullptr, X_out,
+                           n, C, dtype, stream);
 }
 
 int pxm_randn(void* out, int64_t n, int C, int dtype, uint64_t seed, uint64_t chain0, uint64_t iter,

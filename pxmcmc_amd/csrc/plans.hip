@@ -389,6 +389,7 @@ struct pxm_wav_plan_s {
   hipStream_t side[NSIDE] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[NSIDE] = {nullptr, nullptr, nullptr};
   int nside = 2;
+  bool plain_group = true;  // blocks <-> rings of the member scales in one grid (PXM_NO_PLAIN_DFT_GROUP=1: per scale)
   std::vector<int> lane_of;  // per scale: -1 = caller's stream, else side stream index
   Dft3GroupList dft_group;   // every scale's rings -> X' -> rings kernel in one grid (ring-space step)
   // weak-lensing attachment (pxm_wav_wl_attach): spin-2 ring tables at L, their ring array, the harmonic kernel
@@ -469,6 +470,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   p->fused_combine = !getenv("PXM_NO_FUSED_COMBINE");
   p->fused_dft = !getenv("PXM_NO_FUSED_DFT");
   p->dft_small_first = !getenv("PXM_DFT_TOP_FIRST");
+  p->plain_group = !getenv("PXM_NO_PLAIN_DFT_GROUP");
   for (int s = 0; s < p->nsc; ++s) {
     p->offG.push_back(w); w += arr_size(p->bl[s], p->ncol);
     p->offH.push_back(w); w += arr_size(p->bl[s], p->ncol);
@@ -619,7 +621,8 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
     for (int s = 0; s < p->nsc; ++s) dp.push_back(&p->dft[s]);
     rc = dft5_group_create(dp, p->offG, p->coef_off, p->ncol, &p->dft_group);
     if (rc == 1) rc = dft3_group_create(dp, p->offG, p->coef_off, p->ncol, &p->dft_group);
-    if (rc < 0) return rc;  // rc == 1: some scale has no wave path -> per-scale launches
+    if (rc < 0) return rc;  // rc == 1: no group -> per-scale launches
+    if (p->dft_group.d && !p->dft_group.five) p->dft_group.all = true;  // (the dft3 group is all scales or nothing)
   }
   *plan = guard.release();
   return 0;
@@ -765,32 +768,72 @@ static inline hipStream_t wav_stream(pxm_wav_plan_t p, int s, hipStream_t st) {
 }
 
 // coefficient blocks -> G_s (scales' px2ring) ; G_s -> coefficient blocks (ring2px with optional fused update)
+// The member scales of the plan's DFT group go in ONE grid (dft5.hip: k_px2ring_group5 / k_ring2px_group5<false>); a
+// scale outside the group (band-limits above 256: four-wave kernels) keeps its own launch, on the calling stream
+// while the group runs on a side stream.
+static inline bool wav_in_group(pxm_wav_plan_t p, int s) {
+  return p->dft_group.d && p->dft_group.five && p->plain_group && p->dft_group.member[s];
+}
+// side stream 0 (made to wait for the fork event if no scale had claimed it), or the caller's stream without side streams
+static inline hipStream_t wav_group_stream(pxm_wav_plan_t p, hipStream_t st, bool used[pxm_wav_plan_s::NSIDE]) {
+  if (!p->ev_fork || !p->side[0]) return st;
+  if (!used[0]) {
+    used[0] = true;
+    (void)hipStreamWaitEvent(p->side[0], p->ev_fork, 0);
+  }
+  return p->side[0];
+}
+
 static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st, uint64_t* bump = nullptr) {
+  const bool grp = p->dft_group.d && p->dft_group.five && p->plain_group;
+  if (grp && p->dft_group.all) {  // every scale in the one grid: no side streams at all
+    PxIn in;
+    in.f = (const double*)X;
+    in.chain_stride = p->ncoefs;
+    in.bump = bump;
+    return dft5_group_px2ring(p->dft_group, p->ws, p->ncol, in, C, st);
+  }
   bool used[pxm_wav_plan_s::NSIDE];
   int rc = wav_fork(p, st, used);
   if (rc) return rc;
+  bool bumped = false;
   for (int s = p->nsc - 1; s >= 0; --s) {  // largest first
+    if (wav_in_group(p, s)) continue;
     PxIn in;
     in.f = (const double*)X;
     in.chain_stride = p->ncoefs;
     in.ring0 = p->coef_off[s];
-    if (s == p->nsc - 1) in.bump = bump;  // once per call, by a kernel that runs after every reader of the counter
-    rc = launch_px2ring(p->dft[s], in, p->ws + p->offG[s], p->ncol, C, wav_stream(p, s, st));
+    if (!bumped) in.bump = bump;  // once per call, by a kernel that runs after every reader of the counter
+    bumped = true;
+    rc = launch_px2ring(p->dft[s], in, p->ws + p->offG[s], p->ncol, C, grp ? st : wav_stream(p, s, st));
     if (rc) return rc;
+  }
+  if (grp) {
+    PxIn in;
+    in.f = (const double*)X;
+    in.chain_stride = p->ncoefs;
+    if (!bumped) in.bump = bump;
+    if ((rc = dft5_group_px2ring(p->dft_group, p->ws, p->ncol, in, C, wav_group_stream(p, st, used)))) return rc;
   }
   return wav_join(p, st, used);
 }
 
 static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
+  const bool grp = p->dft_group.d && p->dft_group.five && p->plain_group;
+  proto.chain_stride = p->ncoefs;
+  if (grp && p->dft_group.all) return dft5_group_ring2px(p->dft_group, p->ws, p->ncol, proto, C, st);
   bool used[pxm_wav_plan_s::NSIDE];
   int rc = wav_fork(p, st, used);
   if (rc) return rc;
   for (int s = p->nsc - 1; s >= 0; --s) {
+    if (wav_in_group(p, s)) continue;
     PxOut out = proto;
-    out.chain_stride = p->ncoefs;
     out.ring0 = p->coef_off[s];
-    rc = launch_ring2px(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, wav_stream(p, s, st));
+    rc = launch_ring2px(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, grp ? st : wav_stream(p, s, st));
     if (rc) return rc;
+  }
+  if (grp) {
+    if ((rc = dft5_group_ring2px(p->dft_group, p->ws, p->ncol, proto, C, wav_group_stream(p, st, used)))) return rc;
   }
   return wav_join(p, st, used);
 }
@@ -805,7 +848,7 @@ static bool wav_can_fuse_dft(pxm_wav_plan_t p) {
 }
 
 static int wav_rings_update_rings(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
-  if (p->dft_group.d) {  // one grid for every scale, small scales first
+  if (p->dft_group.d && p->dft_group.all) {  // one grid for every scale, small scales first
     proto.chain_stride = p->ncoefs;
     if (p->dft_group.five) return dft5_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof);
     return dft3_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof);

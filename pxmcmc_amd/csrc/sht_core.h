@@ -256,6 +256,8 @@ struct Dft3GroupList {
   int n = 0, blocks = 0;
   size_t lds = 0;
   double px_elems = 0;  // sum over scales of bl (2 bl - 1): coefficients per chain slot
+  std::vector<char> member;  // per scale: its rings <-> pixels launches are part of this group
+  bool all = false;          // every scale is a member (needed by the fused rings -> X' -> rings step)
 };
 int dft3_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
                       const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available
@@ -272,6 +274,9 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
                       const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available
 int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
                       Profiler* prof = nullptr);
+// the plain transforms of every member scale in one grid each (blocks <-> rings of the generic wavelet operators)
+int dft5_group_px2ring(const Dft3GroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st);
+int dft5_group_ring2px(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st);
 int dft6_make_tables(int n, Dft6Tables* t);
 int dft6_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft6_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);

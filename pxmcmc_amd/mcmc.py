@@ -235,6 +235,22 @@ class PxMCMC:
         return ops.as_device(w)
 
 
+class _DevCounter:
+    """caller-owned device iteration counter of the generic stepping engine (the fused engines use the plan's)"""
+
+    def __init__(self, start):
+        self.t = torch.full((1,), int(start), dtype=torch.int64, device=ops.device())
+
+    def set(self, v):
+        self.t.fill_(int(v))
+
+    def add(self, inc=1):
+        ops.counter_add(self.t, inc)
+
+    def close(self):
+        pass
+
+
 class MYULA(PxMCMC):
     """The MYULA chain (pxmcmc/mcmc.py:143-201)."""
 
@@ -329,13 +345,22 @@ class MYULA(PxMCMC):
     _GRAPH_PAIRS = 4  # iterations per graph replay = 2 * _GRAPH_PAIRS (fewer, longer launches of the host)
 
     def _graph_ok(self):
-        return self._fused_wav and self.rng == "philox" and self.use_graph
+        return (self._fused_wav or self._generic_engine_ok()) and self.rng == "philox" and self.use_graph
+
+    def _generic_engine_ok(self):
+        """Operators without a fused kernel path (PathIntegralOperator, the analysis setting, user plugins ...) step
+        through the same engine: calc_gradg / proxf / chain_step / forward on static buffers with the device Philox
+        counter, replayed from a HIP graph when the operators can be captured (eager stepping otherwise)."""
+        return (not self._fused_wav and self.rng == "philox" and self.use_graph and isinstance(self.delta, float)
+                and type(self).chain_step is MYULA.chain_step)
 
     def _engine_start(self, X, preds, i0):
         """Static ping-pong state (XA, XB, P), a device iteration counter and a captured graph of 2 * _GRAPH_PAIRS
         iterations."""
         self._engine_stop()  # an engine left over from an interrupted run gives its counter / buffers back first
         f = self.forward
+        if not self._fused_wav:
+            return self._engine_start_generic(X, preds, i0)
         plan = f.transform._plan
         data = f.data_dev_c128
         self._eng = eng = {}
@@ -361,6 +386,7 @@ class MYULA(PxMCMC):
             w = complex(d[0].item())
             plan.ring_set_data(data)
             plan.ring_init(eng["XA"])
+            eng["reset"] = lambda: plan.ring_init(eng["XA"])  # plan-carried state of (XA, P)
             eng["cnt0"] = lambda i: i - 1  # ring_step increments the counter before using it
             eng["cnt"].set(eng["cnt0"](i0))
 
@@ -370,6 +396,7 @@ class MYULA(PxMCMC):
                 eng["P_valid"] = False
         else:
             plan.image_init(eng["P"], data, f.invcov.diag)  # residual rings of the start state, carried by the plan
+            eng["reset"] = lambda: plan.image_init(eng["P"], data, f.invcov.diag)
 
             def one(src, dst):
                 # calc_gradg + proxf + chain_step + forward of the new state (preds written in place)
@@ -377,23 +404,52 @@ class MYULA(PxMCMC):
                 eng["cnt"].add(1)
 
         eng["one"] = one
+        self._engine_capture(eng, X, preds, i0)
+        return eng
+
+    def _engine_start_generic(self, X, preds, i0):
+        """The engine for operators without a fused path: one iteration = the reference's four calls
+        (pxmcmc/mcmc.py:158-163) on static buffers; the noise kernels read the iteration number from a device counter."""
+        f = self.forward
+        self._eng = eng = {"pairs": False, "plan": None, "ring": False, "P_valid": True, "side": "A", "generic": True}
+        X = ops.as_device(X).contiguous()
+        eng["XA"], eng["XB"], eng["P"] = X.clone(), torch.empty_like(X), ops.as_device(preds).clone()
+        eng["cnt"] = _DevCounter(i0)
+        eng["cnt0"] = lambda i: i
+        eng["reset"] = lambda: None
+        kw = dict(noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=0, iter_dev=eng["cnt"].t)
+        delta, lmda = float(self.delta), self.lmda
+
+        def one(src, dst):
+            gradg = ops.as_device(f.calc_gradg(eng["P"]), src.dtype)
+            if self._fused_prox:
+                ops.myula_step(src, gradg, self.prior.T_dev, delta, lmda, out=dst, **kw)
+            else:
+                proxf = ops.as_device(self.prior.proxf(src), src.dtype)
+                ops.chain_step(src, proxf, gradg, delta, lmda, out=dst, **kw)
+            eng["P"].copy_(ops.as_device(f.forward(dst)))
+            eng["cnt"].add(1)
+
+        eng["one"] = one
+        self._engine_capture(eng, X, preds, i0)
+        return eng
+
+    def _engine_capture(self, eng, X, preds, i0):
+        """capture the two graphs of an engine (2 and 2 * _GRAPH_PAIRS iterations); state is (X, preds, i0) afterwards"""
         eng["graph"] = eng["graph_long"] = None
         if self._graph_ok():
             try:
                 stream = torch.cuda.Stream()
                 stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(stream):
-                    one(eng["XA"], eng["XB"])  # warm-up outside capture (lazy allocations, attributes)
-                    one(eng["XB"], eng["XA"])
+                    eng["one"](eng["XA"], eng["XB"])  # warm-up outside capture (lazy allocations, attributes)
+                    eng["one"](eng["XB"], eng["XA"])
                 torch.cuda.current_stream().wait_stream(stream)
                 torch.cuda.synchronize()
                 eng["XA"].copy_(X)
                 eng["P"].copy_(preds)
                 eng["cnt"].set(eng["cnt0"](i0))
-                if eng["ring"]:
-                    plan.ring_init(eng["XA"])
-                else:
-                    plan.image_init(eng["P"], data, f.invcov.diag)
+                eng["reset"]()
                 # two graphs: 2 iterations (short advances between observable events) and 2 * _GRAPH_PAIRS
                 # iterations (long advances: fewer launches by the host).  A plan torn down while a capture is in
                 # progress (the garbage collector may run at any point) only queues its device frees: the
@@ -403,8 +459,8 @@ class MYULA(PxMCMC):
                     g = torch.cuda.CUDAGraph()
                     with ops.capture_scope(), torch.cuda.graph(g):
                         for _ in range(pairs):
-                            one(eng["XA"], eng["XB"])
-                            one(eng["XB"], eng["XA"])
+                            eng["one"](eng["XA"], eng["XB"])
+                            eng["one"](eng["XB"], eng["XA"])
                     graphs.append(g)
                 # capture does not execute: state is still (X, preds, i0)
                 eng["graph"], eng["graph_long"] = graphs
@@ -414,11 +470,7 @@ class MYULA(PxMCMC):
                 eng["XA"].copy_(X)
                 eng["P"].copy_(preds)
                 eng["cnt"].set(eng["cnt0"](i0))
-                if eng["ring"]:
-                    plan.ring_init(eng["XA"])
-                else:
-                    plan.image_init(eng["P"], data, f.invcov.diag)
-        return eng
+                eng["reset"]()
 
     def _engine_advance(self, k):
         """advance the engine's state by k MYULA iterations (graph replays of 2 * _GRAPH_PAIRS + eager remainder)"""
@@ -463,7 +515,7 @@ class MYULA(PxMCMC):
         if eng is not None and eng.get("cnt") is not None:
             eng["cnt"].close()
             eng["graph"] = eng["graph"] is not None  # keep the flags (ring, pairs, graph) for inspection
-            for k in ("one", "XA", "XB", "P", "plan", "cnt", "cnt0", "graph_long"):
+            for k in ("one", "XA", "XB", "P", "plan", "cnt", "cnt0", "graph_long", "reset"):
                 eng[k] = None
 
     def run(self, start_point=None):
@@ -474,7 +526,7 @@ class MYULA(PxMCMC):
         X_curr, curr_preds = self._initial_sample(start_point)
         if self._pairs_ok(X_curr):
             self._pairs_start()
-        if self._fused_wav and self.rng == "philox":
+        if self.rng == "philox" and (self._fused_wav or self._generic_engine_ok()):
             return self._run_engine(X_curr, curr_preds)
         if self._pairs:
             X_curr, curr_preds = self._pack(X_curr), self._pack(curr_preds)

@@ -129,8 +129,9 @@ def _noise_args(noise, x, noise_complex):
     return w, int(w.is_complex())
 
 
-def myula_step(X, gradg, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0):
-    """chain_step(X, soft(X, T), gradg) in one pass (pxmcmc/mcmc.py:185-201 + prior.py:49-50)."""
+def myula_step(X, gradg, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None, out=None):
+    """chain_step(X, soft(X, T), gradg) in one pass (pxmcmc/mcmc.py:185-201 + prior.py:49-50).
+    iter_dev: int64 device counter added to ``it`` when the kernel runs (graph replay); out: result buffer."""
     x, squeeze = _batched(as_device(X))
     g, _ = _batched(as_device(gradg, x.dtype))
     if g.shape != x.shape:
@@ -138,17 +139,25 @@ def myula_step(X, gradg, T, delta, lmda, noise=None, noise_complex=False, seed=0
     Tv, Ts = _vecT(T, x.shape[1], x.device)
     dd, ds = _delta_args(delta, x.shape[0], x.device)
     w, wc = _noise_args(noise, x, noise_complex)
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if out is None else _out_like(out, x)
     check(
-        lib.pxm_myula_step(
-            _p(x), _p(g), _p(Tv), Ts, _p(dd), ds, float(lmda), _p(w), wc, seed, chain0, it, _p(out), x.shape[1], x.shape[0], _dt(x), _stream()
+        lib.pxm_myula_step_it(
+            _p(x), _p(g), _p(Tv), Ts, _p(dd), ds, float(lmda), _p(w), wc, seed, chain0, it, _p(iter_dev), _p(out), x.shape[1],
+            x.shape[0], _dt(x), _stream()
         )
     )
     return out[0] if squeeze else out
 
 
-def chain_step(X, proxf, gradg, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0):
-    """MYULA.chain_step (pxmcmc/mcmc.py:185-201)."""
+def _out_like(out, x):
+    o = out if out.dim() == 2 else out.unsqueeze(0)
+    if o.shape != x.shape or o.dtype != x.dtype or not o.is_contiguous() or o.device != x.device:
+        raise ValueError("out must be a contiguous device array of the state's shape and dtype")
+    return o
+
+
+def chain_step(X, proxf, gradg, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None, out=None):
+    """MYULA.chain_step (pxmcmc/mcmc.py:185-201); iter_dev / out as in :func:`myula_step`."""
     x, squeeze = _batched(as_device(X))
     px, _ = _batched(as_device(proxf, x.dtype))
     g, _ = _batched(as_device(gradg, x.dtype))
@@ -156,10 +165,11 @@ def chain_step(X, proxf, gradg, delta, lmda, noise=None, noise_complex=False, se
         raise ValueError("shape mismatch")
     dd, ds = _delta_args(delta, x.shape[0], x.device)
     w, wc = _noise_args(noise, x, noise_complex)
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if out is None else _out_like(out, x)
     check(
-        lib.pxm_chain_step(
-            _p(x), _p(px), _p(g), _p(dd), ds, float(lmda), _p(w), wc, seed, chain0, it, _p(out), x.shape[1], x.shape[0], _dt(x), _stream()
+        lib.pxm_chain_step_it(
+            _p(x), _p(px), _p(g), _p(dd), ds, float(lmda), _p(w), wc, seed, chain0, it, _p(iter_dev), _p(out), x.shape[1],
+            x.shape[0], _dt(x), _stream()
         )
     )
     return out[0] if squeeze else out

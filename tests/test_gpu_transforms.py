@@ -240,3 +240,30 @@ def test_gemm_task_orders_are_bit_identical(monkeypatch):
     for order in ("xcd", "plain"):
         for a, b in zip(outs["bins"], outs[order]):
             assert torch.equal(torch.view_as_real(a) if a.is_complex() else a, torch.view_as_real(b) if b.is_complex() else b), order
+
+
+@pytest.mark.parametrize("L,B", [(20, 2), (28, 1.5), (64, 2)])
+def test_grouped_plain_dft_launches_match_per_scale_launches(L, B, monkeypatch):
+    """The blocks <-> rings transforms of every member scale run in one grid each (k_px2ring_group5,
+    k_ring2px_group5<false>); PXM_NO_PLAIN_DFT_GROUP=1 keeps one launch per scale.  Same bodies, same numbers: all four
+    wavelet operators agree bit for bit, for a full and a partly filled chain batch."""
+    import torch
+
+    from pxmcmc_amd import ops
+
+    outs = []
+    for env in ({}, {"PXM_NO_PLAIN_DFT_GROUP": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        wav = ops.WavPlan(L, B, 2, max_chains=5)
+        for k in env:
+            monkeypatch.delenv(k)
+        res = []
+        for C in (5, 2):
+            g = torch.Generator().manual_seed(L + C)
+            X = torch.randn(C, wav.ncoefs, dtype=torch.complex128, generator=g).cuda()
+            f = torch.randn(C, wav.npix, dtype=torch.complex128, generator=g).cuda()
+            res += [wav.synthesis(X).cpu(), wav.synthesis_adjoint(f).cpu(), wav.analysis(f).cpu(), wav.analysis_adjoint(X).cpu()]
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
