@@ -2,8 +2,8 @@
 // Hermitian transpose (stored as its own CSR, like the reference's path_matrix.getH()).
 //   y[c][row] = sum_k val[k] * x[c][col[k]],  k in [indptr[row], indptr[row+1])
 // HBM-bound gather: one wave per row, lanes stride over the row's non-zeros (coalesced index / value
-// reads), fixed-shape butterfly reduction -> deterministic sums.  The chain batch re-reads the row's
-// indices and values from cache, only the gathered x differs per chain.
+// reads), fixed-shape butterfly reduction -> deterministic sums.  The chain batch is carried in register blocks
+// (4 complex / 8 real chains per traversal of the row).
 #include "../../include/pxmcmc_amd.h"
 #include "common.h"
 #include "elem.h"
@@ -16,7 +16,54 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// VC: complex values, XC: complex vectors (VC implies XC)
+// VC: complex values, XC: complex vectors (VC implies XC).  CB chains are carried together: one pass over the row's
+// indices and values, CB independent gathers in flight per non-zero, CB (x2) butterfly sums at the end -- the chain
+// batch costs one row traversal per CB chains instead of one per chain.
+template <bool VC, bool XC, int CB>
+__device__ __forceinline__ void csr_row_block(const int32_t* __restrict__ indices, const double* __restrict__ vals,
+                                              const double* __restrict__ x, double* __restrict__ y, int64_t beg, int64_t end,
+                                              int64_t row, int64_t nrows, int64_t ncols, int c0, int lane) {
+  double sr[CB], si[CB];
+#pragma unroll
+  for (int u = 0; u < CB; ++u) sr[u] = si[u] = 0.0;
+  for (int64_t k = beg + lane; k < end; k += 64) {
+    const int64_t col = indices[k];
+    double ar, ai = 0.0;
+    if (VC) {
+      const double2 a = reinterpret_cast<const double2*>(vals)[k];
+      ar = a.x;
+      ai = a.y;
+    } else ar = vals[k];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      if (XC) {
+        const double2 xv = reinterpret_cast<const double2*>(x)[(int64_t)(c0 + u) * ncols + col];
+        if (VC) {
+          sr[u] += ar * xv.x - ai * xv.y;
+          si[u] += ar * xv.y + ai * xv.x;
+        } else {
+          sr[u] += ar * xv.x;
+          si[u] += ar * xv.y;
+        }
+      } else {
+        sr[u] += ar * x[(int64_t)(c0 + u) * ncols + col];
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < CB; ++u) {
+    sr[u] = wave_sum(sr[u]);
+    if (XC) si[u] = wave_sum(si[u]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int u = 0; u < CB; ++u) {
+      if (XC) reinterpret_cast<double2*>(y)[(int64_t)(c0 + u) * nrows + row] = double2{sr[u], si[u]};
+      else y[(int64_t)(c0 + u) * nrows + row] = sr[u];
+    }
+  }
+}
+
 template <bool VC, bool XC>
 __global__ __launch_bounds__(256) void k_csr_matvec(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                     const double* __restrict__ vals, const double* __restrict__ x,
@@ -24,34 +71,27 @@ __global__ __launch_bounds__(256) void k_csr_matvec(const int64_t* __restrict__ 
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  constexpr int CBMAX = XC ? 4 : 8;  // chains per pass (register budget: 2 accumulators per complex chain)
+  // blockIdx.y: chain super-block (so that few rows x many chains still fill the chip)
+  const int cpb = (C + gridDim.y - 1) / gridDim.y;
+  const int cbeg = blockIdx.y * cpb, cend = min(C, cbeg + cpb);
   for (int64_t row = wave0; row < nrows; row += nwaves) {
     const int64_t beg = indptr[row], end = indptr[row + 1];
-    for (int c = 0; c < C; ++c) {
-      double sr = 0.0, si = 0.0;
-      for (int64_t k = beg + lane; k < end; k += 64) {
-        const int64_t col = indices[k];
-        if (XC) {
-          const double2 xv = reinterpret_cast<const double2*>(x)[(int64_t)c * ncols + col];
-          if (VC) {
-            const double2 a = reinterpret_cast<const double2*>(vals)[k];
-            sr += a.x * xv.x - a.y * xv.y;
-            si += a.x * xv.y + a.y * xv.x;
-          } else {
-            const double a = vals[k];
-            sr += a * xv.x;
-            si += a * xv.y;
-          }
-        } else {
-          sr += vals[k] * x[(int64_t)c * ncols + col];
-        }
-      }
-      sr = wave_sum(sr);
-      if (XC) si = wave_sum(si);
-      if (lane == 0) {
-        if (XC) reinterpret_cast<double2*>(y)[(int64_t)c * nrows + row] = double2{sr, si};
-        else y[(int64_t)c * nrows + row] = sr;
-      }
+    int c = cbeg;
+    for (; c + CBMAX <= cend; c += CBMAX) csr_row_block<VC, XC, CBMAX>(indices, vals, x, y, beg, end, row, nrows, ncols, c, lane);
+    if (CBMAX >= 8 && c + 4 <= cend) {
+      csr_row_block<VC, XC, 4>(indices, vals, x, y, beg, end, row, nrows, ncols, c, lane);
+      c += 4;
     }
+    if (c + 2 <= cend) {
+      csr_row_block<VC, XC, 2>(indices, vals, x, y, beg, end, row, nrows, ncols, c, lane);
+      c += 2;
+    }
+    if (c + 2 <= cend) {  // (CBMAX = 4: up to three chains are left after the blocks of four)
+      csr_row_block<VC, XC, 2>(indices, vals, x, y, beg, end, row, nrows, ncols, c, lane);
+      c += 2;
+    }
+    if (c < cend) csr_row_block<VC, XC, 1>(indices, vals, x, y, beg, end, row, nrows, ncols, c, lane);
   }
 }
 
@@ -71,13 +111,18 @@ extern "C" int pxm_csr_matvec(const int64_t* indptr, const int32_t* indices, con
   const int waves_per_block = 4;
   int64_t blocks = (nrows + waves_per_block - 1) / waves_per_block;
   if (blocks > 16384) blocks = 16384;
+  // chain super-blocks: when the rows alone do not fill the chip (256 CUs x 8 workgroups), split the batch over grid.y
+  // in multiples of the register block, otherwise every wave carries the whole batch of its rows
+  const int cbmax = dtype ? 4 : 8;
+  int ysplit = 1;
+  while (blocks * ysplit < 2048 && (C + ysplit) / (ysplit + 1) >= cbmax) ++ysplit;
   hipStream_t st = (hipStream_t)stream;
   const double* v = (const double*)vals;
   const double* xv = (const double*)x;
   double* yv = (double*)y;
-  if (dtype == 0) hipLaunchKernelGGL((k_csr_matvec<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, indptr, indices, v, xv, yv, nrows, ncols, C);
-  else if (!vals_complex) hipLaunchKernelGGL((k_csr_matvec<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, indptr, indices, v, xv, yv, nrows, ncols, C);
-  else hipLaunchKernelGGL((k_csr_matvec<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, indptr, indices, v, xv, yv, nrows, ncols, C);
+  if (dtype == 0) hipLaunchKernelGGL((k_csr_matvec<false, false>), dim3((unsigned)blocks, (unsigned)ysplit), dim3(256), 0, st, indptr, indices, v, xv, yv, nrows, ncols, C);
+  else if (!vals_complex) hipLaunchKernelGGL((k_csr_matvec<false, true>), dim3((unsigned)blocks, (unsigned)ysplit), dim3(256), 0, st, indptr, indices, v, xv, yv, nrows, ncols, C);
+  else hipLaunchKernelGGL((k_csr_matvec<true, true>), dim3((unsigned)blocks, (unsigned)ysplit), dim3(256), 0, st, indptr, indices, v, xv, yv, nrows, ncols, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }
