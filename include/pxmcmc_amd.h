@@ -298,6 +298,12 @@ int pxm_wl_mask_scatter(const void* g, const int64_t* idx, const double* w, void
  * complex128 iff vals_complex; x: [C][ncols], y: [C][nrows], float64 (dtype 0) or complex128 (dtype 1). */
 int pxm_csr_matvec(const int64_t* indptr, const int32_t* indices, const void* vals, int vals_complex,
                    int64_t nrows, int64_t ncols, const void* x, void* y, int C, int dtype, pxm_stream_t stream);
+/* The same product for a chain batch, through a caller-owned scratch of ncols * C elements of x's type: the operand is
+ * first copied chain-minor ([ncols][C]) so that a gathered non-zero reads its C chains from one contiguous segment
+ * instead of C cache lines.  Identical sums in identical order (bit-equal results); scratch NULL = pxm_csr_matvec. */
+int pxm_csr_matvec_batched(const int64_t* indptr, const int32_t* indices, const void* vals, int vals_complex,
+                           int64_t nrows, int64_t ncols, const void* x, void* y, int C, int dtype, void* scratch,
+                           pxm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,7 @@ SIGNATURES = {
     "pxm_wl_mask_gather": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp]),
     "pxm_wl_mask_scatter": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp]),
     "pxm_csr_matvec": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_int, c_int, c_vp]),
+    "pxm_csr_matvec_batched": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, c_i64, c_vp, c_vp, c_int, c_int, c_vp, c_vp]),
 }
 
 

@@ -332,8 +332,10 @@ class CsrMatrix:
         if x.shape[1] != self.shape[1]:
             raise AssertionError(f"expected length {self.shape[1]}, got {x.shape[1]}")
         out = torch.empty((x.shape[0], self.shape[0]), dtype=x.dtype, device=x.device)
-        check(lib.pxm_csr_matvec(_p(self.indptr), _p(self.indices), _p(self.vals), int(self.is_complex), self.shape[0],
-                                 self.shape[1], _p(x), _p(out), x.shape[0], _dt(x), _stream()))
+        # chain batches gather from a chain-minor copy of the operand (caller-owned scratch, stream-ordered reuse)
+        scratch = torch.empty(x.numel(), dtype=x.dtype, device=x.device) if x.shape[0] > 1 else None
+        check(lib.pxm_csr_matvec_batched(_p(self.indptr), _p(self.indices), _p(self.vals), int(self.is_complex), self.shape[0],
+                                         self.shape[1], _p(x), _p(out), x.shape[0], _dt(x), _p(scratch), _stream()))
         return out[0] if squeeze else out
 
 

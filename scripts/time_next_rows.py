@@ -24,13 +24,7 @@ def timed(s, **kw):
     return time.perf_counter() - t0
 
 
-def paths(npaths, npix, nnz_per_path, seed):
-    """great-circle-like rows: nnz_per_path pixels each, positive weights (synthetic stand-in for get_path_matrix)"""
-    rng = np.random.default_rng(seed)
-    cols = rng.integers(0, npix, size=(npaths, nnz_per_path))
-    vals = rng.random((npaths, nnz_per_path)) * 0.01
-    rows = np.repeat(np.arange(npaths), nnz_per_path)
-    return sp.csr_matrix((vals.ravel(), (rows, cols.ravel())), shape=(npaths, npix))
+from time_next_rows_common import paths
 
 
 rng = np.random.default_rng(0)
