@@ -47,6 +47,14 @@ constexpr int KC = 16;  // contraction rows per staged chunk
 #else
 #define PXM_GEMM_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B, ACC, 0, 0, 0);
 #endif
+#ifdef PXM_GEMM_TRACE
+// development build only: per-workgroup timeline (start / end clock, placement, task shape) of every launch into a
+// caller-provided buffer [8 words per record], records appended through an atomic cursor in word 0
+__device__ unsigned long long* g_gemm_trace = nullptr;
+extern "C" int pxm_debug_set_gemm_trace(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int CT, int NSLAB, int NW, int RT, int NSET>
 __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict__ tasks,
                                                       const double* __restrict__ X, double* __restrict__ Y,
@@ -63,6 +71,10 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   const int tid = threadIdx.x, lane = tid & 63;
   if (aff.bump && blockIdx.x == 0 && tid == 0) *aff.bump += 1;  // Philox iteration counter of the ring-space step
   if (t.n_rt == 0) return;  // padding entry of the XCD-queue order (plans.hip: upload_tasks)
+#ifdef PXM_GEMM_TRACE
+  const unsigned long long trace_t0 = wall_clock64();
+  unsigned long long trace_t1 = 0, trace_t2 = 0;
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the row-tile tests scalar
   const int kq = lane >> 4, cl = lane & 15;
   const int n_my = min(RT, max(0, t.n_rt - RT * wave));       // row tiles of this wave
@@ -166,6 +178,9 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
 #if !(PXM_GEMM_ABLATE & 4)
         __syncthreads();
 #endif
+#ifdef PXM_GEMM_TRACE
+        if (ch == 0) trace_t1 = wall_clock64();  // first chunk staged: task fetch + first operand loads are behind us
+#endif
         if (v0) {
 #define PXM_MFMA_CHUNK(NC)                                                                                     \
   _Pragma("unroll") for (int h4 = 0; h4 < 4; ++h4) {                                                           \
@@ -186,8 +201,29 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
 #undef PXM_STAGE_LOAD
 #undef PXM_STAGE_STORE
 #undef PXM_TAB_LOAD
+#ifdef PXM_GEMM_TRACE
+  trace_t2 = wall_clock64();  // contraction done (the last MFMAs may still be in flight)
+#endif
 
-  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg.
+  // Epilogue operands first -- the per-row data term of the Gram step and the per-row scale of the fused combine --
+  // ALL loads in flight together, then the arithmetic and the stores: one memory latency instead of one per output
+  // row (a per-workgroup timeline of the Gram launch showed 5-8 us of its 10-23 us in serial epilogue loads).
+  constexpr int NGRP = NSLAB >= 4 ? 2 : 1;
+  double hdv[RT][NSLAB][4], rsv[RT][NGRP][4];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int rowb = t.row0 + 16 * (RT * wave + (r < n_my ? r : 0)) + kq;  // (rows of a tile this wave does not own: tile 0, discarded)
+#pragma unroll
+    for (int sl = 0; sl < NSLAB; ++sl)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        hdv[r][sl][q] = (aff.on && t.hd_off[sl]) ? (X + t.hd_off[sl])[(int64_t)(rowb + 4 * q) * ncol + (cl & 1)] : 0.0;
+#pragma unroll
+    for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rsv[r][g][q] = t.rs_off[g] ? (X + t.rs_off[g])[rowb + 4 * q] : 1.0;
+  }
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
     if (r >= n_my) continue;
@@ -203,8 +239,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
         const int row = rowb + 4 * q;
         double v = acc[r][c][q];
         if (aff.on) {  // out = w * (ns * acc - hd[row]), complex per chain: (re, im) sit in adjacent lanes
-          const double hdv = (X + t.hd_off[slab])[(int64_t)row * ncol + (cl & 1)];
-          const double u = aff.ns * v - hdv;
+          const double u = aff.ns * v - hdv[r][slab][q];
           int lo = __double2loint(u), hi = __double2hiint(u);
           lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]: partner lane
           hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true);
@@ -212,13 +247,23 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
           v = (cl & 1) ? (aff.wr * u + aff.wi * pu) : (aff.wr * u - aff.wi * pu);
           if (col0 + cin + cl >= aff.ncol_live) v = 0.0;  // padding chains stay at zero (they have no prox / damping)
         }
-        if (row >= t.row_lo[grp] && row < t.row_hi[grp]) {
-          const double rs = t.rs_off[grp] ? (X + t.rs_off[grp])[row] : 1.0;
-          yb[(int64_t)(4 * q) * ncol] = sgn * rs * v;
-        }
+        if (row >= t.row_lo[grp] && row < t.row_hi[grp]) yb[(int64_t)(4 * q) * ncol] = sgn * rsv[r][grp][q] * v;
       }
     }
   }
+#ifdef PXM_GEMM_TRACE
+  __syncthreads();
+  if (tid == 0 && g_gemm_trace) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned long long slot = atomicAdd(g_gemm_trace, 1ull);
+    unsigned long long* r = g_gemm_trace + 8 + 8 * slot;
+    r[0] = blockIdx.x; r[1] = gridDim.x; r[2] = trace_t0; r[3] = wall_clock64();
+    r[4] = ((unsigned long long)(xcc & 0xf) << 32) | hw; r[5] = (unsigned long long)nch | ((unsigned long long)t.n_rt << 16) | ((unsigned long long)aff.on << 32);
+    r[6] = trace_t1; r[7] = trace_t2;
+  }
+#endif
 }
 
 // ---- live profiler: event pairs around GEMM / grouped-DFT launches, owned by a plan ----------------
