@@ -376,11 +376,21 @@ __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in,
 
 // rings -> pixels (inverse DFT by conjugation) with out's epilogue; RING_OUT: the written ring is transformed
 // again and its rings go back IN PLACE over G (rings of S X -> X' and the rings of X' in one kernel).
+#ifdef PXM_D5_TRACE
+__device__ unsigned long long* g_dft_trace = nullptr;
+#define PXM_D5_STAMP(K) d5_stamp[K] = wall_clock64();
+#else
+#define PXM_D5_STAMP(K)
+#endif
 template <int R0, bool RING_OUT>
 __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restrict__ G, int ncol, const PxOut& out, int C,
                                               int bx, int by, double2* lds5) {
   // chain groups without a live chain do nothing (see run_tasks / GemmAffine::ncol_live: nothing iterates on them)
   if ((by << a.lgR) >= C) return;
+#ifdef PXM_D5_TRACE
+  unsigned long long d5_stamp[4] = {0, 0, 0, 0};
+  const unsigned long long d5_t0 = wall_clock64();
+#endif
   PXM_D5_GEOMETRY
   {  // rings of the workgroup -> stage; thread -> (chain rr, k), k advances by threads / R: no integer division
     const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;
@@ -409,6 +419,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
     }
   }
   __syncthreads();
+  PXM_D5_STAMP(0)  // rings staged
   double2 x[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
@@ -417,6 +428,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
   }
   __syncthreads();
   PXM_D5_TRANSFORM(0)
+  PXM_D5_STAMP(1)  // inverse transform done
   const bool act = ch < C && tv;
   const int64_t e0 = out.ring0 + (int64_t)t * n + jb + (int64_t)(8 * R0) * pb;  // the wave's first element; u advances by 8 r0
   const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
@@ -477,12 +489,23 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
     for (int p = 0; p < P1; ++p) x[p] = double2{0.0, 0.0};  // padding chains / rings: their rings are kept at zero
   }
   if (!RING_OUT) return;
+  PXM_D5_STAMP(2)  // prox + update + noise done
   // ---- forward transform of the updated ring
   d5_exchange_fill<1>(x, plane, pplane, lane, half);  // both waves of the ring set need all 8 elements
   __syncthreads();                                    // ... and every exchange read is done before the planes are reused
   PXM_D5_TRANSFORM(0)
+  PXM_D5_STAMP(3)  // forward transform done
   PXM_D5_TO_STAGE
   PXM_D5_STORE_RINGS(false)
+#ifdef PXM_D5_TRACE
+  __syncthreads();
+  if (threadIdx.x == 0 && g_dft_trace) {
+    const unsigned long long slot = atomicAdd(g_dft_trace + 1, 1ull);
+    unsigned long long* rr_ = g_dft_trace + 8 + 8 * 4096 + 8 * slot;  // phase records behind the workgroup records
+    rr_[0] = R0; rr_[1] = d5_stamp[0] - d5_t0; rr_[2] = d5_stamp[1] - d5_t0; rr_[3] = d5_stamp[2] - d5_t0;
+    rr_[4] = d5_stamp[3] - d5_t0; rr_[5] = wall_clock64() - d5_t0; rr_[6] = bx; rr_[7] = by;
+  }
+#endif
 }
 
 template <int R0>
@@ -518,11 +541,20 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px5(Dft5Args a, doubl
 // Grouped launch of the ring-space step: the rings -> X' -> rings bodies (RING_OUT) of EVERY scale of a wavelet plan
 // in one grid, largest scales first (their workgroups are the long ones; the small scales fill the tail); without
 // RING_OUT the plain rings -> pixels transform of every member scale (generic synthesis / adjoint operators).
+#ifdef PXM_D5_TRACE
+// development build only: per-workgroup timeline of the grouped launches (see sht_gemm.hip: PXM_GEMM_TRACE)
+extern "C" int pxm_debug_set_dft_trace(unsigned long long* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_dft_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <bool RING_OUT>
 __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5Group* __restrict__ ents, int nent,
                                                                                        double* __restrict__ ws, int ncol, PxOut out,
                                                                                        int C) {
   extern __shared__ double2 lds5[];
+#ifdef PXM_D5_TRACE
+  const unsigned long long trace_t0 = wall_clock64();
+#endif
   PXM_D5_GROUP_DECODE
   out.ring0 = g.ring0;
   switch (g.r0) {
@@ -531,6 +563,17 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5G
     case 2: ring2px_body5<2, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
     default: ring2px_body5<1, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
   }
+#ifdef PXM_D5_TRACE
+  if (threadIdx.x == 0 && g_dft_trace) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const unsigned long long slot = atomicAdd(g_dft_trace, 1ull);
+    unsigned long long* r = g_dft_trace + 8 + 8 * slot;
+    r[0] = blockIdx.x; r[1] = gridDim.x; r[2] = trace_t0; r[3] = wall_clock64();
+    r[4] = ((unsigned long long)(xcc & 0xf) << 32) | hw; r[5] = g.r0; r[6] = e; r[7] = by;
+  }
+#endif
 }
 
 // pixels -> rings of every member scale in one grid

@@ -35,8 +35,46 @@ s._engine_start(X, preds, 0)
 s._engine_advance(40)
 torch.cuda.synchronize()
 
-NREC = 8192
+NREC = 8192  # (DFT trace: workgroup records in the first 4096 slots, phase records behind them)
 buf = torch.zeros(8 + 8 * NREC, dtype=torch.int64, device="cuda")
+if os.environ.get("TRACE") == "dft":  # grouped DFT kernel instead (-DPXM_D5_TRACE build)
+    fn = lib.pxm_debug_set_dft_trace
+    fn.argtypes = [C.c_void_p]
+    assert fn(C.c_void_p(buf.data_ptr())) == 0
+    s._engine_advance(2)
+    torch.cuda.synchronize()
+    buf.zero_()
+    s._engine_advance(1)
+    torch.cuda.synchronize()
+    h = buf.cpu().numpy().astype(np.uint64)
+    n = int(h[0])
+    a = h[8:8 + 8 * n].reshape(n, 8).astype(np.int64)
+    t0, t1 = a[:, 2].min(), a[:, 3].max()
+    dur, start, ends = (a[:, 3] - a[:, 2]) / 100.0, (a[:, 2] - t0) / 100.0, (a[:, 3] - t0) / 100.0
+    hw, xcc = a[:, 4] & 0xffffffff, a[:, 4] >> 32
+    cu = ((xcc * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xf)
+    print(f"k_ring2px_group5: {n} workgroups recorded (grid {int(a[0, 1])}), span {(t1 - t0) / 100.0:.1f} us, CUs used {len(set(cu.tolist()))}")
+    print("  scale entry (r0): workgroups, duration us min / median / max, start median / max, end median / max")
+    for e in sorted(set(a[:, 6].tolist())):
+        sel = a[:, 6] == e
+        print(f"  entry {e} (r0={int(a[sel, 5][0])}): {int(sel.sum()):5d}  {dur[sel].min():5.1f} / {np.median(dur[sel]):5.1f} / {dur[sel].max():5.1f}"
+              f"   start {np.median(start[sel]):5.1f} / {start[sel].max():5.1f}   end {np.median(ends[sel]):5.1f} / {ends[sel].max():5.1f}")
+    busy = collections.defaultdict(float)
+    for c_, d_ in zip(cu.tolist(), dur.tolist()):
+        busy[c_] += d_
+    b = np.array(list(busy.values()))
+    print(f"  workgroup-time per CU: min {b.min():.0f} / median {np.median(b):.0f} / max {b.max():.0f} us (2 workgroups resident per CU: "
+          f"ideal span = total / (2 x 256) = {dur.sum() / 512:.1f} us)")
+    for q in (50, 75, 90, 95, 99, 100):
+        print(f"  {q:3d} % of the workgroups have finished by {np.percentile(ends, q):5.1f} us")
+    m = int(h[1])
+    ph = h[8 + 8 * 4096:8 + 8 * 4096 + 8 * m].reshape(m, 8).astype(np.int64)
+    print(f"  phases (us from workgroup start; median over {m} workgroups): r0: rings staged / inverse transform / update / forward transform / rings stored")
+    for r0 in sorted(set(ph[:, 0].tolist())):
+        q = ph[ph[:, 0] == r0]
+        med = np.median(q[:, 1:6], axis=0) / 100.0
+        print(f"    r0={r0}: " + " / ".join(f"{v:5.1f}" for v in med) + f"   ({len(q)} workgroups)")
+    sys.exit(0)
 fn = lib.pxm_debug_set_gemm_trace  # (only in a -DPXM_GEMM_TRACE build)
 fn.argtypes = [C.c_void_p]
 assert fn(C.c_void_p(buf.data_ptr())) == 0
