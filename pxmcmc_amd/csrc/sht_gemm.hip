@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   double hdv[RT][NSLAB][4], rsv[RT][NGRP][4];
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
-    const int rowb = t.row0 + 16 * (RT * wave + (r < n_my ? r : 0)) + kq;  // (rows of a tile this wave does not own: tile 0, discarded)
+    const int rowb = t.row0 + 16 * (r < n_my ? RT * wave + r : 0) + kq;  // (a tile this wave does not own: the task's tile 0 -- valid rows, values discarded)
 #pragma unroll
     for (int sl = 0; sl < NSLAB; ++sl)
 #pragma unroll
