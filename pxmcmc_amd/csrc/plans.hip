@@ -24,6 +24,7 @@ struct TaskList {
   int merged = -1;       // index i: transforms i and i+1 share one pass over their table (counted once)
   double mfma_units = 0; // sum over tasks of row tiles x k-steps x slabs: MFMAs per column tile
   bool gram = false;     // Gram launch: table sum_m (L-m)^2 entries, harmonic side read and written
+  int flags = 0;         // bit 0: tasks sum a second operand in while staging; bit 1: per-row operand scale (kernel variant)
 };
 
 static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std::vector<int> bls,
@@ -120,6 +121,9 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
   for (const GemmTask& t : v) {
     if (t.nslab == 4) out->nslab = 4;
     out->mfma_units += (double)t.n_rt * ((t.k_end - t.k_beg) / 4) * t.nslab;
+    for (int sl = 0; sl < 4; ++sl)
+      if (t.x2_off[sl]) out->flags |= 1;
+    if (t.ks_off[0] || t.ks_off[1]) out->flags |= 2;
   }
   if (v.empty()) return 0;
   PXM_HIP(hipMalloc(&out->d, v.size() * sizeof(GemmTask)));
@@ -146,7 +150,7 @@ static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, i
     GemmAffine a = aff;
     if (col0) a.bump = nullptr;  // the iteration counter advances once per call, not once per column group
     a.ncol_live = 2 * C;
-    int rc = launch_gemm(tl.d, tl.n, tl.nslab, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, a, prof);
+    int rc = launch_gemm(tl.d, tl.n, tl.nslab, tl.flags, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, a, prof);
     if (rc) return rc;
   }
   return 0;
@@ -510,7 +514,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   // their GEMMs are emitted as MERGED tasks -- one pass over the table, four column slabs.
   const int top = p->nsc - 1;
   const bool merge = p->fused_combine && p->nsc >= 2 && p->bl[top] == p->bl[top - 1] && p->T[top] == p->T[top - 1] &&
-                     getenv("PXM_GEMM_MERGE");  // measured time-neutral (the launch is MFMA-issue-bound): off by default
+                     false;  // (merged two-scale tasks were measured time-neutral in rounds 1-2 and are not built any more)
   auto cls_of = [&](int s) { return (s == 0) ? 1 : ((s - 1) & 1); };
   // the four per-scale stages as GemmSide descriptors
   auto side = [&](int s, int which) {

@@ -133,7 +133,7 @@ void append_gemm_tasks_merged(const ShtTables& T, int kind, int ncol, const Gemm
 // tiles (1 or 2) of the group
 // alg_bytes: algorithmic bytes of this launch (table once + operand + result), for the live profiler
 // nslab: 1 (unpaired), 2 (+-m pairs) or 4 (the list holds merged tasks)
-int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X, double* Y, int ncol,
+int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, int flags, const double* X, double* Y, int ncol,
                 int col0, int ct, double alg_bytes, double flops, hipStream_t stream,
                 const GemmAffine& aff = GemmAffine(), Profiler* prof = nullptr);
 

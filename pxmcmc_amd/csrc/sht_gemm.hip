@@ -9,6 +9,8 @@
 #include "../../include/pxmcmc_amd.h"
 #include "sht_core.h"
 
+#include <type_traits>
+
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
@@ -55,15 +57,28 @@ extern "C" int pxm_debug_set_gemm_trace(unsigned long long* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
-template <int CT, int NSLAB, int NW, int RT, int NSET>
+__device__ __forceinline__ double stage_add(double a, double b, bool on) { return a + (on ? b : 0.0); }
+__device__ __forceinline__ double2 stage_add(double2 a, double2 b, bool on) { return double2{a.x + (on ? b.x : 0.0), a.y + (on ? b.y : 0.0)}; }
+__device__ __forceinline__ double stage_scale(double a, double sc) { return a * sc; }
+__device__ __forceinline__ double2 stage_scale(double2 a, double sc) { return double2{a.x * sc, a.y * sc}; }
+// TWO: the tasks of the launch sum a second operand in while staging; SK: they scale the operand per contraction row
+// (compile-time, so that the launches without them issue no loads for them)
+template <int CT, int NSLAB, int NW, int RT, int NSET, bool TWO, bool SK>
 __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict__ tasks,
                                                       const double* __restrict__ X, double* __restrict__ Y,
                                                       int ncol, int col0, GemmAffine aff) {
   constexpr int NCT = CT * NSLAB;
+  // all B-fragment LDS reads of a chunk ahead of its MFMAs (one LDS round trip per chunk instead of four): pays in the
+  // Gram launch (1.5 workgroups per CU, nothing else to hide the latency: 22.3 -> 21.8 us), costs 6-10 VGPRs and with
+  // them the eighth wave per SIMD in the streaming launches (32.0 -> 32.7 us) -- on for the two-operand variants only
+  constexpr bool HOIST = TWO;
   constexpr int COLS = 16 * NCT;                          // staged operand columns
   constexpr int PITCH = COLS + (COLS == 16 ? 0 : 16);     // doubles; PITCH*8 = 128 (mod 256)
-  constexpr int NV = KC * COLS / 2;                       // double2 per chunk
   constexpr int NT = 64 * NW;                             // threads per workgroup
+  // staging unit: a double2 per thread where the chunk has at least one for everybody, otherwise a double (so that
+  // every thread of the workgroup stages the same amount and nobody loads twice)
+  constexpr int VW = (KC * COLS / 2 >= NT) ? 2 : 1;       // doubles per staging load
+  constexpr int NV = KC * COLS / VW;                      // staging units per chunk
   constexpr int IT = (NV + NT - 1) / NT;                  // staging loads per thread per chunk
   __shared__ double xs[2][KC][PITCH];
 
@@ -74,57 +89,74 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
 #ifdef PXM_GEMM_TRACE
   const unsigned long long trace_t0 = wall_clock64();
   unsigned long long trace_t1 = 0, trace_t2 = 0;
+  long long trace_c[5] = {0, 0, 0, 0, 0};  // shader-clock stamps inside one steady-state chunk (chunk 8 of tasks that have it)
+#define PXM_GEMM_CSTAMP(K) if (ch == 8) trace_c[K] = clock64();
+#else
+#define PXM_GEMM_CSTAMP(K)
 #endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the row-tile tests scalar
   const int kq = lane >> 4, cl = lane & 15;
   const int n_my = min(RT, max(0, t.n_rt - RT * wave));       // row tiles of this wave
   const int nch = (t.k_end - t.k_beg) / KC;
 
-  // ---- operand staging map: thread -> (row kr, column pair) of the chunk
-  constexpr bool ALL = (NV % NT) == 0 && NSLAB < 4;  // every thread stages in every pass
+  // ---- operand staging map: thread -> (row kr, column pair) of the chunk.
+  // Every thread issues the SAME number of global loads per chunk, unconditionally (threads beyond the staging range
+  // re-read element q mod NV and drop it; a missing second operand / scale vector re-reads the first operand and is
+  // masked by a select): the compiler can then count the loads in flight exactly -- with loads behind divergent or
+  // data-dependent branches it fell back to s_waitcnt vmcnt(0..2) in the loop and every chunk paid two full memory
+  // latencies (one steady-state chunk of the Gram launch: 2 650 cycles, of which 1 330 + 1 170 in those waits).
   const bool live4 = NSLAB < 4 || t.nslab == 4;   // slabs 2, 3 carry a second transform (merged task)
-  const double* sp[IT];
-  int64_t sd[IT];
+  const double* sp[IT];   // first operand
+  const double* sp2[IT];  // second operand summed in while staging (fused wavelet combine)
+  const double* skp[IT];  // per-k operand scale of the thread's slab group
   int so[IT];
-  int64_t sk[IT];  // per-k operand scale vector of the thread's slab group (0 = none)
   bool sv[IT];
 #pragma unroll
   for (int i = 0; i < IT; ++i) {
-    const int q = tid + NT * i;
-    const int kr = (q / (COLS / 2)) % KC, col = 2 * (q % (COLS / 2));
+    const int q0 = tid + NT * i;
+    const int q = q0 % NV;
+    const int kr = (q / (COLS / VW)) % KC, col = VW * (q % (COLS / VW));
     const int slab = col / (16 * CT), cin = col % (16 * CT);
-    sv[i] = (ALL || q < NV) && (slab < 2 || live4);
+    sv[i] = q0 < NV && (slab < 2 || live4);
     // (per-thread slab: read from the task in memory -- a runtime index into the register copy would push
     // the whole struct into scratch)
     const int64_t xo = tasks[blockIdx.x].x_off[slab];
     sp[i] = X + xo + col0 + cin + (int64_t)(t.k_beg + kr) * ncol;
-    sd[i] = tasks[blockIdx.x].x2_off[slab] - xo;
+    sp2[i] = sp[i];
+    skp[i] = sp[i];
+    if (TWO) {  // a task of a TWO launch without a second operand (x2_off = 0) re-reads the first and adds zero
+      const int64_t x2o = tasks[blockIdx.x].x2_off[slab];
+      if (x2o) sp2[i] = sp[i] + (x2o - xo);
+    }
+    if (SK) {
+      const int64_t ks = tasks[blockIdx.x].ks_off[slab >> 1];
+      if (ks) skp[i] = X + ks + t.k_beg + kr;
+    }
     so[i] = kr * PITCH + col;
-    sk[i] = tasks[blockIdx.x].ks_off[slab >> 1];
   }
-  const bool two = t.x2_off[0] != 0;  // second operand summed in while staging (fused wavelet combine)
-  double2 st[NSET - 1][IT], st2[NSET - 1][IT];  // operand chunks in flight (register sets, compile-time indices)
+  const bool two = TWO && t.x2_off[0] != 0;
+  const bool has_sk0 = SK && t.ks_off[0] != 0, has_sk1 = SK && t.ks_off[NSLAB >= 4 ? 1 : 0] != 0;
+  typedef typename std::conditional<VW == 2, double2, double>::type stage_t;
+  stage_t st[NSET - 1][IT], st2[NSET - 1][IT];  // operand chunks in flight (register sets, compile-time indices)
+  double ssc[NSET - 1][IT];
 #define PXM_STAGE_LOAD(SET, CH)                                                                     \
   {                                                                                                 \
     const int cs = min((CH), nch - 1);                                                              \
-    _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i]) {                               \
-      st[SET][i] = *reinterpret_cast<const double2*>(sp[i] + (int64_t)cs * KC * ncol);              \
-      if (two) st2[SET][i] = *reinterpret_cast<const double2*>(sp[i] + sd[i] + (int64_t)cs * KC * ncol); \
+    _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                                \
+      st[SET][i] = *reinterpret_cast<const stage_t*>(sp[i] + (int64_t)cs * KC * ncol);              \
+      if (TWO) st2[SET][i] = *reinterpret_cast<const stage_t*>(sp2[i] + (int64_t)cs * KC * ncol);   \
+      if (SK) ssc[SET][i] = skp[i][cs * KC];                                                        \
     }                                                                                               \
   }
-#define PXM_STAGE_STORE(SET, CH, BUF)                                                               \
-  _Pragma("unroll") for (int i = 0; i < IT; ++i) if (ALL || sv[i]) {                                 \
-    double2 v = st[SET][i];                                                                         \
-    if (two) {                                                                                      \
-      v.x += st2[SET][i].x;                                                                         \
-      v.y += st2[SET][i].y;                                                                         \
+#define PXM_STAGE_STORE(SET, BUF)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                                  \
+    stage_t v = st[SET][i];                                                                         \
+    if (TWO) v = stage_add(v, st2[SET][i], two);                                                    \
+    if (SK) {                                                                                       \
+      const bool hs = (NSLAB >= 4 && (so[i] % PITCH) >= 32 * CT) ? has_sk1 : has_sk0;               \
+      v = stage_scale(v, hs ? ssc[SET][i] : 1.0);                                                   \
     }                                                                                               \
-    if (sk[i]) {                                                                                    \
-      const double sc = (X + sk[i])[t.k_beg + (CH) * KC + so[i] / PITCH];                           \
-      v.x *= sc;                                                                                    \
-      v.y *= sc;                                                                                    \
-    }                                                                                               \
-    *reinterpret_cast<double2*>(&xs[BUF][0][0] + so[i]) = v;                                         \
+    if (sv[i]) *reinterpret_cast<stage_t*>(&xs[BUF][0][0] + so[i]) = v;                             \
   }
 
   // ---- table stream: per row tile two double2 per chunk (k-steps {0,1} and {2,3}).
@@ -153,49 +185,67 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
 #pragma unroll
     for (int c = 0; c < NCT; ++c) acc[r][c] = d4{0, 0, 0, 0};
 
-  // operand set of chunk ch: ch % (NSET-1); table set: ch % NSET.  Both streams run NSET-1 chunks ahead; the loop
-  // is unrolled over NSET (NSET-1) = LCM-free pattern by making the period NSET * (NSET - 1) explicit below.
+  // One loop, no prologue: iteration it stores chunk it - (NSET-1) to LDS (a dummy store of zeros while that is
+  // negative), loads chunk it (operand set it % (NSET-1), table set it % NSET; clamped past the end), passes the
+  // barrier and multiplies chunk it - (NSET-1).  Up to the barrier the body is straight-line and identical in every
+  // iteration, so the steady-state load counts hold on every path into it and the waits are exact: vmcnt(2) before
+  // the LDS store (the two table loads may stay in flight), vmcnt(5+) before the MFMAs.
 #pragma unroll
-  for (int u = 0; u < NSET - 1; ++u) {
-    PXM_STAGE_LOAD(u, u)
-    PXM_TAB_LOAD(u, u)
-  }
+  for (int u = 0; u < NSET - 1; ++u)
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      st[u][i] = st2[u][i] = stage_t{};
+      ssc[u][i] = 0.0;
+    }
   constexpr int PER = NSET * (NSET - 1);
-  for (int ch0 = 0; ch0 < nch; ch0 += PER) {
+  const int nit = nch + NSET - 1;
+  for (int it0 = 0; it0 < nit; it0 += PER) {
 #pragma unroll
     for (int pv = 0; pv < PER; ++pv) {
-      const int ch = ch0 + pv;
-      const int u = pv % NSET;
-      if (ch < nch) {
-        const int buf = ch & 1;
+      const int it = it0 + pv;
+      const int ch = it - (NSET - 1);                      // the chunk stored / multiplied in this iteration
+      constexpr int LAG = NSET - 1;
+      const int us = pv % (NSET - 1);                       // operand set: stored, then reloaded with chunk it
+      const int ut = pv % NSET;                             // table set loaded with chunk it
+      const int um = (pv + NSET - LAG % NSET) % NSET;       // table set of chunk ch
+      const int buf = (pv + PER - LAG) & 1;                 // LDS buffer of chunk ch (PER is even)
+      PXM_GEMM_CSTAMP(0)
+#ifdef PXM_GEMM_TRACE
+      if (ch == 9) trace_c[4] = clock64();
+#endif
 #if !(PXM_GEMM_ABLATE & 4)
-        PXM_STAGE_STORE(pv % (NSET - 1), ch, buf)
-        PXM_STAGE_LOAD(pv % (NSET - 1), ch + NSET - 1)   // (the set just stored is free again; clamped past the end)
+      PXM_STAGE_STORE(us, buf)
+      PXM_GEMM_CSTAMP(1)  // operand of this chunk arrived and went to LDS
+      PXM_STAGE_LOAD(us, it)
 #endif
 #if !(PXM_GEMM_ABLATE & 2)
-        PXM_TAB_LOAD((u + NSET - 1) % NSET, ch + NSET - 1)
+      PXM_TAB_LOAD(ut, it)
 #endif
 #if !(PXM_GEMM_ABLATE & 4)
-        __syncthreads();
+      __syncthreads();
 #endif
 #ifdef PXM_GEMM_TRACE
-        if (ch == 0) trace_t1 = wall_clock64();  // first chunk staged: task fetch + first operand loads are behind us
+      if (ch == 0) trace_t1 = wall_clock64();  // first chunk staged: task fetch + first operand loads are behind us
 #endif
-        if (v0) {
+      PXM_GEMM_CSTAMP(2)  // barrier passed
+      if (v0 && ch >= 0 && ch < nch) {
 #define PXM_MFMA_CHUNK(NC)                                                                                     \
-  _Pragma("unroll") for (int h4 = 0; h4 < 4; ++h4) {                                                           \
-    double b[NC];                                                                                              \
-    _Pragma("unroll") for (int c = 0; c < NC; ++c) b[c] = xs[buf][4 * h4 + kq][16 * c + cl];                   \
-    _Pragma("unroll") for (int r = 0; r < RT; ++r) {                                                           \
-      const double av = (h4 & 1) ? A[u][r][h4 >> 1].y : A[u][r][h4 >> 1].x;                                    \
-      _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                           \
-          PXM_GEMM_MFMA(acc[r][c], av, b[c])                                                                   \
-    }                                                                                                          \
+  {                                                                                                            \
+    double b[4][NC]; /* all B fragments of the chunk first: one LDS round trip instead of one per k-step */    \
+    _Pragma("unroll") for (int h4 = 0; h4 < 4; ++h4)                                                           \
+      _Pragma("unroll") for (int c = 0; c < NC; ++c) b[h4][c] = xs[buf][4 * h4 + kq][16 * c + cl];             \
+    if (HOIST) __builtin_amdgcn_sched_barrier(0); /* (otherwise the scheduler sinks the reads between the MFMAs) */ \
+    _Pragma("unroll") for (int h4 = 0; h4 < 4; ++h4)                                                           \
+      _Pragma("unroll") for (int r = 0; r < RT; ++r) {                                                         \
+        const double av = (h4 & 1) ? A[um][r][h4 >> 1].y : A[um][r][h4 >> 1].x;                                \
+        _Pragma("unroll") for (int c = 0; c < NC; ++c)                                                         \
+            PXM_GEMM_MFMA(acc[r][c], av, b[h4][c])                                                             \
+      }                                                                                                        \
   }
-          if (live4) { PXM_MFMA_CHUNK(NCT) } else { PXM_MFMA_CHUNK((NSLAB == 4 ? NCT / 2 : NCT)) }
+        if (live4) { PXM_MFMA_CHUNK(NCT) } else { PXM_MFMA_CHUNK((NSLAB == 4 ? NCT / 2 : NCT)) }
 #undef PXM_MFMA_CHUNK
-        }
       }
+      PXM_GEMM_CSTAMP(3)  // MFMAs of the chunk issued (table fragment of this chunk had to be there)
     }
   }
 #undef PXM_STAGE_LOAD
@@ -262,6 +312,12 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     r[0] = blockIdx.x; r[1] = gridDim.x; r[2] = trace_t0; r[3] = wall_clock64();
     r[4] = ((unsigned long long)(xcc & 0xf) << 32) | hw; r[5] = (unsigned long long)nch | ((unsigned long long)t.n_rt << 16) | ((unsigned long long)aff.on << 32);
     r[6] = trace_t1; r[7] = trace_t2;
+    if (nch > 9) {  // second record: the chunk-8 stamps (cycles): stage store done, barrier passed, MFMAs issued, next chunk's top
+      const unsigned long long s2 = atomicAdd(g_gemm_trace + 1, 1ull);
+      unsigned long long* q = g_gemm_trace + 8 + 8 * 8192 + 8 * s2;
+      q[0] = nch; q[1] = trace_c[1] - trace_c[0]; q[2] = trace_c[2] - trace_c[1]; q[3] = trace_c[3] - trace_c[2];
+      q[4] = trace_c[4] - trace_c[3]; q[5] = aff.on; q[6] = gridDim.x; q[7] = 0;
+    }
   }
 #endif
 }
@@ -317,54 +373,44 @@ int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* byte
   return 0;
 }
 
-// GEMM workgroup geometry: NW waves x RT row tiles per wave (a task covers NW*RT row tiles):
-//   81  8 waves x 1 row tile  -- default: same operand staging traffic as 4 x 2, twice the waves to hide
-//                                latency, <= 128 VGPR
-//   41  4 waves x 1 row tile  -- half-size tasks: 2 % faster at 16 columns (better tail balance) but the
-//                                operand is staged twice as often (PMC: 1.14x the algorithmic bytes instead
-//                                of 0.90x), so it is not the default
-//   42  4 waves x 2 row tiles -- kept for A/B runs
-// PXM_GEMM_GEOM=81|41|42 selects one.
-int gemm_geom(int ncol) {
+// GEMM workgroup geometry: 8 waves x 1 row tile per wave (a task covers 8 row tiles).  (4 waves x 1 and 4 x 2 were
+// A/B variants until round 2: 26.1 us and slower for the Gram launch, operand staged twice as often.)
+int gemm_rows_per_task(int ncol) {
   (void)ncol;
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("PXM_GEMM_GEOM");
-    const int v = e ? atoi(e) : 0;
-    forced = (v == 81 || v == 41 || v == 42) ? v : 0;
-  }
-  return forced ? forced : 81;
+  return 8;
 }
-int gemm_rows_per_task(int ncol) { return gemm_geom(ncol) == 41 ? 4 : 8; }
 
-int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X, double* Y, int ncol,
+// flags: bit 0 = the list's tasks carry a second operand, bit 1 = a per-contraction-row operand scale
+int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, int flags, const double* X, double* Y, int ncol,
                 int col0, int ct, double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff, Profiler* prof) {
   if (n_tasks == 0) return 0;
-  const int geom = gemm_geom(ncol);
-  dim3 grid(n_tasks), block(geom == 81 ? 512 : 256);  // 41: 4 waves x 1 row tile (tasks of 4 row tiles)
+  PXM_REQUIRE(nslab == 1 || nslab == 2, "launch_gemm: merged (four-slab) task lists are not built any more");
+  dim3 grid(n_tasks), block(512);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->gemm, &ev0, &ev1, alg_bytes, flops);
-#define PXM_GEMM_LAUNCH(A, B)                                                                                         \
-  if (geom == 81) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 8, 1, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
-  else if (geom == 41) hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 1, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff); \
-  else hipExtLaunchKernelGGL((k_sht_gemm<A, B, 4, 2, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
-  static const int gram_nset = getenv("PXM_GEMM_GRAM_NSET") ? atoi(getenv("PXM_GEMM_GRAM_NSET")) : 2;
-  if (aff.on && geom == 81 && nslab == 2 && gram_nset != 2) {  // Gram launch: few workgroups, long chains -> deep look-ahead
-    if (gram_nset == 3) {
-      if (ct == 1) hipExtLaunchKernelGGL((k_sht_gemm<1, 2, 8, 1, 3>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
-      else hipExtLaunchKernelGGL((k_sht_gemm<2, 2, 8, 1, 3>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
-    } else {
-      if (ct == 1) hipExtLaunchKernelGGL((k_sht_gemm<1, 2, 8, 1, 4>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
-      else hipExtLaunchKernelGGL((k_sht_gemm<2, 2, 8, 1, 4>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff);
-    }
-  } else if (nslab == 4) {
-    if (ct == 1) { PXM_GEMM_LAUNCH(1, 4) } else { PXM_GEMM_LAUNCH(2, 4) }
-  } else if (nslab == 2) {
-    if (ct == 1) { PXM_GEMM_LAUNCH(1, 2) } else { PXM_GEMM_LAUNCH(2, 2) }
-  } else {
-    if (ct == 1) { PXM_GEMM_LAUNCH(1, 1) } else { PXM_GEMM_LAUNCH(2, 1) }
+  // look-ahead of the table / operand streams in chunks + 1: PXM_GEMM_NSET (all launches), PXM_GEMM_GRAM_NSET (Gram)
+  static const int all_nset = getenv("PXM_GEMM_NSET") ? atoi(getenv("PXM_GEMM_NSET")) : 2;
+  static const int gram_nset = getenv("PXM_GEMM_GRAM_NSET") ? atoi(getenv("PXM_GEMM_GRAM_NSET")) : all_nset;
+  const int nset = (aff.on ? gram_nset : all_nset) == 3 ? 3 : 2;
+#define PXM_GEMM_L4(CT_, NS_, NSET_, TWO_, SK_) \
+  hipExtLaunchKernelGGL((k_sht_gemm<CT_, NS_, 8, 1, NSET_, TWO_, SK_>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff)
+#define PXM_GEMM_L3(CT_, NS_, NSET_)                                   \
+  switch (flags & 3) {                                                 \
+    case 0: PXM_GEMM_L4(CT_, NS_, NSET_, false, false); break;         \
+    case 1: PXM_GEMM_L4(CT_, NS_, NSET_, true, false); break;          \
+    case 2: PXM_GEMM_L4(CT_, NS_, NSET_, false, true); break;          \
+    default: PXM_GEMM_L4(CT_, NS_, NSET_, true, true); break;          \
   }
-#undef PXM_GEMM_LAUNCH
+#define PXM_GEMM_L2(CT_, NS_) \
+  if (nset == 3) { PXM_GEMM_L3(CT_, NS_, 3) } else { PXM_GEMM_L3(CT_, NS_, 2) }
+  if (nslab == 2) {
+    if (ct == 1) { PXM_GEMM_L2(1, 2) } else { PXM_GEMM_L2(2, 2) }
+  } else {
+    if (ct == 1) { PXM_GEMM_L2(1, 1) } else { PXM_GEMM_L2(2, 1) }
+  }
+#undef PXM_GEMM_L2
+#undef PXM_GEMM_L3
+#undef PXM_GEMM_L4
   PXM_HIP(hipGetLastError());
   return 0;
 }

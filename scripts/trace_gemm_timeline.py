@@ -35,8 +35,8 @@ s._engine_start(X, preds, 0)
 s._engine_advance(40)
 torch.cuda.synchronize()
 
-NREC = 8192  # (DFT trace: workgroup records in the first 4096 slots, phase records behind them)
-buf = torch.zeros(8 + 8 * NREC, dtype=torch.int64, device="cuda")
+NREC = 8192  # (DFT trace: workgroup records in the first 4096 slots, phase records behind them; GEMM: chunk stamps behind 8192)
+buf = torch.zeros(8 + 8 * 2 * NREC, dtype=torch.int64, device="cuda")
 if os.environ.get("TRACE") == "dft":  # grouped DFT kernel instead (-DPXM_D5_TRACE build)
     fn = lib.pxm_debug_set_dft_trace
     fn.argtypes = [C.c_void_p]
@@ -123,3 +123,11 @@ for (grid, gram), rows in launches:
     ends = (a[:, 3] - t0) / 100.0
     print(f"  last workgroup to finish: block {int(a[np.argmax(ends), 0])} with {int(nchs[np.argmax(ends)])} chunks, started at {start[np.argmax(ends)]:.1f} us, "
           f"ran {dur[np.argmax(ends)]:.1f} us; 90 % of the workgroups are done by {np.percentile(ends, 90):.1f} us")
+
+m = int(h[1])
+q = h[8 + 8 * 8192:8 + 8 * 8192 + 8 * m].reshape(m, 8).astype(np.int64)
+print("\nchunk 8 of the tasks that have one (thread 0 of the workgroup; shader-clock cycles, median): operand wait + LDS store / barrier / B reads + MFMA issue / loop tail")
+for key in sorted(set(zip(q[:, 6].tolist(), q[:, 5].tolist(), q[:, 0].tolist()))):
+    sel = (q[:, 6] == key[0]) & (q[:, 5] == key[1]) & (q[:, 0] == key[2])
+    med = np.median(q[sel, 1:5], axis=0)
+    print(f"  grid {key[0]} gram={key[1]} chunks={key[2]}: " + " / ".join(f"{int(v):6d}" for v in med) + f"   sum {int(med.sum())} cycles ({int(sel.sum())} workgroups)")
