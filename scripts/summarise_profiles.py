@@ -77,12 +77,15 @@ for k in sorted(fetch):
         rd = 2 * 1024 * sum(fetch[k]) / len(fetch[k])
         wr = 1024 * sum(write[k]) / len(write[k])
         out.append(f"| `{k[:60]}` | {len(fetch[k])} | {rd/1e6:.1f} | {wr/1e6:.1f} | {(rd+wr)/1e6:.1f} |")
-        if "k_sht_gemm<" in k and k.strip() == dominant:  # the variant the timed steps launch
-            summary["k_sht_gemm_hbm_bytes_per_launch"] = rd + wr
-            summary["k_sht_gemm_read_bytes"] = rd
-            summary["k_sht_gemm_write_bytes"] = wr
-            summary["kernel"] = k.strip()
-            summary["launches_sampled"] = len(fetch[k])
+        # the variants the timed steps launch: same <CT, NSLAB, NW, RT, NSET> as the dominant one, any operand flags
+        # (Gram: second operand, forward-adjoint: row scale, forward: neither) -- averaged over all their launches
+        if "k_sht_gemm<" in k and k.strip().split(",")[:5] == dominant.split(",")[:5]:
+            n0 = summary.get("launches_sampled", 0)
+            n1 = len(fetch[k])
+            for key, val in (("k_sht_gemm_hbm_bytes_per_launch", rd + wr), ("k_sht_gemm_read_bytes", rd), ("k_sht_gemm_write_bytes", wr)):
+                summary[key] = (summary.get(key, 0.0) * n0 + val * n1) / (n0 + n1)
+            summary["kernel"] = ",".join(dominant.split(",")[:5]) + ", *, *> (all operand-flag variants of the timed steps)"
+            summary["launches_sampled"] = n0 + n1
 if bench.get("roofline", {}).get("launch_classes"):
     out.append("\n## k_sht_gemm launch classes from the bench line (live HIP events, algorithmic bytes per launch)\n\n| alg MB | launches | avg us | TB/s | of 8 TB/s |\n|---|---|---|---|---|")
     for c in bench["roofline"]["launch_classes"]:
