@@ -444,16 +444,34 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
     const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
 #pragma unroll
     for (int g0 = 0; g0 < P1; g0 += 4) {  // all loads of a group first (independent), then its arithmetic
+      // The loads are unconditional (elements past the ring end re-read the ring's element 0 and are dropped below;
+      // the threshold vector and the injected noise sit behind ONE uniform branch per group): with a per-element
+      // predicate around each load the compiler drained the memory pipe (s_waitcnt vmcnt(0)) once per element and
+      // the workgroup paid four memory latencies here instead of one.
       double2 xs[4], wn[4];
       double Ts[4];
+      int64_t eo[4];  // element offset from e0 (or to the ring's element 0)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int p = g0 + u;
         const bool ok = jb + 8 * R0 * (pb + p) < n;
-        const int64_t off = (int64_t)(8 * R0) * p;
-        xs[u] = ok ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
-        Ts[u] = (ok && out.T) ? out.T[e0 + off] : out.T_scalar;
-        wn[u] = (ok && out.noise) ? px_noise_load(out, ch, e0 + off) : double2{0.0, 0.0};
+        eo[u] = ok ? (int64_t)(8 * R0) * p : -(int64_t)(jb + 8 * R0 * pb);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xs[u] = reinterpret_cast<const double2*>(out.X)[ce0 + eo[u]];
+      if (out.T) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Ts[u] = out.T[e0 + eo[u]];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Ts[u] = out.T_scalar;
+      }
+      if (out.noise) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wn[u] = px_noise_load(out, ch, e0 + eo[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wn[u] = double2{0.0, 0.0};
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
