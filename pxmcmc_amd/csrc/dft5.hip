@@ -352,13 +352,27 @@ __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in,
   if ((by << a.lgR) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
   PXM_D5_GEOMETRY
   // each wave of the pair fetches half of the ring set (its four p) and the two share it through the stage
+  {  // the wave's four elements: batched loads (elements past the ring end / dead rings re-read a valid element)
+    int64_t ev[4];
+    bool ok[4];
+    double2 v[4];
+    const bool act = ch < C && tv;
+    const int64_t e_ring = in.ring0 + (int64_t)(tv ? t : 0) * n;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int j = jb + 8 * R0 * (pb + u);
-    if (j < n) {
-      double2 v{0.0, 0.0};
-      if (ch < C && tv) v = px_in_load(in, ch, in.ring0 + (int64_t)t * n + j);
-      stage[PXM_D5_SLOT(trs, j, r)] = v;
+    for (int u = 0; u < 4; ++u) {
+      const int j = jb + 8 * R0 * (pb + u);
+      ok[u] = act && j < n;
+      ev[u] = e_ring + (j < n ? j : 0);
+    }
+    if (ch < C) px_in_load_n<4>(in, ch, ev, ok, v);
+    else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = double2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = jb + 8 * R0 * (pb + u);
+      if (j < n) stage[PXM_D5_SLOT(trs, j, r)] = v[u];
     }
   }
   __syncthreads();  // (also: the LDS copy of the twiddles is complete)
@@ -491,25 +505,38 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
       }
     }
   } else if (act) {
+    // plain / gathered output of the wave's P1 elements, and (RING_OUT) the residual invcov .* (image - data) that
+    // goes back to the rings: the loads of all elements first (elements past the ring end re-read the ring's
+    // element 0), then the arithmetic -- one memory latency per batch instead of one or two per element
+    bool ok[P1];
+    int64_t ev[P1];
+    double2 yv[P1];
 #pragma unroll
     for (int p = 0; p < P1; ++p) {
-      if (jb + 8 * R0 * (pb + p) >= n) {
-        x[p] = double2{0.0, 0.0};
-        continue;
-      }
-      const int64_t e = e0 + (int64_t)(8 * R0) * p;
-      double2 y{x[p].x, -x[p].y};
-      px_out_store(out, ch, e, y);
-      if (RING_OUT && out.rdata) {  // residual invcov .* (image - data) goes back to the rings
-        y = csub(y, reinterpret_cast<const double2*>(out.rdata)[e]);
-        if (out.rinvcov_complex) y = cmul(reinterpret_cast<const double2*>(out.rinvcov)[e], y);
-        else {
-          const double wt = out.rinvcov[e];
-          y = double2{wt * y.x, wt * y.y};
-        }
-      }
-      x[p] = y;
+      ok[p] = jb + 8 * R0 * (pb + p) < n;
+      ev[p] = ok[p] ? e0 + (int64_t)(8 * R0) * p : out.ring0 + (int64_t)t * n;
+      yv[p] = double2{x[p].x, -x[p].y};
     }
+    px_out_store_n<P1>(out, ch, ev, yv, ok);
+    if (RING_OUT && out.rdata) {
+      double2 rd[P1], rc[P1];
+#pragma unroll
+      for (int p = 0; p < P1; ++p) rd[p] = reinterpret_cast<const double2*>(out.rdata)[ev[p]];
+      if (out.rinvcov_complex) {
+#pragma unroll
+        for (int p = 0; p < P1; ++p) rc[p] = reinterpret_cast<const double2*>(out.rinvcov)[ev[p]];
+      } else {
+#pragma unroll
+        for (int p = 0; p < P1; ++p) rc[p] = double2{out.rinvcov[ev[p]], 0.0};
+      }
+#pragma unroll
+      for (int p = 0; p < P1; ++p) {
+        const double2 d = csub(yv[p], rd[p]);
+        yv[p] = out.rinvcov_complex ? cmul(rc[p], d) : double2{rc[p].x * d.x, rc[p].x * d.y};
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < P1; ++p) x[p] = ok[p] ? yv[p] : double2{0.0, 0.0};
   } else {
 #pragma unroll
     for (int p = 0; p < P1; ++p) x[p] = double2{0.0, 0.0};  // padding chains / rings: their rings are kept at zero
@@ -708,20 +735,27 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
   if ((by << a.lgR) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
   PXM_D6_GEOMETRY
   // every wave fetches a quarter of the ring (its two p, both halves) and the four share it through the stage
+  {  // batched loads of the wave's four elements (elements past the ring end re-read element 0 of the ring)
+    int64_t ev[4];
+    bool ok[4];
+    double2 v[4];
 #pragma unroll
-  for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-    for (int hq = 0; hq < 2; ++hq) {
-      const int j = lane + 64 * (2 * w + ii) + 512 * hq;
-      if (j < n) {
-        const int64_t e = in.ring0 + (int64_t)t * n + j;
-#if PXM_D5_ABLATE & 16
-        stage[PXM_D6_SLOT(j, r)] = double2{1.0 + (double)(e & 7), 0.5};
-#else
-        stage[PXM_D6_SLOT(j, r)] = (ch < C) ? px_in_load(in, ch, e) : double2{0.0, 0.0};
-#endif
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int j = lane + 64 * (2 * w + (u >> 1)) + 512 * (u & 1);
+      ok[u] = ch < C && j < n;
+      ev[u] = in.ring0 + (int64_t)t * n + (j < n ? j : 0);
     }
+    if (ch < C) px_in_load_n<4>(in, ch, ev, ok, v);
+    else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = double2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = lane + 64 * (2 * w + (u >> 1)) + 512 * (u & 1);
+      if (j < n) stage[PXM_D6_SLOT(j, r)] = v[u];
+    }
+  }
   __syncthreads();  // (also: the LDS copy of the twiddles is complete)
   double2 xl[8], xh[8];
 #pragma unroll
@@ -805,31 +839,45 @@ __global__ __launch_bounds__(512, 4) void k_ring2px6(Dft6Args a, const double* _
   const int64_t e0 = out.ring0 + (int64_t)t * n + lane + 64 * pb;
   const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
   // the four elements of the lane: loads first (independent), then the arithmetic
-  double2 xs[4], wn[4];
-  double Ts[4];
+  // (unconditional loads behind uniform branches, elements past the ring end re-read the lane's first element: see
+  // ring2px_body5 -- one memory latency per batch instead of one per element)
   bool ok[4];
+  int64_t eo[4];
+  double2 yv[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int ii = u >> 1, hq = u & 1;
-    const int64_t off = 64 * ii + 512 * hq;
     ok[u] = lane + 64 * (pb + ii) + 512 * hq < n;
-    xs[u] = (ok[u] && out.X) ? reinterpret_cast<const double2*>(out.X)[ce0 + off] : double2{0.0, 0.0};
-    Ts[u] = (ok[u] && out.X && out.T) ? out.T[e0 + off] : out.T_scalar;
-    wn[u] = (ok[u] && out.X && out.noise) ? px_noise_load(out, ch, e0 + off) : double2{0.0, 0.0};
+    eo[u] = ok[u] ? 64 * ii + 512 * hq : 0;  // (the lane's first element, lane + 64 pb < 512 < n, always exists)
+    yv[u] = double2{fo[ii][hq].x, -fo[ii][hq].y};
   }
+  if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
+    double2 xs[4], wn[4];
+    double Ts[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (!ok[u]) continue;
-    const int ii = u >> 1, hq = u & 1;
-    const int64_t off = 64 * ii + 512 * hq;
-    const double2 y{fo[ii][hq].x, -fo[ii][hq].y};
-    if (out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
-      double2 wv = wn[u];
-      if (!out.noise) wv = px_noise_philox(out, ch, e0 + off, it_eff);
-      reinterpret_cast<double2*>(out.f)[ce0 + off] = px_update(out, xs[u], Ts[u], y, wv);
+    for (int u = 0; u < 4; ++u) xs[u] = reinterpret_cast<const double2*>(out.X)[ce0 + eo[u]];
+    if (out.T) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Ts[u] = out.T[e0 + eo[u]];
     } else {
-      px_out_store(out, ch, e0 + off, y);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Ts[u] = out.T_scalar;
     }
+    if (out.noise) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wn[u] = px_noise_load(out, ch, e0 + eo[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const double2 wv = out.noise ? wn[u] : px_noise_philox(out, ch, e0 + eo[u], it_eff);
+      reinterpret_cast<double2*>(out.f)[ce0 + eo[u]] = px_update(out, xs[u], Ts[u], yv[u], wv);
+    }
+  } else {
+    int64_t ev[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ev[u] = e0 + eo[u];
+    px_out_store_n<4>(out, ch, ev, yv, ok);
   }
 }
 

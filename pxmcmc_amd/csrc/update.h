@@ -41,6 +41,62 @@ __device__ __forceinline__ double2 px_in_load(const PxIn& in, int ch, int64_t e)
   return v;
 }
 
+// The same for N elements of a lane: the index loads (if any) together, then every load that depends on them together
+// -- two memory latencies for the batch.  ok[u] false: the element is zero (its e must still be a valid index).
+template <int N>
+__device__ __forceinline__ void px_in_load_n(const PxIn& in, int ch, const int64_t (&e)[N], const bool (&ok)[N], double2 (&v)[N]) {
+  int64_t src[N];
+  bool live[N];
+  if (in.gidx) {
+    int idx[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) idx[u] = in.gidx[e[u]];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      live[u] = ok[u] && idx[u] >= 0;
+      src[u] = idx[u] < 0 ? 0 : idx[u];
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      live[u] = ok[u];
+      src[u] = e[u];
+    }
+  }
+  const double2* f = reinterpret_cast<const double2*>(in.f) + (int64_t)ch * in.chain_stride;
+#pragma unroll
+  for (int u = 0; u < N; ++u) v[u] = f[src[u]];
+  if (in.data) {
+    double2 d[N], c[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) d[u] = reinterpret_cast<const double2*>(in.data)[src[u]];
+    if (in.invcov_complex) {
+#pragma unroll
+      for (int u = 0; u < N; ++u) c[u] = reinterpret_cast<const double2*>(in.invcov)[src[u]];
+#pragma unroll
+      for (int u = 0; u < N; ++u) v[u] = cmul(c[u], csub(v[u], d[u]));
+    } else {
+#pragma unroll
+      for (int u = 0; u < N; ++u) c[u].x = in.invcov[src[u]];
+#pragma unroll
+      for (int u = 0; u < N; ++u) {
+        const double2 r = csub(v[u], d[u]);
+        v[u] = double2{c[u].x * r.x, c[u].x * r.y};
+      }
+    }
+  }
+  if (in.gw) {
+    double w[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) w[u] = in.gw[src[u]];
+#pragma unroll
+    for (int u = 0; u < N; ++u) v[u] = double2{w[u] * v[u].x, w[u] * v[u].y};
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u)
+    if (!live[u]) v[u] = double2{0.0, 0.0};
+}
+
 // plain output element e of chain ch of a ring2px kernel: the image, or its masked + weighted data vector
 __device__ __forceinline__ void px_out_store(const PxOut& out, int ch, int64_t e, double2 y) {
   if (out.gidx) {
@@ -54,6 +110,33 @@ __device__ __forceinline__ void px_out_store(const PxOut& out, int ch, int64_t e
     return;
   }
   reinterpret_cast<double2*>(out.f)[(int64_t)ch * out.chain_stride + e] = y;
+}
+
+// The same for N elements of a lane: the index loads, then the weight loads, then the stores -- two memory latencies
+// for the batch instead of two per element.  ok[u] false: element not written (its e must still be a valid index).
+template <int N>
+__device__ __forceinline__ void px_out_store_n(const PxOut& out, int ch, const int64_t (&e)[N], const double2 (&y)[N], const bool (&ok)[N]) {
+  double2* f = reinterpret_cast<double2*>(out.f) + (int64_t)ch * out.chain_stride;
+  if (out.gidx) {
+    int idx[N];
+    double w[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) idx[u] = out.gidx[e[u]];
+    if (out.gw) {
+#pragma unroll
+      for (int u = 0; u < N; ++u) w[u] = out.gw[idx[u] < 0 ? 0 : idx[u]];
+    } else {
+#pragma unroll
+      for (int u = 0; u < N; ++u) w[u] = 1.0;
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u)
+      if (ok[u] && idx[u] >= 0) f[idx[u]] = double2{w[u] * y[u].x, w[u] * y[u].y};
+    return;
+  }
+#pragma unroll
+  for (int u = 0; u < N; ++u)
+    if (ok[u]) f[e[u]] = y[u];
 }
 
 // injected noise of (slot c, element e); real-pair noise is a real [2 * slots][chain_stride] array
