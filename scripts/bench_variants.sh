@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B helper (run on the GPU box via gpurun): one bench line per environment setting, e.g.
-#   bash scripts/bench_variants.sh "PXM_X=0" "PXM_NO_DFT_GROUP=1" "PXM_GEMM_GEOM=41"
+#   bash scripts/bench_variants.sh "PXM_X=0" "PXM_NO_DFT_GROUP=1" "PXM_GEMM_ORDER=plain"
 # prints samples/s, ms per step, GEMM us per launch, HBM fraction, MFMA TFLOP/s.
 [ $# -eq 0 ] && set -- "PXM_X=0"
 for v in "$@"; do
