@@ -18,10 +18,9 @@ struct TaskList {
   GemmTask* d = nullptr;
   int n = 0;
   bool paired = false;
-  int nslab = 2;         // kernel variant: 1 unpaired, 2 +-m pairs, 4 the list holds merged (two-transform) tasks
+  int nslab = 2;         // kernel variant: 1 unpaired, 2 +-m pairs
   std::vector<int> bls;  // bandlimits of the transforms grouped in this launch (roofline accounting)
   std::vector<int> los;  // their support cuts el_lo (0 = none)
-  int merged = -1;       // index i: transforms i and i+1 share one pass over their table (counted once)
   double mfma_units = 0; // sum over tasks of row tiles x k-steps x slabs: MFMAs per column tile
   bool gram = false;     // Gram launch: table sum_m (L-m)^2 entries, harmonic side read and written
   int flags = 0;         // bit 0: tasks sum a second operand in while staging; bit 1: per-row operand scale (kernel variant)
@@ -119,7 +118,6 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
   out->paired = paired;
   out->nslab = paired ? 2 : 1;
   for (const GemmTask& t : v) {
-    if (t.nslab == 4) out->nslab = 4;
     out->mfma_units += (double)t.n_rt * ((t.k_end - t.k_beg) / 4) * t.nslab;
     for (int sl = 0; sl < 4; ++sl)
       if (t.x2_off[sl]) out->flags |= 1;
@@ -145,8 +143,6 @@ static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, i
       if (tl.gram) bytes += 8.0 * Ld * (Ld + 1) * (2 * Ld + 1) / 6 + 2 * 16.0 * cg * Ld * Ld;
       else bytes += gemm_alg_bytes(tl.bls[i], tl.paired, cg, tl.los[i]);
     }
-    if (tl.merged >= 0)  // two transforms, one pass over the table: the smaller of the two row ranges is not re-read
-      bytes -= gemm_table_bytes(tl.bls[tl.merged], tl.paired, std::max(tl.los[tl.merged], tl.los[tl.merged + 1]));
     GemmAffine a = aff;
     if (col0) a.bump = nullptr;  // the iteration counter advances once per call, not once per column group
     a.ncol_live = 2 * C;
@@ -510,11 +506,6 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   }
   // task lists
   std::vector<GemmTask> v_syn_fwd, v_adj_fwdadj, v_ana_inv, v_anadj_invadj, v;
-  // The two finest scales usually share the bandlimit L (bl = min(ceil(B^(j+1)), L)) and therefore the table:
-  // their GEMMs are emitted as MERGED tasks -- one pass over the table, four column slabs.
-  const int top = p->nsc - 1;
-  const bool merge = p->fused_combine && p->nsc >= 2 && p->bl[top] == p->bl[top - 1] && p->T[top] == p->T[top - 1] &&
-                     false;  // (merged two-scale tasks were measured time-neutral in rounds 1-2 and are not built any more)
   auto cls_of = [&](int s) { return (s == 0) ? 1 : ((s - 1) & 1); };
   // the four per-scale stages as GemmSide descriptors
   auto side = [&](int s, int which) {
@@ -552,14 +543,9 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   std::vector<GemmTask>* lists[4] = {&v_syn_fwd, &v_adj_fwdadj, &v_ana_inv, &v_anadj_invadj};
   for (int s = 0; s < p->nsc; ++s) {
     for (int w = 0; w < 4; ++w) {
-      if (merge && s == top) continue;  // emitted together with top - 1
-      if (merge && s == top - 1) {
-        append_gemm_tasks_merged(*p->T[s], kinds[w], p->ncol, side(s, w), side(top, w), p->offS, p->ws, *lists[w]);
-      } else {
-        const GemmSide g = side(s, w);
-        append_gemm_tasks(*p->T[s], kinds[w], p->ncol, g.x_base, g.x_L, g.x_Rp, g.y_base, g.y_L, g.y_Rp, g.kscale, p->offS,
-                          p->ws, *lists[w], g.el_lo, g.fuse);
-      }
+      const GemmSide g = side(s, w);
+      append_gemm_tasks(*p->T[s], kinds[w], p->ncol, g.x_base, g.x_L, g.x_Rp, g.y_base, g.y_L, g.y_Rp, g.kscale, p->offS,
+                        p->ws, *lists[w], g.el_lo, g.fuse);
     }
     p->table_bytes[0] += p->T[s]->bytes[TAB_FWD];
     p->table_bytes[1] += p->T[s]->bytes[TAB_FWD_ADJ];
@@ -570,7 +556,6 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl, el_lo))) return rc;
   if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl, el_lo))) return rc;
   if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl, el_lo))) return rc;
-  if (merge) p->syn_fwd.merged = p->adj_fwdadj.merged = p->ana_inv.merged = p->anadj_invadj.merged = top - 1;
   v.clear();
   GemmFuse sum2;
   sum2.x2_base = p->offHB;

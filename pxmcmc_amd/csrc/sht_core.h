@@ -44,7 +44,7 @@ struct GemmTask {
   int k_beg, k_end;    // contraction range, multiples of 16
   int row0;            // first output row of this task
   int n_rt;            // row tiles in this task (1..8)
-  int nslab;           // live slabs: 1 (all m stored), 2 (+-m pair) or 4 (merged pair of transforms)
+  int nslab;           // live slabs: 1 (all m stored) or 2 (+-m pair)
   double sign1;        // factor on the -m outputs ((-1)^m)
 };
 
@@ -126,13 +126,11 @@ struct GemmSide {
   int el_lo;
   GemmFuse fuse;
 };
-void append_gemm_tasks_merged(const ShtTables& T, int kind, int ncol, const GemmSide& a, const GemmSide& b,
-                              int64_t scratch_off, const double* ws_base, std::vector<GemmTask>& tasks);
 
 // launch: tasks on device; X/Y = workspace base; col0 = first column of this chain group, ct = column
 // tiles (1 or 2) of the group
 // alg_bytes: algorithmic bytes of this launch (table once + operand + result), for the live profiler
-// nslab: 1 (unpaired), 2 (+-m pairs) or 4 (the list holds merged tasks)
+// nslab: 1 (unpaired) or 2 (+-m pairs)
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, int flags, const double* X, double* Y, int ncol,
                 int col0, int ct, double alg_bytes, double flops, hipStream_t stream,
                 const GemmAffine& aff = GemmAffine(), Profiler* prof = nullptr);

@@ -105,7 +105,6 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   // masked by a select): the compiler can then count the loads in flight exactly -- with loads behind divergent or
   // data-dependent branches it fell back to s_waitcnt vmcnt(0..2) in the loop and every chunk paid two full memory
   // latencies (one steady-state chunk of the Gram launch: 2 650 cycles, of which 1 330 + 1 170 in those waits).
-  const bool live4 = NSLAB < 4 || t.nslab == 4;   // slabs 2, 3 carry a second transform (merged task)
   const double* sp[IT];   // first operand
   const double* sp2[IT];  // second operand summed in while staging (fused wavelet combine)
   const double* skp[IT];  // per-k operand scale of the thread's slab group
@@ -117,7 +116,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     const int q = q0 % NV;
     const int kr = (q / (COLS / VW)) % KC, col = VW * (q % (COLS / VW));
     const int slab = col / (16 * CT), cin = col % (16 * CT);
-    sv[i] = q0 < NV && (slab < 2 || live4);
+    sv[i] = q0 < NV;
     // (per-thread slab: read from the task in memory -- a runtime index into the register copy would push
     // the whole struct into scratch)
     const int64_t xo = tasks[blockIdx.x].x_off[slab];
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     so[i] = kr * PITCH + col;
   }
   const bool two = TWO && t.x2_off[0] != 0;
-  const bool has_sk0 = SK && t.ks_off[0] != 0, has_sk1 = SK && t.ks_off[NSLAB >= 4 ? 1 : 0] != 0;
+  const bool has_sk = SK && t.ks_off[0] != 0;
   typedef typename std::conditional<VW == 2, double2, double>::type stage_t;
   stage_t st[NSET - 1][IT], st2[NSET - 1][IT];  // operand chunks in flight (register sets, compile-time indices)
   double ssc[NSET - 1][IT];
@@ -153,8 +152,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     stage_t v = st[SET][i];                                                                         \
     if (TWO) v = stage_add(v, st2[SET][i], two);                                                    \
     if (SK) {                                                                                       \
-      const bool hs = (NSLAB >= 4 && (so[i] % PITCH) >= 32 * CT) ? has_sk1 : has_sk0;               \
-      v = stage_scale(v, hs ? ssc[SET][i] : 1.0);                                                   \
+      v = stage_scale(v, has_sk ? ssc[SET][i] : 1.0);                                               \
     }                                                                                               \
     if (sv[i]) *reinterpret_cast<stage_t*>(&xs[BUF][0][0] + so[i]) = v;                             \
   }
@@ -242,7 +240,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
             PXM_GEMM_MFMA(acc[r][c], av, b[h4][c])                                                             \
       }                                                                                                        \
   }
-        if (live4) { PXM_MFMA_CHUNK(NCT) } else { PXM_MFMA_CHUNK((NSLAB == 4 ? NCT / 2 : NCT)) }
+        PXM_MFMA_CHUNK(NCT)
 #undef PXM_MFMA_CHUNK
       }
       PXM_GEMM_CSTAMP(3)  // MFMAs of the chunk issued (table fragment of this chunk had to be there)
@@ -259,7 +257,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   // Epilogue operands first -- the per-row data term of the Gram step and the per-row scale of the fused combine --
   // ALL loads in flight together, then the arithmetic and the stores: one memory latency instead of one per output
   // row (a per-workgroup timeline of the Gram launch showed 5-8 us of its 10-23 us in serial epilogue loads).
-  constexpr int NGRP = NSLAB >= 4 ? 2 : 1;
+  constexpr int NGRP = 1;  // (slab groups: one transform per task)
   double hdv[RT][NSLAB][4], rsv[RT][NGRP][4];
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
@@ -280,7 +278,6 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
       const int slab = c / CT, cin = 16 * (c % CT), grp = slab >> 1;
-      if (slab >= 2 && !live4) continue;
       const double sgn = (slab & 1) ? t.sign1 : 1.0;
       const int rowb = t.row0 + 16 * (RT * wave + r) + kq;
       double* yb = Y + t.y_off[slab] + col0 + cin + cl + (int64_t)rowb * ncol;
@@ -384,7 +381,7 @@ int gemm_rows_per_task(int ncol) {
 int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, int flags, const double* X, double* Y, int ncol,
                 int col0, int ct, double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff, Profiler* prof) {
   if (n_tasks == 0) return 0;
-  PXM_REQUIRE(nslab == 1 || nslab == 2, "launch_gemm: merged (four-slab) task lists are not built any more");
+  PXM_REQUIRE(nslab == 1 || nslab == 2, "launch_gemm: nslab must be 1 (unpaired tables) or 2 (+-m pairs)");
   dim3 grid(n_tasks), block(512);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->gemm, &ev0, &ev1, alg_bytes, flops);
@@ -453,16 +450,13 @@ static void fill_side(GemmTask& g, int grp, const ShtTables& T, int kind, int m,
   (void)kind;
 }
 
-static void append_tasks_impl(const ShtTables& T, int kind, int ncol, const GemmSide* sides, int nsides,
+static void append_tasks_impl(const ShtTables& T, int kind, int ncol, const GemmSide& side,
                               int64_t scratch_off, const double* ws_base, std::vector<GemmTask>& tasks) {
-  // el_lo: harmonic degrees below it carry no signal for a transform (compact support of a wavelet
-  // kernel): the rows (ring->el kinds) or contraction steps (el->ring kinds) below it are skipped.  A merged
-  // task starts at the smaller of its two cuts; rows / steps between the cuts are masked (row_lo) or carry a
-  // zero operand scale for the transform that does not need them.
+  // el_lo: harmonic degrees below it carry no signal for the transform (compact support of a wavelet kernel): the
+  // rows (ring->el kinds) or contraction steps (el->ring kinds) below it are skipped.
   const bool rows_el = kind_rows_are_el(kind), k_el = kind_k_is_el(kind);
   const int Rp = T.Rp;
-  int el_lo = sides[0].el_lo;
-  for (int i = 1; i < nsides; ++i) el_lo = std::min(el_lo, sides[i].el_lo);
+  const int el_lo = side.el_lo;
   const int lo16 = round_down(std::max(el_lo, 0), 16);
   const int rpt = gemm_rows_per_task(ncol);  // row tiles per task
   for (int i = 0; i < T.n_m; ++i) {
@@ -479,8 +473,8 @@ static void append_tasks_impl(const ShtTables& T, int kind, int ncol, const Gemm
       GemmTask g;
       g.tab_off = (T.d_tab[kind] + T.m_off[kind][i] + tab_skip + (int64_t)rt * rt_stride) - ws_base;
       g.rt_stride = rt_stride;
-      for (int s = 0; s < 2; ++s) fill_side(g, s, T, kind, m, ncol, sides[s < nsides ? s : 0], scratch_off, ws_base);
-      g.nslab = nsides == 2 ? 4 : (T.paired ? 2 : 1);
+      for (int s = 0; s < 2; ++s) fill_side(g, s, T, kind, m, ncol, side, scratch_off, ws_base);  // (slab groups 0 and 1 alike)
+      g.nslab = T.paired ? 2 : 1;
       g.k_beg = k_beg;
       g.k_end = k_end;
       g.row0 = row_beg + 16 * rt;
@@ -495,13 +489,7 @@ void append_gemm_tasks(const ShtTables& T, int kind, int ncol, int64_t x_base, i
                        int64_t y_base, int y_L, int y_Rp, const double* kscale, int64_t scratch_off,
                        const double* ws_base, std::vector<GemmTask>& tasks, int el_lo, const GemmFuse& fuse) {
   const GemmSide sd{x_base, y_base, x_L, x_Rp, y_L, y_Rp, kscale, el_lo, fuse};
-  append_tasks_impl(T, kind, ncol, &sd, 1, scratch_off, ws_base, tasks);
-}
-
-void append_gemm_tasks_merged(const ShtTables& T, int kind, int ncol, const GemmSide& a, const GemmSide& b,
-                              int64_t scratch_off, const double* ws_base, std::vector<GemmTask>& tasks) {
-  const GemmSide sides[2] = {a, b};
-  append_tasks_impl(T, kind, ncol, sides, 2, scratch_off, ws_base, tasks);
+  append_tasks_impl(T, kind, ncol, sd, scratch_off, ws_base, tasks);
 }
 
 // ---------------------------------------------------------------------------------------
