@@ -155,44 +155,18 @@ int make_dft_plan(int L, DftPlan* p) {
   PXM_HIP(hipMemcpy(p->d_chirp, b.chirp.data(), b.chirp.size() * sizeof(double), hipMemcpyHostToDevice));
   PXM_HIP(hipMemcpy(p->d_bhat, b.bhat.data(), b.bhat.size() * sizeof(double), hipMemcpyHostToDevice));
   PXM_HIP(hipMemcpy(p->d_tw, b.tw.data(), b.tw.size() * sizeof(double), hipMemcpyHostToDevice));
-  // default for L <= 256: eight points per lane (dft5.hip); PXM_DFT_NO_V=1 selects the 16-points-per-lane wave path
-  if (dft5_r0(b.n) && !getenv("PXM_DFT_NO_V") && !getenv("PXM_DFT_NO_W")) {
+  // L <= 256: eight points per lane, a pair of waves per ring set (dft5.hip); PXM_DFT_NO_W=1: the radix-2 in-LDS
+  // kernels of this file for every size (independent implementation, kept as the L > 512 path and as a cross-check)
+  if (dft5_r0(b.n) && !getenv("PXM_DFT_NO_W")) {
     int rc = dft5_make_tables(b.n, &p->t5);
     if (rc) return rc;
     dft5_geometry(b.n, &p->R5, &p->TR5, &p->lds5);
     p->use5 = true;
   }
-  if (b.n > 512 && b.n <= 1023 && !getenv("PXM_DFT_NO_Q") && !getenv("PXM_DFT_NO_W") && !getenv("PXM_DFT_NO_W2")) {
+  if (b.n > 512 && b.n <= 1023 && !getenv("PXM_DFT_NO_W")) {
     int rc = dft6_make_tables(b.n, &p->t6);  // 256 < L <= 512: four waves per ring, 8 points per lane
     if (rc) return rc;
     p->use6 = true;
-  }
-  const int M3 = getenv("PXM_DFT_NO_W") ? 0 : dft3_size(b.n);
-  if (M3) {  // wave path: square size, its own filter transform and twiddle matrix
-    BluesteinTables b3 = (M3 == b.M) ? b : make_bluestein(b.n, M3);
-    int rc = dft3_make_tables(b3, &p->d_bhatn3, &p->d_twm3);
-    if (rc) return rc;
-    const char* e3 = getenv("PXM_DFT_R3");
-    p->M3 = M3;
-    dft3_geometry(M3, b.n, e3 ? atoi(e3) : 0, &p->R3, &p->TR3, &p->lds3);
-    p->use3 = true;
-  }
-  if (!M3 && b.M == 2048 && !getenv("PXM_DFT_NO_W") && !getenv("PXM_DFT_NO_W2")) {  // two waves per ring
-    std::vector<double> bn(2 * (size_t)b.M);
-    for (int i = 0; i < b.M; ++i) {  // b.bhat is in bit-reversed order
-      int r = 0;
-      for (int bit = 0; bit < b.logM; ++bit) r |= ((i >> bit) & 1) << (b.logM - 1 - bit);
-      bn[2 * (size_t)r] = b.bhat[2 * (size_t)i];
-      bn[2 * (size_t)r + 1] = b.bhat[2 * (size_t)i + 1];
-    }
-    PXM_HIP(hipMalloc(&p->d_bhatn4, bn.size() * sizeof(double)));
-    PXM_HIP(hipMemcpy(p->d_bhatn4, bn.data(), bn.size() * sizeof(double), hipMemcpyHostToDevice));
-    BluesteinTables b1k = make_bluestein(2, 1024);  // only its size matters: the 32 x 32 W_1024 twiddle matrix
-    double* unused = nullptr;
-    int rc = dft3_make_tables(b1k, &unused, &p->d_twm4);
-    if (rc) return rc;
-    deferred_free(unused);
-    p->use4 = true;
   }
   static bool attr_set = false;
   if (!attr_set) {
@@ -209,12 +183,7 @@ void free_dft_plan(DftPlan* p) {
   if (p->d_chirp) deferred_free(p->d_chirp);
   if (p->d_bhat) deferred_free(p->d_bhat);
   if (p->d_tw) deferred_free(p->d_tw);
-  if (p->d_bhatn3) deferred_free(p->d_bhatn3);
-  if (p->d_twm3) deferred_free(p->d_twm3);
-  if (p->d_bhatn4) deferred_free(p->d_bhatn4);
-  if (p->d_twm4) deferred_free(p->d_twm4);
-  p->d_bhatn4 = p->d_twm4 = nullptr;
-  p->d_chirp = p->d_bhat = p->d_tw = p->d_bhatn3 = p->d_twm3 = nullptr;
+  p->d_chirp = p->d_bhat = p->d_tw = nullptr;
 }
 
 static DftArgs make_args(const DftPlan& p) {
@@ -233,9 +202,7 @@ static DftArgs make_args(const DftPlan& p) {
 
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream) {
   if (p.use5) return dft5_px2ring(p, in, G, ncol, C, stream);
-  if (p.use3) return dft3_px2ring(p, in, G, ncol, C, stream);
   if (p.use6) return dft6_px2ring(p, in, G, ncol, C, stream);
-  if (p.use4) return dft4_px2ring(p, in, G, ncol, C, stream);
   const int Cp = ncol / 2;
   dim3 grid(p.L, (Cp + p.R - 1) / p.R), block(p.threads);
   hipLaunchKernelGGL(k_px2ring, grid, block, p.lds, stream, make_args(p), in, G, ncol, C);
@@ -245,15 +212,12 @@ int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C,
 
 int launch_ring2px2ring(const DftPlan& p, double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
   if (p.use5) return dft5_ring2px(p, G, ncol, out, C, stream, true);
-  if (p.use3) return dft3_ring2px(p, G, ncol, out, C, stream, true);
   return 1;
 }
 
 int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t stream) {
   if (p.use5) return dft5_ring2px(p, G, ncol, out, C, stream);
-  if (p.use3) return dft3_ring2px(p, G, ncol, out, C, stream);
   if (p.use6) return dft6_ring2px(p, G, ncol, out, C, stream);
-  if (p.use4) return dft4_ring2px(p, G, ncol, out, C, stream);
   dim3 grid(p.L, (C + p.R - 1) / p.R), block(p.threads);
   hipLaunchKernelGGL(k_ring2px, grid, block, p.lds, stream, make_args(p), G, ncol, out, C);
   PXM_HIP(hipGetLastError());

@@ -7,7 +7,7 @@
 // A PAIR of waves owns a ring set of RPW = 8 / r0 rings (one ring of 512 slots, two of 256, ...): wave 0 runs the
 // even-bin convolution, wave 1 the odd-bin one, each with 8 complex points per lane; they exchange their shares
 // through LDS (workgroup barrier) and each finishes FOUR of the eight elements a lane holds (epilogue, Philox).
-// 84-127 VGPR, no spills: 4 waves per SIMD -- the one-wave M = 1024 kernels of dft3.hip hold 16 points per lane at
+// 84-127 VGPR, no spills: 4 waves per SIMD -- the one-wave M = 1024 kernels of round 1 (dft3.hip, removed) held 16 points per lane at
 // 203 VGPR, 2 waves per SIMD, and were bound by VALU issue latency at that occupancy with 1.5x the instructions
 // (DESIGN.md section 9).  Inside a wave every transpose of the transform needs wave-local ordering only.
 //
@@ -1030,7 +1030,7 @@ int dft5_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, 
 
 // ---- grouped launch (wavelet plan: every scale in one grid) -----------------------------------------------------
 int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
-                      const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out) {
+                      const std::vector<int64_t>& ring0, int ncol, DftGroupList* out) {
   // members: the scales on the eight-points-per-lane path that share the workgroup shape of the largest of them
   // (the others keep their own launches); longest workgroups first, the smaller scales fill the tail
   std::vector<int> order;
@@ -1083,7 +1083,13 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
   return 0;
 }
 
-int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st, Profiler* prof) {
+void dft_group_destroy(DftGroupList* g) {
+  if (g->d) deferred_free(g->d);
+  g->d = nullptr;
+  g->n = 0;
+}
+
+int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st, Profiler* prof) {
   // algorithmic bytes: rings read + written (16 B per slot and coefficient, every padded slot), state read, new state
   // written (live slots), thresholds read once
   const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
@@ -1095,14 +1101,14 @@ int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut&
   return 0;
 }
 
-int dft5_group_px2ring(const Dft3GroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st) {
+int dft5_group_px2ring(const DftGroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st) {
   hipLaunchKernelGGL(k_px2ring_group5, dim3(g.blocks), dim3(g.threads), g.lds, st, reinterpret_cast<const Dft5Group*>(g.d), g.n,
                      ws, ncol, in, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
-int dft5_group_ring2px(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
+int dft5_group_ring2px(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
   hipLaunchKernelGGL(k_ring2px_group5<false>, dim3(g.blocks), dim3(g.threads), g.lds, st, reinterpret_cast<const Dft5Group*>(g.d),
                      g.n, ws, ncol, out, C);
   PXM_HIP(hipGetLastError());

@@ -391,7 +391,7 @@ struct pxm_wav_plan_s {
   int nside = 2;
   bool plain_group = true;  // blocks <-> rings of the member scales in one grid (PXM_NO_PLAIN_DFT_GROUP=1: per scale)
   std::vector<int> lane_of;  // per scale: -1 = caller's stream, else side stream index
-  Dft3GroupList dft_group;   // every scale's rings -> X' -> rings kernel in one grid (ring-space step)
+  DftGroupList dft_group;   // every scale's rings -> X' -> rings kernel in one grid (ring-space step)
   // weak-lensing attachment (pxm_wav_wl_attach): spin-2 ring tables at L, their ring array, the harmonic kernel
   ShtTables* T2 = nullptr;
   int64_t offG2 = 0;
@@ -609,9 +609,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
     std::vector<const DftPlan*> dp;
     for (int s = 0; s < p->nsc; ++s) dp.push_back(&p->dft[s]);
     rc = dft5_group_create(dp, p->offG, p->coef_off, p->ncol, &p->dft_group);
-    if (rc == 1) rc = dft3_group_create(dp, p->offG, p->coef_off, p->ncol, &p->dft_group);
     if (rc < 0) return rc;  // rc == 1: no group -> per-scale launches
-    if (p->dft_group.d && !p->dft_group.five) p->dft_group.all = true;  // (the dft3 group is all scales or nothing)
   }
   *plan = guard.release();
   return 0;
@@ -621,7 +619,7 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   if (!p) return 0;
   // Nothing is freed here directly: device memory and events go to the graveyard, which is emptied at once unless
   // a stream capture is in progress (the garbage collector may run this in the middle of one).
-  dft3_group_destroy(&p->dft_group);
+  dft_group_destroy(&p->dft_group);
   for (auto& d : p->dft) free_dft_plan(&d);
   free_dft_plan(&p->dftL);
   deferred_free(p->ws);
@@ -839,8 +837,7 @@ static bool wav_can_fuse_dft(pxm_wav_plan_t p) {
 static int wav_rings_update_rings(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
   if (p->dft_group.d && p->dft_group.all) {  // one grid for every scale, small scales first
     proto.chain_stride = p->ncoefs;
-    if (p->dft_group.five) return dft5_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof);
-    return dft3_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof);
+    return dft5_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof);
   }
   bool used[pxm_wav_plan_s::NSIDE];
   int rc = wav_fork(p, st, used);
@@ -988,7 +985,7 @@ int pxm_wav_image_step(pxm_wav_plan_t p, const void* X, const void* data, const 
   PxOut po;
   po.f = (double*)preds_out;
   po.chain_stride = (int64_t)p->L * (2 * p->L - 1);
-  if ((p->dftL.use5 || p->dftL.use3) && p->fused_dft) {  // (only the wave paths implement the residual epilogue)  // rings -> preds -> residual -> rings, one kernel
+  if (p->dftL.use5 && p->fused_dft) {  // (only the wave paths implement the residual epilogue)  // rings -> preds -> residual -> rings, one kernel
     image_residual(po, data, invcov, invcov_complex);
     rc = launch_ring2px2ring(p->dftL, p->ws + p->offGL, p->ncol, po, C, st);
     return rc < 0 ? rc : (rc ? -1 : 0);

@@ -185,11 +185,6 @@ struct DftPlan {
   int threads = 0;  // workgroup size
   size_t lds = 0;
   double *d_chirp = nullptr, *d_bhat = nullptr, *d_tw = nullptr;
-  // wave path (dft3.hip): square Bluestein size M3 in {16, 64, 256, 1024}, used for every L <= 256
-  bool use3 = false;
-  int M3 = 0, R3 = 0, TR3 = 0;  // R3 chains x TR3 rings per workgroup
-  size_t lds3 = 0;
-  double *d_bhatn3 = nullptr, *d_twm3 = nullptr;
   // eight-points-per-lane path (dft5.hip): M = 2 Mh, two half-size convolutions per wave, every L <= 256 (default)
   bool use5 = false;
   Dft5Tables t5;
@@ -198,9 +193,6 @@ struct DftPlan {
   // four waves per ring (dft5.hip, k_*6): M = 2048 = 4 x 512 for 256 < L <= 512 (default there)
   bool use6 = false;
   Dft6Tables t6;
-  // two-wave path (dft3.hip, k_*4): M = 2048 for 256 < L <= 512
-  bool use4 = false;
-  double *d_bhatn4 = nullptr, *d_twm4 = nullptr;  // FFT_2048(filter)/2048 natural order; 32 x 32 W_1024 table
 };
 
 int make_dft_plan(int L, DftPlan* p);
@@ -243,11 +235,8 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
   const double* gw = nullptr;
 };
 
-// device tables of the wave paths for a square (or M = 2 x square) Bluestein size: the filter transform in
-// natural order and the [N1][N1] twiddle matrix W_M^(k1 j2)
-int dft3_make_tables(const BluesteinTables& b, double** d_bhatn, double** d_twm);
-// grouped launch of every scale's rings -> X' -> rings kernel (dft3.hip)
-struct Dft3GroupList {
+// grouped launches of a wavelet plan's member scales (dft5.hip): one grid for every scale
+struct DftGroupList {
   void* d = nullptr;  // device array of per-scale descriptors
   bool five = false;  // descriptors of the eight-points-per-lane kernel (dft5.hip)
   int threads = 512;  // ... and its workgroup size
@@ -257,11 +246,7 @@ struct Dft3GroupList {
   std::vector<char> member;  // per scale: its rings <-> pixels launches are part of this group
   bool all = false;          // every scale is a member (needed by the fused rings -> X' -> rings step)
 };
-int dft3_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
-                      const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available
-void dft3_group_destroy(Dft3GroupList* g);
-int dft3_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
-                      Profiler* prof = nullptr);
+void dft_group_destroy(DftGroupList* g);
 // eight-points-per-lane path (dft5.hip)
 int dft5_r0(int n);  // Mh / 64 for ring length n, 0 = not covered (n > 512)
 int dft5_make_tables(int n, Dft5Tables* t);
@@ -269,21 +254,15 @@ void dft5_geometry(int n, int* R, int* TR, size_t* lds);
 int dft5_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft5_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
 int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
-                      const std::vector<int64_t>& ring0, int ncol, Dft3GroupList* out);  // 1 = not available
-int dft5_group_launch(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
+                      const std::vector<int64_t>& ring0, int ncol, DftGroupList* out);  // 1 = not available
+int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
                       Profiler* prof = nullptr);
 // the plain transforms of every member scale in one grid each (blocks <-> rings of the generic wavelet operators)
-int dft5_group_px2ring(const Dft3GroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st);
-int dft5_group_ring2px(const Dft3GroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st);
+int dft5_group_px2ring(const DftGroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st);
+int dft5_group_ring2px(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st);
 int dft6_make_tables(int n, Dft6Tables* t);
 int dft6_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft6_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
-int dft4_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
-int dft4_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st);
-int dft3_size(int n);  // square Bluestein size of the wave path for ring length n, 0 = none
-void dft3_geometry(int M, int n, int R_want, int* R, int* TR, size_t* lds);
-int dft3_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
-int dft3_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
 
 // f(t,p) -> G[m][t][c]  (unnormalised, e^{-i m phi});  G -> f (e^{+i m phi})
 int launch_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t stream);
@@ -291,7 +270,7 @@ int launch_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out
 // fused: rings -> out.f (with out's epilogue) and the rings of what was written, in place over G.
 // Returns 1 (nothing launched) when the plan's DFT size has no fused kernel.
 int launch_ring2px2ring(const DftPlan& p, double* G, int ncol, const PxOut& out, int C, hipStream_t stream);
-inline bool dft_can_fuse(const DftPlan& p) { return p.use5 || p.use3; }
+inline bool dft_can_fuse(const DftPlan& p) { return p.use5; }
 
 // ---- layout repack (public harmonic layout el^2+el+m <-> internal [m][el][c]) ----------
 int launch_lm_to_mel(const double* flm, double* H, int L, int Rp, int ncol, int C, int spin, hipStream_t stream);

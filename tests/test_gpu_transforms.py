@@ -111,10 +111,10 @@ def test_full_size_properties_L256():
     assert (one - wav.synthesis(X)[3]).abs().max() == 0
 
 
-def test_two_wave_dft_path_L_above_256(monkeypatch):
-    """256 < L <= 512: the phi-DFT runs as four waves per ring (M = 2048 = 4 x 512, 8 points per lane; default) or as
-    two waves per ring (M = 2048 = 2 x 1024, PXM_DFT_NO_Q=1).  Same results as the radix-2 in-LDS fallback kernel,
-    exact round trip, adjoint dot tests, and the fused residual / MYULA epilogues."""
+def test_four_wave_dft_path_L_above_256(monkeypatch):
+    """256 < L <= 512: the phi-DFT runs as four waves per ring (M = 2048 = 4 x 512, 8 points per lane).  Same results
+    as the independent radix-2 in-LDS kernels (PXM_DFT_NO_W=1, the L > 512 path), exact round trip, adjoint dot
+    tests, and the fused residual / MYULA epilogues."""
     import torch
 
     from pxmcmc_amd import ops
@@ -124,16 +124,12 @@ def test_two_wave_dft_path_L_above_256(monkeypatch):
     flm = torch.randn(C, L * L, dtype=torch.complex128, generator=g)
     x = torch.randn(C, L * (2 * L - 1), dtype=torch.complex128, generator=g)
     fast = ops.ShtPlan(L, 0, max_chains=C)
-    monkeypatch.setenv("PXM_DFT_NO_Q", "1")
-    two = ops.ShtPlan(L, 0, max_chains=C)
-    monkeypatch.delenv("PXM_DFT_NO_Q")
-    monkeypatch.setenv("PXM_DFT_NO_W2", "1")
+    monkeypatch.setenv("PXM_DFT_NO_W", "1")
     slow = ops.ShtPlan(L, 0, max_chains=C)
-    monkeypatch.delenv("PXM_DFT_NO_W2")
+    monkeypatch.delenv("PXM_DFT_NO_W")
     for name, arg in (("inverse", flm), ("forward_adjoint", flm), ("forward", x), ("inverse_adjoint", x)):
-        a, a2, b = getattr(fast, name)(arg), getattr(two, name)(arg), getattr(slow, name)(arg)
+        a, b = getattr(fast, name)(arg), getattr(slow, name)(arg)
         assert float((a - b).abs().max()) < 1e-11 * float(b.abs().max()), name
-        assert float((a2 - b).abs().max()) < 1e-11 * float(b.abs().max()), name
     f = fast.inverse(flm)
     assert float((fast.forward(f).cpu() - flm).abs().max()) < 1e-10 * float(flm.abs().max())
     for fwd, adj, a, b in ((fast.inverse, fast.inverse_adjoint, flm, x), (fast.forward, fast.forward_adjoint, x, flm)):
@@ -159,8 +155,8 @@ def test_two_wave_dft_path_L_above_256(monkeypatch):
 @pytest.mark.parametrize("L", [4, 10, 33, 64, 100, 128, 200, 256])
 def test_dft_kernel_variants_agree_and_match_oracle(L, monkeypatch):
     """The phi-DFT of every L <= 256 has two kernels: eight points per lane, one half-size convolution per wave
-    (default, csrc/dft5.hip; also with 2 chains per workgroup, PXM_DFT_R=2), and the 16-points-per-lane wave path
-    (PXM_DFT_NO_V=1, csrc/dft3.hip).  All four SHT operators through each of them match the oracle; L covers every
+    (default, csrc/dft5.hip; also with 2 chains per workgroup, PXM_DFT_R=2), and the independent radix-2 in-LDS
+    kernels (PXM_DFT_NO_W=1, csrc/dft.hip).  All four SHT operators through each of them match the oracle; L covers every
     Mh = 64 ... 512 (8, 4, 2, 1 rings per wave pair) and lengths that are not powers of two."""
     from oracle import ssht
     from pxmcmc_amd import ops
@@ -176,7 +172,7 @@ def test_dft_kernel_variants_agree_and_match_oracle(L, monkeypatch):
         "forward": np.stack([T.forward(x) for x in f]),
         "inverse_adjoint": np.stack([T.inverse_adjoint(x) for x in f]),
     }
-    for env in ({}, {"PXM_DFT_R": "2"}, {"PXM_DFT_NO_V": "1"}):
+    for env in ({}, {"PXM_DFT_R": "2"}, {"PXM_DFT_NO_W": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         plan = ops.ShtPlan(L, spin, max_chains=C)
