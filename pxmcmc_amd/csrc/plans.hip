@@ -44,7 +44,7 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
   // (almost) resident at once and the per-CU bins win (L=256: 24.5 vs 26.5 us Gram, 31.4 vs 32.1 us groups); with
   // many rounds per slot the queues win (L=512: 200 vs 218 us, 218 vs 231 us).
   const char* order_env = getenv("PXM_GEMM_ORDER");
-  const std::string order = getenv("PXM_GEMM_PLAIN_ORDER") ? "plain" : (order_env ? order_env : (v.size() > 2048 ? "xcd" : "bins"));
+  const std::string order = order_env ? order_env : (v.size() > 2048 ? "xcd" : "bins");
   const int64_t fixed = order == "xcd" ? 32 : 0;  // start-up / drain of a task in contraction steps
   auto work = [fixed](const GemmTask& a) { return (int64_t)(a.k_end - a.k_beg + fixed) * a.n_rt; };
   std::stable_sort(v.begin(), v.end(), [&](const GemmTask& a, const GemmTask& b) { return work(a) > work(b); });
