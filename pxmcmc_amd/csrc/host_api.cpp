@@ -82,7 +82,7 @@ int drain_deferred() {
 
 extern "C" {
 
-int pxm_version(void) { return 200; }
+int pxm_version(void) { return 210; }  // 2.1: + pxm_myula_step_it, pxm_chain_step_it, pxm_csr_matvec_batched
 
 int pxm_capture_begin(void) {
   std::lock_guard<std::mutex> lock(pxm::g_grave_mu);
