@@ -154,6 +154,51 @@ def parity_leg(plan, data, T_dev, T, delta, n_iter=3, chains=(0, 9), C=CHAINS_PE
     return err
 
 
+def live_traffic(timeout_s=120):
+    """HBM bytes per k_sht_gemm launch of the timed steps, measured NOW: two child runs of this script under
+    ``rocprofv3 --pmc`` (FETCH_SIZE, then WRITE_SIZE: separate passes, MI355X_MICROARCH.md section HBM), started before
+    this process touches the GPU.  KiB units; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads
+    (doubled here), WRITE_SIZE is taken as is.  Returns (bytes per launch, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3")
+    if not rocprof:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    t0 = time.perf_counter()
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pxm_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "10", "--warmup", "2", "--ramp", "0", "--no-cpu-baseline", "--no-layout-compare", "--no-live-traffic"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s"
+        files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+        per = []
+        if r.returncode == 0 and files:
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    # the GEMM launches of the timed steps: real pairs, +-m pairs, any operand flags
+                    if row["Counter_Name"] == counter and "k_sht_gemm<1, 2, 8, 1, 2," in row["Kernel_Name"]:
+                        per.append(float(row["Counter_Value"]))
+        shutil.rmtree(d, ignore_errors=True)
+        if not per:
+            return None, f"rocprofv3 --pmc {counter} pass gave no k_sht_gemm records (exit {r.returncode})"
+        vals[counter] = (sum(per) / len(per), len(per))
+    rd = 2 * 1024 * vals["FETCH_SIZE"][0]
+    wr = 1024 * vals["WRITE_SIZE"][0]
+    return rd + wr, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command with --steps 10 "
+                     f"({vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} k_sht_gemm launches, {rd / 1e6:.1f} MB read + {wr / 1e6:.1f} MB "
+                     f"written per launch, {time.perf_counter() - t0:.0f} s)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,7 +210,14 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = min(cores, 16))")
     ap.add_argument("--no-real-pairs", action="store_true", help="one complex128 slot per chain (reference layout)")
     ap.add_argument("--no-layout-compare", action="store_true", help="skip the reference-layout side measurement")
+    ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/pmc_summary.json instead of two rocprofv3 --pmc child passes")
     args = ap.parse_args()
+
+    # PMC traffic of the dominant kernel, live: before anything here initialises the GPU (the children are ordinary
+    # child processes of a process that holds no GPU state yet); N = 1 only, like the CPU legs
+    live = (None, None)
+    if not args.no_live_traffic and not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1:
+        live = live_traffic()
 
     import torch
     import torch.distributed as dist
@@ -287,12 +339,13 @@ def main():
         value = world * C * args.steps / dt
         gemm_avg_us = ms.value * 1e3 / max(nl.value, 1)
         achieved = nb.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
-        traffic, traffic_src = None, None
+        traffic, traffic_src = live
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):  # PMC counters need their own rocprofv3 passes: a committed, static figure
+        if traffic is None and os.path.exists(pmc):  # no live passes (flag, N > 1, or they failed): the committed figure
+            live_note = f"; live passes: {live[1]}" if live[1] else ""
             with open(pmc) as fh:
                 traffic = json.load(fh).get("k_sht_gemm_hbm_bytes_per_launch")
-            traffic_src = "profiles/pmc_summary.json (static: rocprofv3 --pmc passes of this command, not measured in this run)"
+            traffic_src = "profiles/pmc_summary.json (static: rocprofv3 --pmc passes of this command, not measured in this run)" + live_note
         out = {
             "metric": "MYULA samples/sec at L=256 synthesis",
             "value": value,
