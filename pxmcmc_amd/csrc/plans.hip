@@ -118,6 +118,10 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
   out->paired = paired;
   out->nslab = paired ? 2 : 1;
   for (const GemmTask& t : v) {
+    // shape invariants the kernel relies on (its clamped prefetches stay inside the task's own rows and chunks)
+    PXM_REQUIRE(t.n_rt >= 0 && t.n_rt <= 8 && t.row0 >= 0 && t.row0 % 16 == 0 && t.k_beg >= 0 && t.k_beg % 16 == 0 &&
+                    (t.n_rt == 0 || (t.k_end > t.k_beg && (t.k_end - t.k_beg) % 16 == 0)),
+                "upload_tasks: malformed GEMM task");
     out->mfma_units += (double)t.n_rt * ((t.k_end - t.k_beg) / 4) * t.nslab;
     for (int sl = 0; sl < 4; ++sl)
       if (t.x2_off[sl]) out->flags |= 1;
