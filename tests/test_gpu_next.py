@@ -281,3 +281,31 @@ def test_csr_matvec_chain_batches_are_bit_equal_to_single_chains(cplx_mat, cplx_
         assert torch.equal(torch.view_as_real(got) if got.is_complex() else got, torch.view_as_real(one) if one.is_complex() else one)
         ref = (A @ X.T).T
         np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=1e-12, atol=1e-13)
+
+
+def test_generic_engine_complex_noise_and_identity_operators():
+    """The generic stepping engine with params.complex = True (complex Philox noise through pxm_myula_step_it) and with
+    the toy identity operators of BASELINE config 1: graph replay equals the eager loop bit for bit, and the imaginary
+    part of the state carries noise of the expected size."""
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.measurements import Identity
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import L1
+    from pxmcmc_amd.transforms import IdentityTransform
+
+    n = 1024
+    rng = np.random.default_rng(3)
+    data = rng.normal(size=n) + 1j * rng.normal(size=n)
+    runs = []
+    for use_graph in (True, False):
+        op = ForwardOperator(data, 0.5, "synthesis", IdentityTransform(), Identity(n, n), nparams=n)
+        reg = L1("synthesis", None, None, 1e-3)
+        p = PxMCMCParams(lmda=1e-3, delta=2e-4, mu=1.0, nsamples=5, nburn=4, ngap=7, complex=True, verbosity=0)
+        s = MYULA(op, reg, p, nchains=2, rng="philox", seed=5, use_graph=use_graph)
+        _quiet(s.run, start_point=np.zeros(n))
+        assert getattr(s, "used_graph", False) == use_graph, getattr(s, "graph_error", None)
+        runs.append(s)
+    g, e = runs
+    np.testing.assert_array_equal(np.asarray(g.chain), np.asarray(e.chain))
+    Xc = np.asarray(g.X_curr.cpu())
+    assert np.iscomplexobj(Xc) and Xc.imag.std() > 0.3 * Xc.real.std() > 0

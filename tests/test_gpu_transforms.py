@@ -263,3 +263,29 @@ def test_grouped_plain_dft_launches_match_per_scale_launches(L, B, monkeypatch):
         outs.append(res)
     for a, b in zip(*outs):
         assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
+
+
+def test_padding_chain_columns_stay_zero_after_partial_batches():
+    """A plan built for 6 chains and used with 1 and 3: chain groups without a live chain do not run in the pixels ->
+    rings kernels, the last live group zero-fills the padding slots of its ring lines, so the workspace stays finite and
+    the live chains equal the single-chain results bit for bit whatever ran before."""
+    import torch
+
+    from pxmcmc_amd import ops
+
+    L = 24
+    wav = ops.WavPlan(L, 2, 2, max_chains=6)
+    one = ops.WavPlan(L, 2, 2, max_chains=1)
+    g = torch.Generator().manual_seed(2)
+    X6 = torch.randn(6, wav.ncoefs, dtype=torch.complex128, generator=g).cuda()
+    f6 = torch.randn(6, wav.npix, dtype=torch.complex128, generator=g).cuda()
+    wav.synthesis(X6), wav.synthesis_adjoint(f6)  # fills every chain slot of the workspace
+    for C in (1, 3):
+        got_s, got_a = wav.synthesis(X6[:C]), wav.synthesis_adjoint(f6[:C])
+        got_n, got_b = wav.analysis(f6[:C]), wav.analysis_adjoint(X6[:C])
+        assert wav.workspace_nonfinite() == 0
+        for c in range(C):
+            assert torch.equal(torch.view_as_real(got_s[c]), torch.view_as_real(one.synthesis(X6[c])))
+            assert torch.equal(torch.view_as_real(got_a[c]), torch.view_as_real(one.synthesis_adjoint(f6[c])))
+            assert torch.equal(torch.view_as_real(got_n[c]), torch.view_as_real(one.analysis(f6[c])))
+            assert torch.equal(torch.view_as_real(got_b[c]), torch.view_as_real(one.analysis_adjoint(X6[c])))
