@@ -7,8 +7,12 @@ pxmcmc/mcmc.py:158-161) of a batch of 16 chains per GPU: spherical-wavelet synth
 operator (L=256, B=2, J_min=2), identity measurement, S2_Wavelets_L1 prox, complex128 state
 (the reference's layout), synthetic band-limited data already resident in HBM.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N=1)
+    python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Started plainly with --gpus N > 1 (no torchrun environment) the script launches its own N ranks as a child
+``python -m torch.distributed.run`` BEFORE it imports torch or touches the GPU, relays rank 0's JSON line and
+returns the child's exit code.
 
 Prints ONE JSON line on rank 0 with the throughput, the roofline of the dominant kernel
 (the SHT ring GEMM, timed live with HIP events on its own stream) and the CPU baseline
@@ -118,6 +122,66 @@ def cpu_baseline(data, T, n_iter, delta, procs=1):
     return procs * n_iter / wall, wall
 
 
+def self_launch(n, argv):
+    """Start the N ranks of ``bench.py --gpus N`` as a child ``python -m torch.distributed.run`` (one rank per GPU,
+    rendezvous on 127.0.0.1 at a free port).  Called before torch is imported: the parent holds no GPU state, the
+    child is an ordinary subprocess (never an exec), rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
+NOISE_NOTES = {
+    32: "philox4x32-10 counter stream, Box-Muller on the f32 transcendental units (v_log_f32 / v_sin_f32 / v_cos_f32, exact "
+        "fp64 exponent: deviates ~1e-6 relative, tail to 8.5 sigma); the reference draws fp64 randn (pxmcmc/mcmc.py:193)",
+    64: "philox4x32-10 counter stream, Box-Muller in fp64 (log / sincospi / sqrt in double)",
+}
+
+NOMINAL_S_NORM2 = 1.35e4  # ||S||^2 at L=256, B=2, J_min=2 (power iteration on the GPU at start-up: checked below)
+
+
+def cpu_legs(args):
+    """Both CPU legs, run BEFORE this process imports torch or initialises the GPU (the worker pool is forked from a
+    process that holds no HIP runtime state).  The oracle operator is built from host data: the same seeded field as
+    the GPU leg, synthesised by the oracle's own inverse SHT (equal to the device-made field to round-off; the timing
+    does not depend on the values).  Returns the ``cpu_baseline`` object of the JSON line."""
+    from oracle import pxmcmc_np as ref
+    from oracle import ssht
+
+    truth, rng = synthetic_field(lambda flm: ssht.inverse(flm, L, 0).ravel(), L, seed=2)
+    data = truth + SIGMA * rng.normal(size=truth.size)
+    T = ref.S2_Wavelets_L1("synthesis", None, None, LMDA * MU, L, int(B), J_MIN).T
+    delta = 0.8 / (NOMINAL_S_NORM2 / SIGMA ** 2 + 1.0 / LMDA)
+    v, secs = cpu_baseline(data, T, args.cpu_iters, delta, procs=1)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = args.cpu_procs or min(ncpu, 32)
+    it_all = max(8, args.cpu_iters // 3)
+    v_all, secs_all = cpu_baseline(data, T, it_all, delta, procs=procs)
+    return {
+        "value": v,
+        "unit": "samples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{args.cpu_iters} MYULA iterations of ONE chain at L=256 (oracle numpy restatement, "
+                  f"table+FFT SHT, BLAS / OpenMP pools pinned to 1 thread, {secs:.1f} s) on this host, before the GPU is touched",
+        "value_all_cores": v_all,
+        "cores_all": procs,
+        "cores_rule": "min(usable cores, 32): the host share of one GPU on an 8-GPU node with 256 cores",
+        "sample_all_cores": f"{procs} independent chains, one single-threaded process each (the reference's --jobid "
+                            f"model), {it_all} iterations per chain, {secs_all:.1f} s wall incl. process start; "
+                            f"host reports {ncpu} usable cores",
+    }
+
+
 def parity_leg(plan, data, T_dev, T, delta, n_iter=3, chains=(0, 9), C=CHAINS_PER_GPU):
     """Full-size parity on the box the benchmark runs on: n_iter iterations of the benchmarked step (ring-space +
     Gram + real pairs) with injected noise against the oracle's literal loop on the same noise.  Returns the max
@@ -158,45 +222,70 @@ def live_traffic(timeout_s=120):
     """HBM bytes per k_sht_gemm launch of the timed steps, measured NOW: two child runs of this script under
     ``rocprofv3 --pmc`` (FETCH_SIZE, then WRITE_SIZE: separate passes, MI355X_MICROARCH.md section HBM), started before
     this process touches the GPU.  KiB units; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads
-    (doubled here), WRITE_SIZE is taken as is.  Returns (bytes per launch, description) or (None, reason)."""
+    (doubled here), WRITE_SIZE is taken as is.  Returns (bytes per launch, description, per-launch-class list) or
+    (None, reason, None)."""
     import csv
     import glob
     import shutil
+    import signal
     import subprocess
     import tempfile
 
     rocprof = shutil.which("rocprofv3")
     if not rocprof:
-        return None, "rocprofv3 not on PATH"
+        return None, "rocprofv3 not on PATH", None
     vals = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pxm_pmc_", dir="/tmp")
         cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                "--steps", "10", "--warmup", "2", "--ramp", "0", "--no-cpu-baseline", "--no-layout-compare", "--no-live-traffic"]
+        # own session: on a timeout the whole group (rocprofv3 AND the profiled python) is killed and waited for
+        # before this process goes near the GPU
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                stderr=subprocess.DEVNULL, start_new_session=True)
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=timeout_s)
+            rc = proc.wait(timeout=timeout_s)
         except subprocess.TimeoutExpired:
+            with contextlib.suppress(ProcessLookupError):
+                os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait()
+            time.sleep(1.0)
             shutil.rmtree(d, ignore_errors=True)
-            return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s"
+            return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s", None
         files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
-        per = []
-        if r.returncode == 0 and files:
+        per = {}
+        if rc == 0 and files:
             with open(files[0]) as fh:
                 for row in csv.DictReader(fh):
-                    # the GEMM launches of the timed steps: real pairs, +-m pairs, any operand flags
-                    if row["Counter_Name"] == counter and "k_sht_gemm<1, 2, 8, 1, 2," in row["Kernel_Name"]:
-                        per.append(float(row["Counter_Value"]))
+                    # every ring-GEMM launch, keyed by launch class = (kernel variant, workgroups): the child's steps
+                    # launch the same three classes as the timed region (Gram, forward-adjoint group, forward group);
+                    # the set-up launches of other variants / grids are dropped when the classes are joined below
+                    if row["Counter_Name"] == counter and row["Kernel_Name"].startswith("void pxm::k_sht_gemm<"):
+                        wgs = int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1)
+                        per.setdefault((row["Kernel_Name"].split("(")[0], wgs), []).append(float(row["Counter_Value"]))
         shutil.rmtree(d, ignore_errors=True)
         if not per:
-            return None, f"rocprofv3 --pmc {counter} pass gave no k_sht_gemm records (exit {r.returncode})"
-        vals[counter] = (sum(per) / len(per), len(per))
-    rd = 2 * 1024 * vals["FETCH_SIZE"][0]
-    wr = 1024 * vals["WRITE_SIZE"][0]
-    return rd + wr, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command with --steps 10 "
-                     f"({vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} k_sht_gemm launches, {rd / 1e6:.1f} MB read + {wr / 1e6:.1f} MB "
-                     f"written per launch, {time.perf_counter() - t0:.0f} s)")
+            return None, f"rocprofv3 --pmc {counter} pass gave no k_sht_gemm records (exit {rc})", None
+        vals[counter] = per
+    # classes of the stepping loop: the ones launched (almost) once per step of the 12-step child
+    steps_seen = 10
+    classes = {}
+    for key, rd_list in vals["FETCH_SIZE"].items():
+        wr_list = vals["WRITE_SIZE"].get(key)
+        if wr_list is None or len(rd_list) < steps_seen:
+            continue
+        rd = 2 * 1024 * sum(rd_list) / len(rd_list)
+        wr = 1024 * sum(wr_list) / len(wr_list)
+        classes[key] = {"kernel": key[0].replace("void pxm::", ""), "workgroups": key[1], "launches": len(rd_list),
+                        "read_MB": rd / 1e6, "write_MB": wr / 1e6, "hbm_MB": (rd + wr) / 1e6}
+    if not classes:
+        return None, "rocprofv3 --pmc passes gave no per-step k_sht_gemm launch class", None
+    n = sum(c["launches"] for c in classes.values())
+    total = sum(c["hbm_MB"] * c["launches"] for c in classes.values()) * 1e6 / n
+    return total, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command with --steps 10 "
+                   f"({n} k_sht_gemm launches of {len(classes)} per-step launch classes, FETCH_SIZE x2 gfx950 correction, "
+                   f"{time.perf_counter() - t0:.0f} s)"), sorted(classes.values(), key=lambda c: c["workgroups"])
 
 
 def main():
@@ -213,10 +302,18 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/pmc_summary.json instead of two rocprofv3 --pmc child passes")
     args = ap.parse_args()
 
-    # PMC traffic of the dominant kernel, live: before anything here initialises the GPU (the children are ordinary
-    # child processes of a process that holds no GPU state yet); N = 1 only, like the CPU legs
-    live = (None, None)
-    if not args.no_live_traffic and not args.no_cpu_baseline and int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1:
+    # --gpus N > 1 without a torchrun environment: this process has not imported torch nor touched the GPU -- it
+    # starts the N ranks as a CHILD torchrun (never an exec), lets rank 0's JSON line through on the inherited
+    # stdout and leaves with the child's exit code
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
+    # CPU legs and the PMC traffic of the dominant kernel, live: before anything here initialises the GPU (the
+    # worker pool / the profiler children are started by a process that holds no GPU state yet); N = 1 only
+    single = int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1
+    cpu = cpu_legs(args) if single and not args.no_cpu_baseline else None
+    live = (None, None, None)
+    if single and not args.no_live_traffic and not args.no_cpu_baseline:
         live = live_traffic()
 
     import torch
@@ -225,8 +322,8 @@ def main():
     from pxmcmc_amd import distributed as D
 
     rank, local_rank, world = D.env_rank_world()
-    if world == 1 and args.gpus > 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} started with WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only compute path")
     # rehearsal aid for a one-GPU box: PXM_BENCH_REHEARSE=1 puts every rank on cuda:0 and uses gloo for the
@@ -269,10 +366,11 @@ def main():
     eng = sampler._engine_start(X, preds, 0)
     barrier = D.barrier
 
-    # Declared clock ramp: the driver's default run times 20 steps = 5 ms, shorter than the time the GPU takes to
-    # reach its sustained clocks from idle; --ramp untimed iterations precede the W warm-up steps (reported below).
-    sampler._engine_advance(args.ramp)
-    sampler._engine_advance(args.warmup)
+    # Clock ramp: the driver's default run times 20 steps = 3 ms, shorter than the time the GPU takes to reach its
+    # sustained clocks from idle; --ramp untimed iterations precede the W requested warm-up steps.  The JSON's
+    # top-level "warmup" is the TOTAL untimed count (ramp + W); config.warmup_requested / clock_ramp_steps split it.
+    untimed = args.ramp + args.warmup
+    sampler._engine_advance(untimed)
     barrier()
     t0 = time.perf_counter()
     sampler._engine_advance(args.steps)
@@ -296,13 +394,13 @@ def main():
     sampler._engine_advance(n_prof)
     eng["graph"], eng["graph_long"] = graphs
     torch.cuda.synchronize()
-    l_ms, l_bytes = plan.profile_read_launches(3 * n_prof + 8)
+    l_ms, l_bytes, l_wgs = plan.profile_read_launches(3 * n_prof + 8)
     plan.profile_enable(0)
-    gemm_classes = []
-    for nbytes in sorted(set(np.round(l_bytes).tolist())):
-        sel = np.round(l_bytes) == nbytes
+    gemm_classes = []  # one per (workgroups, algorithmic bytes): Gram, forward-adjoint group, forward group
+    for wgs, nbytes in sorted(set(zip(l_wgs.tolist(), np.round(l_bytes).tolist()))):
+        sel = (l_wgs == wgs) & (np.round(l_bytes) == nbytes)
         us = float(l_ms[sel].mean() * 1e3)
-        gemm_classes.append({"alg_MB": nbytes / 1e6, "launches": int(sel.sum()), "avg_us": us,
+        gemm_classes.append({"workgroups": int(wgs), "alg_MB": nbytes / 1e6, "launches": int(sel.sum()), "avg_us": us,
                              "GBs": nbytes / us / 1e3, "frac": nbytes / us / 1e3 / HBM_PEAK_GBS})
 
     class _V:  # (keeps the field names of the report below)
@@ -315,6 +413,7 @@ def main():
         assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
 
     dt = D.max_over_ranks(dt)
+    ranks_seen = D.count_ranks()  # all-reduced over the process group (RCCL): the record shows N ranks took part
     used_graph = eng["graph"] is not None
 
     # informative side figure (rank 0, outside the timed region): the same iteration with one complex128 slot
@@ -327,7 +426,7 @@ def main():
         with contextlib.redirect_stdout(io.StringIO()):
             X2, P2 = s2._initial_sample(np.zeros(op.nparams))
         s2._engine_start(X2, P2, 0)
-        s2._engine_advance(args.ramp // 2 + args.warmup)
+        s2._engine_advance(untimed)  # the same untimed count as the main leg
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         s2._engine_advance(args.steps)
@@ -339,20 +438,34 @@ def main():
         value = world * C * args.steps / dt
         gemm_avg_us = ms.value * 1e3 / max(nl.value, 1)
         achieved = nb.value / (ms.value * 1e-3) / 1e9 if ms.value > 0 else 0.0
-        traffic, traffic_src = live
+        traffic, traffic_src, traffic_classes = live
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if traffic is None and os.path.exists(pmc):  # no live passes (flag, N > 1, or they failed): the committed figure
             live_note = f"; live passes: {live[1]}" if live[1] else ""
             with open(pmc) as fh:
                 traffic = json.load(fh).get("k_sht_gemm_hbm_bytes_per_launch")
             traffic_src = "profiles/pmc_summary.json (static: rocprofv3 --pmc passes of this command, not measured in this run)" + live_note
+        # measured HBM rate: PMC bytes of the per-step launch classes (child passes) over the live event time of the
+        # same classes in this process, joined class by class in launch order of size (Gram < groups)
+        measured = None
+        by_wgs = {c["workgroups"]: c for c in traffic_classes or []}
+        if gemm_classes and all(g["workgroups"] in by_wgs for g in gemm_classes):
+            joined = [dict(by_wgs[g["workgroups"]], alg_MB=g["alg_MB"], avg_us=g["avg_us"],
+                           hbm_GBs=by_wgs[g["workgroups"]]["hbm_MB"] / g["avg_us"] * 1e3) for g in gemm_classes]
+            tb = sum(c["hbm_MB"] * 1e6 * g["launches"] for c, g in zip(joined, gemm_classes))
+            tt = sum(g["avg_us"] * 1e-6 * g["launches"] for g in gemm_classes)
+            measured = {"hbm_GBs": tb / tt / 1e9, "hbm_frac": tb / tt / 1e9 / HBM_PEAK_GBS,
+                        "what": "PMC bytes (FETCH_SIZE x2 + WRITE_SIZE, child passes) of each per-step launch class, joined "
+                                "on the workgroup count, / the live event time of the same class in this process",
+                        "classes": joined}
         out = {
             "metric": "MYULA samples/sec at L=256 synthesis",
             "value": value,
             "unit": "samples/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": untimed,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -372,17 +485,22 @@ def main():
                 "parallelism": f"chains sharded over {world} GPU(s), no collective on the data path",
                 "hip_graph": used_graph,
                 "graph_iterations_per_replay": 2 * sampler._GRAPH_PAIRS if used_graph else 0,
+                "warmup_requested": args.warmup,
                 "clock_ramp_steps": args.ramp,
+                "noise": NOISE_NOTES.get(ops.noise_bits(), "unknown"),
             },
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_sht_gemm (SHT ring-table GEMM, v_mfma_f64_16x16x4_f64)",
                 "achieved": achieved,
+                "achieved_is": "algorithmic bytes (DESIGN.md section 6) / live kernel time -- an effective rate; the HBM rate "
+                               "of the bytes the counters saw is roofline.measured",
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "measured": measured,
                 "avg_launch_us": gemm_avg_us,
                 "launches": int(nl.value),
                 "launch_classes": gemm_classes,
@@ -405,8 +523,9 @@ def main():
                 "achieved_GBs": dnb.value / (dms.value * 1e-3) / 1e9,
                 "hbm_frac": dnb.value / (dms.value * 1e-3) / 1e9 / HBM_PEAK_GBS,
             }
-        if not args.no_cpu_baseline and world == 1:  # the CPU legs run at N = 1 only
+        if cpu is not None:  # the CPU legs ran at N = 1 only, before the GPU was touched
             T = reg.T
+            assert abs(s_norm2 / NOMINAL_S_NORM2 - 1.0) < 0.05, "the CPU legs' nominal ||S||^2 is off"
             # free full-size parity evidence on this box: the benchmarked step vs the oracle on the same noise
             if eng["pairs"]:
                 out["parity"] = {
@@ -414,24 +533,7 @@ def main():
                     "what": "3 iterations of the benchmarked step (ring-space + Gram + real pairs, injected noise) vs the "
                             "oracle's literal loop, chains 0 and 9, error relative to max |X|",
                 }
-            v, secs = cpu_baseline(data, T, args.cpu_iters, delta, procs=1)
-            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            procs = args.cpu_procs or min(ncpu, 16)
-            it_all = max(8, args.cpu_iters // 3)
-            v_all, secs_all = cpu_baseline(data, T, it_all, delta, procs=procs)
-            out["cpu_baseline"] = {
-                "value": v,
-                "unit": "samples/s",
-                "cores": 1,
-                "kind": "port",
-                "sample": f"{args.cpu_iters} MYULA iterations of ONE chain at L=256 (oracle numpy restatement, "
-                          f"table+FFT SHT, BLAS / OpenMP pools pinned to 1 thread, {secs:.1f} s) on this host",
-                "value_all_cores": v_all,
-                "cores_all": procs,
-                "sample_all_cores": f"{procs} independent chains, one single-threaded process each (the reference's --jobid "
-                                    f"model), {it_all} iterations per chain, {secs_all:.1f} s wall incl. process start; "
-                                    f"host reports {ncpu} usable cores",
-            }
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

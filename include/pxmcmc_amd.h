@@ -38,6 +38,9 @@ typedef void* pxm_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------ */
 int pxm_version(void);
+/* precision of the Box-Muller step of the Philox noise stream this library was built with: 32 (default: f32
+ * transcendental units, deviates ~1e-6 relative) or 64 (-DPXM_NOISE_F64 build; pxmcmc/mcmc.py:193 draws fp64) */
+int pxm_noise_bits(void);
 const char* pxm_last_error(void);
 /* number of visible HIP devices (0 when none; never fails) */
 int pxm_device_count(void);
@@ -98,8 +101,12 @@ int64_t pxm_wav_table_bytes(pxm_wav_plan_t plan, int op /*0 synthesis,1 synthesi
 /* Device-resident Philox iteration counter OF ONE PLAN (HIP-graph replay of the MYULA step): when registered,
  * the plan's fused steps use iteration = iter + *counter, read on the device at execution time, so a captured
  * graph draws fresh noise at every replay.  Two plans (two samplers) in one process never share a counter.
- * pxm_wav_iter_counter_add enqueues "*counter += inc" on the stream.  NULL unregisters. */
+ * pxm_wav_iter_counter_add enqueues "*counter += inc" on the stream.  A plan holds ONE live counter: registering
+ * a different one while another is live is an error (two stepping engines on one plan would redirect each other's
+ * noise stream); NULL unregisters unconditionally, pxm_wav_release_iter_counter only if `counter_dev` is still the
+ * registered one (the owner's teardown call: never drops somebody else's counter). */
 int pxm_wav_set_iter_counter(pxm_wav_plan_t plan, uint64_t* counter_dev);
+int pxm_wav_release_iter_counter(pxm_wav_plan_t plan, const uint64_t* counter_dev);
 int pxm_wav_iter_counter_add(pxm_wav_plan_t plan, uint64_t inc, pxm_stream_t stream);
 
 /* Live kernel timing of one plan (bench.py roofline leg).  pxm_wav_profile_enable(plan, n) with n > 0 creates
@@ -112,10 +119,11 @@ int pxm_wav_profile_enable(pxm_wav_plan_t plan, int max_launches);
 int pxm_wav_profile_read(pxm_wav_plan_t plan, double* gemm_ms, int64_t* gemm_launches, double* gemm_alg_bytes,
                          double* gemm_flops);
 int pxm_wav_profile_read_dft(pxm_wav_plan_t plan, double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes);
-/* per-launch form of pxm_wav_profile_read (instead of it): kernel time (ms) and algorithmic bytes of each of the
- * first `cap` ring-GEMM launches, in launch order; *launches = how many were bracketed; then resets */
-int pxm_wav_profile_read_launches(pxm_wav_plan_t plan, double* launch_ms, double* launch_alg_bytes, int64_t cap,
-                                  int64_t* launches);
+/* per-launch form of pxm_wav_profile_read (instead of it): kernel time (ms), algorithmic bytes and (optional, may be
+ * NULL) workgroup count of each of the first `cap` ring-GEMM launches, in launch order -- the workgroup count is the
+ * key a rocprofv3 record of the same launch carries; *launches = how many were bracketed; then resets */
+int pxm_wav_profile_read_launches(pxm_wav_plan_t plan, double* launch_ms, double* launch_alg_bytes,
+                                  int32_t* launch_workgroups, int64_t cap, int64_t* launches);
 /* test aid: number of non-finite doubles in the plan's workspace (ring / harmonic arrays incl. the padding
  * chains' columns); synchronises the stream */
 int64_t pxm_wav_workspace_nonfinite(pxm_wav_plan_t plan, pxm_stream_t stream);

@@ -42,6 +42,25 @@ def wigner_d_eig(el, betas):
     return d.real
 
 
+def wigner_d_eig_pair(el, m, n, betas):
+    """d^el_{m n}(betas) for ONE (m, n) pair by the same eigen route (O(el) per angle once J_y is decomposed):
+    the literal definition at bandlimits where the full [b, m', m] array of ``wigner_d_eig`` would not fit."""
+    betas = np.atleast_1d(np.asarray(betas, dtype=float))
+    if el not in _EIG_CACHE:
+        lam, v = np.linalg.eigh(_jy(el))
+        _EIG_CACHE[el] = (np.rint(lam), v)
+    lam, v = _EIG_CACHE[el]
+    ph = np.exp(-1j * betas[:, None] * lam[None, :])
+    return (ph @ (v[m + el] * v[n + el].conj())).real
+
+
+def spin_harmonic_literal(el, m, spin, thetas, phis):
+    """sY_lm on a (theta, phi) grid from the definition in the header: (-1)^s sqrt((2l+1)/4pi) d^l_{m,-s}(theta)
+    exp(i m phi), d^l by the eigen route -- no recursion in l."""
+    col = (-1.0) ** spin * np.sqrt((2 * el + 1) / (4 * np.pi)) * wigner_d_eig_pair(el, m, -spin, thetas)
+    return col[:, None] * np.exp(1j * m * np.asarray(phis))[None, :]
+
+
 def delta_half_pi(el):
     """Delta^el_{m' m} = d^el_{m' m}(pi/2), index [m'+el, m+el]."""
     return wigner_d_eig(el, [np.pi / 2])[0]

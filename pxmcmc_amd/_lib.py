@@ -22,6 +22,7 @@ c_i64, c_u64, c_int, c_dbl, c_vp = C.c_int64, C.c_uint64, C.c_int, C.c_double, C
 # name -> (restype, argtypes): every symbol include/pxmcmc_amd.h declares
 SIGNATURES = {
     "pxm_version": (c_int, []),
+    "pxm_noise_bits": (c_int, []),
     "pxm_last_error": (C.c_char_p, []),
     "pxm_device_count": (c_int, []),
     "pxm_capture_begin": (c_int, []),
@@ -29,10 +30,11 @@ SIGNATURES = {
     "pxm_deferred_pending": (c_int, []),
     "pxm_tables_trim": (c_int, []),
     "pxm_wav_set_iter_counter": (c_int, [c_vp, c_vp]),
+    "pxm_wav_release_iter_counter": (c_int, [c_vp, c_vp]),
     "pxm_wav_iter_counter_add": (c_int, [c_vp, c_u64, c_vp]),
     "pxm_wav_profile_enable": (c_int, [c_vp, c_int]),
     "pxm_wav_profile_read": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "pxm_wav_profile_read_launches": (c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "pxm_wav_profile_read_launches": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "pxm_wav_profile_read_dft": (c_int, [c_vp, c_vp, c_vp, c_vp]),
     "pxm_wav_workspace_nonfinite": (c_i64, [c_vp, c_vp]),
     "pxm_reduce_scratch_doubles": (c_i64, [c_int]),

@@ -77,7 +77,23 @@ struct Dft5Group {
   int64_t ring0;  // offset of its coefficient block inside a chain (complex elements)
   int r0;
   int b0, nbx, nby;  // first block of the scale in the grid, its blocks along rings / chain groups
+  int64_t tbase;     // the scale's table allocation as an offset (doubles) from the workspace base ...
+  int toff[7];       // ... and cE, cO, dO, tw1, wt, bE, bO inside it (doubles)
 };
+
+// Workgroup barrier of these kernels: every exchange between waves goes through LDS, so only the LDS counter has to
+// drain before the barrier.  __syncthreads() is fence + s_barrier = s_waitcnt vmcnt(0) lgkmcnt(0): it also waited
+// for every global load AND STORE in flight -- the stores of the updated coefficients sat in front of the exchange
+// barrier of the forward transform, the ring stores of a chain group in front of nothing at all.  Global memory needs
+// no intra-kernel ordering here: a workgroup only re-reads global data it has not written (the in-place ring stores
+// come after every ring load of the workgroup has been consumed into LDS).  -DPXM_D5_FULL_BARRIER: the old barrier.
+__device__ __forceinline__ void d5_barrier() {
+#ifdef PXM_D5_FULL_BARRIER
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 
 __device__ __forceinline__ void d5_wave_sync() {
 #if PXM_D5_ABLATE & 4
@@ -262,7 +278,7 @@ template <int SLOT>
 __device__ __forceinline__ void d5_exchange_sum(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) plane[256 * SLOT + 64 * u + lane] = d5_sel(half, x[u], x[4 + u]);
-  __syncthreads();
+  d5_barrier();
 #pragma unroll
   for (int u = 0; u < 4; ++u) x[u] = cadd(d5_sel(half, x[4 + u], x[u]), pplane[256 * SLOT + 64 * u + lane]);
 }
@@ -271,7 +287,7 @@ template <int SLOT>
 __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) plane[256 * SLOT + 64 * u + lane] = x[u];
-  __syncthreads();
+  d5_barrier();
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const double2 o = pplane[256 * SLOT + 64 * u + lane], own = x[u];
@@ -339,12 +355,12 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
   d5_exchange_sum<SLOT>(x, plane, pplane, lane, half);
 // own elements of x -> stage (after every plane of the workgroup is dead)
 #define PXM_D5_TO_STAGE                                                   \
-  __syncthreads();                                                        \
+  d5_barrier();                                                        \
   _Pragma("unroll") for (int u = 0; u < P1; ++u) {                        \
     const int j = jb + 8 * R0 * (pb + u);                                 \
     if (j < n) stage[PXM_D5_SLOT(trs, j, r)] = x[u];                      \
   }                                                                       \
-  __syncthreads();
+  d5_barrier();
 
 template <int R0>
 __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in, double* __restrict__ G, int ncol, int C,
@@ -375,14 +391,14 @@ __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in,
       if (j < n) stage[PXM_D5_SLOT(trs, j, r)] = v[u];
     }
   }
-  __syncthreads();  // (also: the LDS copy of the twiddles is complete)
+  d5_barrier();  // (also: the LDS copy of the twiddles is complete)
   double2 x[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
     const int j = jb + 8 * R0 * p;
     x[p] = j < n ? stage[PXM_D5_SLOT(trs, j, r)] : double2{0.0, 0.0};
   }
-  __syncthreads();  // the stage is dead: the planes may be written
+  d5_barrier();  // the stage is dead: the planes may be written
   PXM_D5_TRANSFORM(0)
   PXM_D5_TO_STAGE
   PXM_D5_STORE_RINGS(true)
@@ -440,7 +456,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
       }
     }
   }
-  __syncthreads();
+  d5_barrier();
   PXM_D5_STAMP(0)  // rings staged
   double2 x[8];
 #pragma unroll
@@ -448,7 +464,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
     const int j = jb + 8 * R0 * p;
     x[p] = j < n ? stage[PXM_D5_SLOT(trs, j, r)] : double2{0.0, 0.0};
   }
-  __syncthreads();
+  d5_barrier();
   PXM_D5_TRANSFORM(0)
   PXM_D5_STAMP(1)  // inverse transform done
   const bool act = ch < C && tv;
@@ -545,13 +561,13 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
   PXM_D5_STAMP(2)  // prox + update + noise done
   // ---- forward transform of the updated ring
   d5_exchange_fill<1>(x, plane, pplane, lane, half);  // both waves of the ring set need all 8 elements
-  __syncthreads();                                    // ... and every exchange read is done before the planes are reused
+  d5_barrier();                                    // ... and every exchange read is done before the planes are reused
   PXM_D5_TRANSFORM(0)
   PXM_D5_STAMP(3)  // forward transform done
   PXM_D5_TO_STAGE
   PXM_D5_STORE_RINGS(false)
 #ifdef PXM_D5_TRACE
-  __syncthreads();
+  d5_barrier();
   if (threadIdx.x == 0 && g_dft_trace) {
     const unsigned long long slot = atomicAdd(g_dft_trace + 1, 1ull);
     unsigned long long* rr_ = g_dft_trace + 8 + 8 * 4096 + 8 * slot;  // phase records behind the workgroup records
@@ -580,6 +596,11 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px5(Dft5Args a, doubl
 // the 128-B lines of the ring arrays (8 chain slots per (m, ring)), so they are given block ids that differ by 8 --
 // same XCD (same L2) under the round-robin placement of blocks, dispatched back to back: the second one finds its
 // half-lines in L2 and their half-line stores merge there.  (b0 and the per-scale block counts are multiples of 8.)
+// The table pointers of a group entry would be LOADED from the descriptor array: the compiler cannot see their
+// address space and emits flat_load for every chirp / filter / twiddle access (162 of them in the fused kernel) --
+// flat loads count on lgkmcnt as well as vmcnt, so every s_waitcnt lgkmcnt(0) of the LDS transposes also drained
+// the table loads in flight.  The entries therefore carry the tables as offsets (doubles) from the workspace base,
+// a kernel argument: pointers derived from it are global and the loads are global_load (like the GEMM's tab_off).
 #define PXM_D5_GROUP_DECODE                                              \
   int e = 0;                                                             \
   while (e + 1 < nent && (int)blockIdx.x >= ents[e + 1].b0) ++e;         \
@@ -589,7 +610,17 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px5(Dft5Args a, doubl
   const int by = rest % g.nby, bx = (rest / g.nby) * 8 + (local & 7);    \
   if (bx >= g.nbx) return;                                               \
   double* G = ws + g.g_off;                                              \
-  const Dft5Args a = g.a;
+  Dft5Args a = g.a;                                                      \
+  {                                                                      \
+    const double* tb = ws + g.tbase;                                     \
+    a.cE = reinterpret_cast<const double2*>(tb + g.toff[0]);             \
+    a.cO = reinterpret_cast<const double2*>(tb + g.toff[1]);             \
+    a.dO = reinterpret_cast<const double2*>(tb + g.toff[2]);             \
+    a.tw1 = reinterpret_cast<const double2*>(tb + g.toff[3]);            \
+    a.wt = reinterpret_cast<const double2*>(tb + g.toff[4]);             \
+    a.bE = reinterpret_cast<const double2*>(tb + g.toff[5]);             \
+    a.bO = reinterpret_cast<const double2*>(tb + g.toff[6]);             \
+  }
 
 // Grouped launch of the ring-space step: the rings -> X' -> rings bodies (RING_OUT) of EVERY scale of a wavelet plan
 // in one grid, largest scales first (their workgroups are the long ones; the small scales fill the tail); without
@@ -707,20 +738,20 @@ __device__ __forceinline__ void d6_transform(double2 (&xl)[8], const double2 (&x
     plane[64 * i + lane] = cmul(ys, dA[ps]);
     plane[256 + 64 * i + lane] = cmul(ys, dB[ps]);
   }
-  __syncthreads();
+  d5_barrier();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     su[i] = cadd(su[i], pp1[64 * i + lane]);
     sv[i] = cadd(sv[i], pp1[256 + 64 * i + lane]);
   }
-  __syncthreads();  // every read of exchange 1 is done before the planes take exchange 2
+  d5_barrier();  // every read of exchange 1 is done before the planes take exchange 2
   // ---- pair exchange 2 (w <-> w ^ 2): keep i in {2 wb, 2 wb + 1}
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii) {
     plane[64 * ii + lane] = d5_sel(wb, su[ii], su[2 + ii]);
     plane[128 + 64 * ii + lane] = d5_sel(wb, sv[ii], sv[2 + ii]);
   }
-  __syncthreads();
+  d5_barrier();
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii) {
     fo[ii][0] = cadd(d5_sel(wb, su[2 + ii], su[ii]), pp2[64 * ii + lane]);
@@ -756,7 +787,7 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
       if (j < n) stage[PXM_D6_SLOT(j, r)] = v[u];
     }
   }
-  __syncthreads();  // (also: the LDS copy of the twiddles is complete)
+  d5_barrier();  // (also: the LDS copy of the twiddles is complete)
   double2 xl[8], xh[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
@@ -764,10 +795,10 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
     xl[p] = stage[PXM_D6_SLOT(j, r)];
     xh[p] = (j + 512 < n) ? stage[PXM_D6_SLOT(j + 512, r)] : double2{0.0, 0.0};
   }
-  __syncthreads();  // the stage is dead: the planes may be written
+  d5_barrier();  // the stage is dead: the planes may be written
   double2 fo[2][2];
   d6_transform(xl, xh, fo, plane, pp1, pp2, tw, lane, q, w, a);
-  __syncthreads();  // the planes are dead; the same LDS is the [k][chain] layout-transpose stage
+  d5_barrier();  // the planes are dead; the same LDS is the [k][chain] layout-transpose stage
 #pragma unroll
   for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -775,7 +806,7 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
       const int j = lane + 64 * (pb + ii) + 512 * hq;
       if (j < n) stage[PXM_D6_SLOT(j, r)] = fo[ii][hq];
     }
-  __syncthreads();
+  d5_barrier();
   {
     const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;
     const int mstride = a.Rp * Cp;
@@ -823,7 +854,7 @@ __global__ __launch_bounds__(512, 4) void k_ring2px6(Dft6Args a, const double* _
       }
     }
   }
-  __syncthreads();
+  d5_barrier();
   double2 xl[8], xh[8];
 #pragma unroll
   for (int p = 0; p < 8; ++p) {
@@ -831,7 +862,7 @@ __global__ __launch_bounds__(512, 4) void k_ring2px6(Dft6Args a, const double* _
     xl[p] = stage[PXM_D6_SLOT(j, r)];
     xh[p] = (j + 512 < n) ? stage[PXM_D6_SLOT(j + 512, r)] : double2{0.0, 0.0};
   }
-  __syncthreads();
+  d5_barrier();
   double2 fo[2][2];
   d6_transform(xl, xh, fo, plane, pp1, pp2, tw, lane, q, w, a);
   if (ch >= C) return;
@@ -1030,7 +1061,7 @@ int dft5_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, 
 
 // ---- grouped launch (wavelet plan: every scale in one grid) -----------------------------------------------------
 int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
-                      const std::vector<int64_t>& ring0, int ncol, DftGroupList* out) {
+                      const std::vector<int64_t>& ring0, int ncol, const double* ws_base, DftGroupList* out) {
   // members: the scales on the eight-points-per-lane path that share the workgroup shape of the largest of them
   // (the others keep their own launches); longest workgroups first, the smaller scales fill the tail
   std::vector<int> order;
@@ -1050,6 +1081,9 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
     g.g_off = g_off[s];
     g.ring0 = ring0[s];
     g.r0 = p.t5.r0;
+    g.tbase = p.t5.d_all - ws_base;
+    const double* tp[7] = {p.t5.cE, p.t5.cO, p.t5.dO, p.t5.tw1, p.t5.wt, p.t5.bE, p.t5.bO};
+    for (int k = 0; k < 7; ++k) g.toff[k] = (int)(tp[k] - p.t5.d_all);
     const int rings = p.TR5 * (8 / g.r0);
     g.nbx = (p.L + rings - 1) / rings;
     g.nby = (ncol / 2 + p.R5 - 1) / p.R5;

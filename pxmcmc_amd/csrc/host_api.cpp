@@ -82,7 +82,15 @@ int drain_deferred() {
 
 extern "C" {
 
-int pxm_version(void) { return 210; }  // 2.1: + pxm_myula_step_it, pxm_chain_step_it, pxm_csr_matvec_batched
+int pxm_version(void) { return 300; }  // 3.0: + pxm_noise_bits, pxm_wav_release_iter_counter; profile_read_launches takes a workgroup array
+
+int pxm_noise_bits(void) {
+#ifdef PXM_NOISE_F64  // (EXTRA=-DPXM_NOISE_F64: every translation unit of the build sees it, csrc/philox.h)
+  return 64;
+#else
+  return 32;
+#endif
+}
 
 int pxm_capture_begin(void) {
   std::lock_guard<std::mutex> lock(pxm::g_grave_mu);

@@ -43,6 +43,22 @@ __device__ inline NormalPair box_muller_fast(double u1, double u2) {
   return NormalPair{(double)(r * __builtin_amdgcn_cosf(turns)), (double)(r * __builtin_amdgcn_sinf(turns))};
 }
 
+// The same transform in double precision (build switch -DPXM_NOISE_F64: log / sincospi / sqrt of the fp64 math
+// library; deviates to fp64 round-off, like the reference's numpy randn).  pxm_noise_bits() reports which one a
+// library was built with; BASELINE.md gives the step time both ways.
+__device__ inline NormalPair box_muller_f64(double u1, double u2) {
+  const double r = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  return NormalPair{r * c, r * s};
+}
+
+#ifdef PXM_NOISE_F64
+#define PXM_NOISE_BITS 64
+#else
+#define PXM_NOISE_BITS 32
+#endif
+
 // two independent N(0,1) draws for counter (index, iter) under key (seed, chain)
 __device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter) {
   const uint64_t key = seed + chain * 0x9E3779B97F4A7C15ull;
@@ -52,7 +68,11 @@ __device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, u
   const uint64_t b = (((uint64_t)c[3] << 32) | c[2]) >> 11;
   const double u1 = ((double)a + 0.5) * 0x1.0p-53;
   const double u2 = ((double)b + 0.5) * 0x1.0p-53;
+#ifdef PXM_NOISE_F64
+  return box_muller_f64(u1, u2);
+#else
   return box_muller_fast(u1, u2);
+#endif
 }
 
 // Real stream: chains come in pairs -- chain ch takes draw (ch & 1) of the Philox pair keyed by

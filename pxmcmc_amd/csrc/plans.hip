@@ -612,7 +612,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   if (!getenv("PXM_NO_DFT_GROUP")) {
     std::vector<const DftPlan*> dp;
     for (int s = 0; s < p->nsc; ++s) dp.push_back(&p->dft[s]);
-    rc = dft5_group_create(dp, p->offG, p->coef_off, p->ncol, &p->dft_group);
+    rc = dft5_group_create(dp, p->offG, p->coef_off, p->ncol, p->ws, &p->dft_group);
     if (rc < 0) return rc;  // rc == 1: no group -> per-scale launches
   }
   *plan = guard.release();
@@ -643,7 +643,18 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
 
 int pxm_wav_set_iter_counter(pxm_wav_plan_t p, uint64_t* counter_dev) {
   PXM_REQUIRE(p, "pxm_wav_set_iter_counter: null plan");
+  // one live counter per plan: a second stepping engine on the same plan must not silently redirect the
+  // Philox iteration number of the first (graphs captured earlier keep the pointer they were captured with)
+  PXM_REQUIRE(!counter_dev || !p->iter_dev || p->iter_dev == counter_dev,
+              "pxm_wav_set_iter_counter: this plan already has a live iteration counter (one stepping engine per plan "
+              "at a time; release the first with pxm_wav_release_iter_counter)");
   p->iter_dev = counter_dev;
+  return 0;
+}
+
+int pxm_wav_release_iter_counter(pxm_wav_plan_t p, const uint64_t* counter_dev) {
+  PXM_REQUIRE(p, "pxm_wav_release_iter_counter: null plan");
+  if (p->iter_dev == counter_dev) p->iter_dev = nullptr;  // somebody else's counter stays registered
   return 0;
 }
 
@@ -669,10 +680,10 @@ int pxm_wav_profile_read(pxm_wav_plan_t p, double* gemm_ms, int64_t* gemm_launch
   PXM_REQUIRE(p, "pxm_wav_profile_read: null plan");
   return profiler_read(&p->prof.gemm, gemm_ms, gemm_launches, gemm_alg_bytes, gemm_flops);
 }
-int pxm_wav_profile_read_launches(pxm_wav_plan_t p, double* launch_ms, double* launch_alg_bytes, int64_t cap,
-                                  int64_t* launches) {
+int pxm_wav_profile_read_launches(pxm_wav_plan_t p, double* launch_ms, double* launch_alg_bytes,
+                                  int32_t* launch_workgroups, int64_t cap, int64_t* launches) {
   PXM_REQUIRE(p && launch_ms && launch_alg_bytes && cap >= 0, "pxm_wav_profile_read_launches: bad arguments");
-  return profiler_read(&p->prof.gemm, nullptr, launches, nullptr, nullptr, launch_ms, launch_alg_bytes, cap);
+  return profiler_read(&p->prof.gemm, nullptr, launches, nullptr, nullptr, launch_ms, launch_alg_bytes, cap, launch_workgroups);
 }
 int pxm_wav_profile_read_dft(pxm_wav_plan_t p, double* dft_ms, int64_t* dft_launches, double* dft_alg_bytes) {
   PXM_REQUIRE(p, "pxm_wav_profile_read_dft: null plan");

@@ -64,10 +64,11 @@ struct Profiler {
     size_t used = 0;
     double bytes = 0, flops = 0;
     std::vector<double> launch_bytes;  // algorithmic bytes of every bracketed launch (launch classes of bench.py)
+    std::vector<int> launch_wgs;       // workgroups of every bracketed launch (the key rocprofv3 records join on)
   };
   bool on = false;
   Pool gemm, dft;
-  void next(Pool& p, hipEvent_t* start, hipEvent_t* stop, double alg_bytes, double flops) {
+  void next(Pool& p, hipEvent_t* start, hipEvent_t* stop, double alg_bytes, double flops, int workgroups = 0) {
     *start = *stop = nullptr;
     if (!on || p.used >= p.ev.size()) return;
     *start = p.ev[p.used].first;
@@ -75,12 +76,14 @@ struct Profiler {
     p.bytes += alg_bytes;
     p.flops += flops;
     p.launch_bytes.push_back(alg_bytes);
+    p.launch_wgs.push_back(workgroups);
     ++p.used;
   }
 };
 int profiler_enable(Profiler* pr, int max_launches);  // 0 = off (events are released)
 int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* bytes, double* flops,
-                  double* per_launch_ms = nullptr, double* per_launch_bytes = nullptr, int64_t cap = 0);
+                  double* per_launch_ms = nullptr, double* per_launch_bytes = nullptr, int64_t cap = 0,
+                  int32_t* per_launch_wgs = nullptr);
 void profiler_release(Profiler* pr);
 
 // extras of append_gemm_tasks for the fused wavelet combine
@@ -254,7 +257,8 @@ void dft5_geometry(int n, int* R, int* TR, size_t* lds);
 int dft5_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft5_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);
 int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vector<int64_t>& g_off,
-                      const std::vector<int64_t>& ring0, int ncol, DftGroupList* out);  // 1 = not available
+                      const std::vector<int64_t>& ring0, int ncol, const double* ws_base,
+                      DftGroupList* out);  // 1 = not available
 int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
                       Profiler* prof = nullptr);
 // the plain transforms of every member scale in one grid each (blocks <-> rings of the generic wavelet operators)

@@ -345,10 +345,11 @@ void profiler_release(Profiler* pr) {
     p->used = 0;
     p->bytes = p->flops = 0;
     p->launch_bytes.clear();
+    p->launch_wgs.clear();
   }
 }
 int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* bytes, double* flops, double* per_launch_ms,
-                  double* per_launch_bytes, int64_t cap) {
+                  double* per_launch_bytes, int64_t cap, int32_t* per_launch_wgs) {
   double tot = 0;
   for (size_t i = 0; i < p->used; ++i) {
     PXM_HIP(hipEventSynchronize(p->ev[i].second));
@@ -358,6 +359,7 @@ int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* byte
     if ((int64_t)i < cap) {
       if (per_launch_ms) per_launch_ms[i] = t;
       if (per_launch_bytes) per_launch_bytes[i] = p->launch_bytes[i];
+      if (per_launch_wgs) per_launch_wgs[i] = p->launch_wgs[i];
     }
   }
   if (ms) *ms = tot;
@@ -367,6 +369,7 @@ int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* byte
   p->used = 0;
   p->bytes = p->flops = 0;
   p->launch_bytes.clear();
+  p->launch_wgs.clear();
   return 0;
 }
 
@@ -384,7 +387,7 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, int flags, cons
   PXM_REQUIRE(nslab == 1 || nslab == 2, "launch_gemm: nslab must be 1 (unpaired tables) or 2 (+-m pairs)");
   dim3 grid(n_tasks), block(512);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (prof) prof->next(prof->gemm, &ev0, &ev1, alg_bytes, flops);
+  if (prof) prof->next(prof->gemm, &ev0, &ev1, alg_bytes, flops, n_tasks);
   // look-ahead of the table / operand streams in chunks + 1: PXM_GEMM_NSET (all launches), PXM_GEMM_GRAM_NSET (Gram)
   static const int all_nset = getenv("PXM_GEMM_NSET") ? atoi(getenv("PXM_GEMM_NSET")) : 2;
   static const int gram_nset = getenv("PXM_GEMM_GRAM_NSET") ? atoi(getenv("PXM_GEMM_GRAM_NSET")) : all_nset;

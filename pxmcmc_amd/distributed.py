@@ -58,6 +58,17 @@ def max_over_ranks(value):
     return float(t.item())
 
 
+def count_ranks():
+    """number of ranks that take part in the process group, by an all-reduce (SUM of ones) over the group's own
+    transport (RCCL for ``nccl``): 1 without a group"""
+    if not dist.is_initialized():
+        return 1
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 def gather_summaries(array):
     """end-of-run gather of per-chain summaries ([C_local, ...] numpy or tensor) onto every rank, chain order kept"""
     t = torch.as_tensor(array)

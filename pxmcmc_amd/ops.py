@@ -589,13 +589,13 @@ class WavPlan:
         check(lib.pxm_wav_profile_enable(self._h, int(max_launches)))
 
     def profile_read_launches(self, cap):
-        """per-launch (ms, algorithmic bytes) of the bracketed ring-GEMM launches, in launch order"""
+        """per-launch (ms, algorithmic bytes, workgroups) of the bracketed ring-GEMM launches, in launch order"""
         import numpy as np
 
-        ms, nb, n = np.zeros(cap), np.zeros(cap), C.c_int64()
-        check(lib.pxm_wav_profile_read_launches(self._h, ms.ctypes.data, nb.ctypes.data, int(cap), C.byref(n)))
+        ms, nb, wg, n = np.zeros(cap), np.zeros(cap), np.zeros(cap, dtype=np.int32), C.c_int64()
+        check(lib.pxm_wav_profile_read_launches(self._h, ms.ctypes.data, nb.ctypes.data, wg.ctypes.data, int(cap), C.byref(n)))
         k = min(int(n.value), cap)
-        return ms[:k], nb[:k]
+        return ms[:k], nb[:k], wg[:k]
 
     def profile_read(self):
         """(gemm: ms, launches, algorithmic bytes, flops), (grouped phi-DFT: ms, launches, algorithmic bytes)"""
@@ -609,7 +609,9 @@ class WavPlan:
 # ---- device-resident iteration counter (HIP-graph replay) -----------------------------------
 class IterCounter:
     """A device int64 registered as the Philox iteration counter of ONE wavelet plan for the lifetime of the
-    object (per-plan state: two samplers in one process never share a counter)."""
+    object.  A plan holds one live counter: a second engine on the same plan (two samplers built on one
+    ForwardOperator) raises ``PxmError`` until the first has stopped; ``close`` only releases the registration if
+    it is still this object's."""
 
     def __init__(self, plan, start=0):
         self.plan = plan
@@ -626,7 +628,7 @@ class IterCounter:
     def close(self):
         if self.active:
             if getattr(self.plan, "_h", None):
-                lib.pxm_wav_set_iter_counter(self.plan._h, C.c_void_p(0))
+                lib.pxm_wav_release_iter_counter(self.plan._h, C.c_void_p(self.t.data_ptr()))
             self.active = False
 
     def __del__(self):
@@ -652,6 +654,11 @@ class capture_scope:
 def tables_trim():
     """free every cached ring table no live plan holds (the cache is per device and shared by plans); MiB released"""
     return int(check(lib.pxm_tables_trim()))
+
+
+def noise_bits():
+    """32 or 64: precision of the Box-Muller step of the device noise stream in the loaded library"""
+    return int(lib.pxm_noise_bits())
 
 
 # ---- host helpers ------------------------------------------------------------------------

@@ -123,3 +123,58 @@ def test_two_rank_hip_chain_sharding(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     assert "HIP-OK 0 3" in res.stdout
+
+
+def test_bench_self_launch_command_is_a_child_torchrun(monkeypatch):
+    """`python bench.py --gpus N` without a torchrun environment starts its N ranks as a CHILD
+    `python -m torch.distributed.run` (no exec, before torch is imported) and returns the child's exit code."""
+    import importlib.util
+    import subprocess
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    assert bench.self_launch(4, ["--gpus", "4", "--steps", "20"]) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "20"]
+    assert seen["env"]["MASTER_ADDR"] == "127.0.0.1" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # and main() takes that branch before importing torch when WORLD_SIZE is unset
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    monkeypatch.setattr(bench, "self_launch", lambda n, argv: 5 if (n, argv) == (2, ["--gpus", "2", "--steps", "3"]) else 99)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 5
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_self_launch_rehearsal():
+    """The driver's N > 1 command issued plainly: `python bench.py --gpus 2` (no torchrun in front).  On the test
+    box's single GPU the two ranks share cuda:0 and use gloo (PXM_BENCH_REHEARSE=1; RCCL refuses two ranks on one
+    device); the JSON line must report both ranks."""
+    import json
+
+    env = dict(os.environ, PXM_BENCH_REHEARSE="1", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--ramp", "10"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 6 and out["warmup"] == 12
+    assert out["config"]["global_chains"] == 32 and out["value"] > 0 and out["scaling"] == "weak"
+    assert "cpu_baseline" not in out  # the CPU legs run at N = 1 only

@@ -75,6 +75,75 @@ def test_sht_four_ops_match_oracle_full_size(L, spin, C):
         assert _rel(got, ref) < TOL, (name, _rel(got, ref))
 
 
+def _sparse_literal_image(L, spin, entries):
+    """f(theta, phi) = sum a_lm sY_lm from the definition (oracle.wigner.spin_harmonic_literal: d^l by the eigen
+    route, no recursion in l, no tables) for a handful of (l, m, a) entries; also the dense flm vector"""
+    from oracle import ssht, wigner
+
+    th, ph = ssht.sample_positions(L)
+    f = np.zeros((L, 2 * L - 1), dtype=complex)
+    flm = np.zeros(L * L, dtype=complex)
+    for el, m, a in entries:
+        f += a * wigner.spin_harmonic_literal(el, m, spin, th, ph)
+        flm[el * el + el + m] += a
+    return flm, f.ravel()
+
+
+def _extreme_entries(L, spin, rng):
+    """low, middle and extreme degrees / orders of the bandlimit (the corners a wrong table row would hide in)"""
+    lm = [(max(2, abs(spin)), 0), (max(2, abs(spin)), -2), (3, 1), (L // 2, L // 4), (L - 212, -(L - 257)), (L - 112, L - 112),
+          (L - 1, 0), (L - 1, 1), (L - 1, -2), (L - 1, 255), (L - 1, -(L - 112)), (L - 1, L - 1), (L - 1, -(L - 1))]
+    return [(el, m, complex(rng.normal(), rng.normal())) for el, m in lm]
+
+
+@pytest.mark.parametrize("L,spin", [(512, 0), (512, 2), (520, 0), (516, 2)])
+def test_sht_four_ops_literal_and_round_trip_large_L(L, spin):
+    """L = 512 (BASELINE configs[4]: four-wave phi-DFT at M = 2048, 0.54 / 1.09-GB tables) and L in (512, 530] (the
+    default radix-2 phi-DFT of csrc/dft.hip at M = 4096), spins 0 and 2 (pxmcmc/measurements.py:223-239).  The fast
+    oracle needs minutes and GBs of long-double tables here, so the checker is the literal definition restricted to
+    13 harmonics at low / middle / extreme (l, m): inverse against the analytic image, forward of the analytic image
+    back to the coefficients, the two adjoints against literal inner products with sY_lm; plus the round trip
+    forward(inverse(flm)) == flm on dense random coefficients and the adjoint dot tests."""
+    import torch
+
+    from oracle import ssht, wigner
+    from pxmcmc_amd import ops
+
+    rng = np.random.default_rng(L + spin)
+    C = 2
+    plan = ops.ShtPlan(L, spin, max_chains=C)
+    entries = _extreme_entries(L, spin, rng)
+    flm_s, f_s = _sparse_literal_image(L, spin, entries)
+    scale = np.abs(f_s).max()
+    # inverse / forward against the definition
+    got = plan.inverse(flm_s).cpu().numpy()
+    assert np.abs(got - f_s).max() < 1e-11 * scale, np.abs(got - f_s).max() / scale
+    back = plan.forward(f_s).cpu().numpy()
+    assert np.abs(back - flm_s).max() < 1e-11 * np.abs(flm_s).max(), np.abs(back - flm_s).max()
+    # dense random coefficients: exact quadrature round trip (both chains of the batch)
+    flm = rng.normal(size=(C, L * L)) + 1j * rng.normal(size=(C, L * L))
+    flm[:, : spin * spin] = 0
+    f = plan.inverse(flm)
+    rt = plan.forward(f).cpu().numpy()
+    assert np.abs(rt - flm).max() < 1e-10 * np.abs(flm).max(), np.abs(rt - flm).max()
+    # adjoints: (inverse_adjoint g)_lm = <sY_lm, g> literally, for the 13 harmonics; dot tests for all of it
+    g = rng.normal(size=(C, L * (2 * L - 1))) + 1j * rng.normal(size=(C, L * (2 * L - 1)))
+    ia = plan.inverse_adjoint(g).cpu().numpy()
+    th, ph = ssht.sample_positions(L)
+    for el, m, _ in entries:
+        y = wigner.spin_harmonic_literal(el, m, spin, th, ph).ravel()
+        want = np.vdot(y, g[1])
+        assert abs(ia[1, el * el + el + m] - want) < 1e-11 * np.abs(g).max() * np.sqrt(g.shape[1]), (el, m, abs(ia[1, el * el + el + m] - want))
+    gd, flmd = ops.as_device(g, torch.complex128), ops.as_device(flm, torch.complex128)
+    fa = plan.forward_adjoint(flm)
+    lhs = torch.sum(torch.conj(fa) * gd, dim=1)                       # <A^H flm, g> == <flm, A g>
+    rhs = torch.sum(torch.conj(flmd) * plan.forward(g), dim=1)
+    assert float(((lhs - rhs).abs() / lhs.abs()).max()) < 1e-11
+    lhs = torch.sum(torch.conj(gd) * f, dim=1)                        # <g, B flm> == <B^H g, flm>
+    rhs = torch.sum(torch.conj(plan.inverse_adjoint(g)) * flmd, dim=1)
+    assert float(((lhs - rhs).abs() / lhs.abs()).max()) < 1e-11
+
+
 # ---- (ii) the fused MYULA iteration of the benchmark ---------------------------------------------------------
 def _plan_steps(path, plan, X0, data_c, invcov, T_dev, delta, lmda, noises, pairs):
     """K MYULA iterations through the very C-ABI calls the stepping engine makes (pxmcmc_amd/mcmc.py
@@ -101,11 +170,13 @@ def _plan_steps(path, plan, X0, data_c, invcov, T_dev, delta, lmda, noises, pair
     return X, P
 
 
-@pytest.mark.parametrize("path", ["ring", "image"])
-def test_fused_myula_steps_match_oracle_L256_16chains(path):
+@pytest.mark.parametrize("path,C", [("ring", 16), ("image", 16), ("ring", 32), ("image", 32), ("ring", 128)])
+def test_fused_myula_steps_match_oracle_L256_16chains(path, C):
     """BASELINE configs[2]: L=256, B=2, J_min=2, 16 chains as 8 real pairs, K iterations with injected noise
     through the ring-space + Gram step (scalar sig_d) and the image-space step (vector sig_d), against
-    oracle.pxmcmc_np.myula_run chain by chain (pxmcmc/mcmc.py:157-164)."""
+    oracle.pxmcmc_np.myula_run chain by chain (pxmcmc/mcmc.py:157-164).  C = 32: 16 slots = the two-column-tile
+    GEMM variant k_sht_gemm<2, ...>; C = 128 (64 slots: SURVEY C4's strong-scaling batch, BASELINE.md's 32 / 64 /
+    128-chain figures) runs the column-tile loop of the launches."""
     import torch
 
     from oracle import pxmcmc_np as ref
@@ -113,7 +184,7 @@ def test_fused_myula_steps_match_oracle_L256_16chains(path):
     from pxmcmc_amd.forward import SphericalWaveletTransformOperator
     from pxmcmc_amd.prior import S2_Wavelets_L1
 
-    L, B, J_min, C, K = 256, 2, 2, 16, 3
+    L, B, J_min, K = 256, 2, 2, 3
     P = L * (2 * L - 1)
     truth, rng = _bandlimited_real_field(L, seed=2)
     sig = 0.05
@@ -135,7 +206,7 @@ def test_fused_myula_steps_match_oracle_L256_16chains(path):
     oop = ref.ForwardOperator(data, sig_d, "synthesis", T, ref.Identity(P, P), T.ncoefs)
     oreg = ref.S2_Wavelets_L1("synthesis", None, None, lmda * mu, L, B, J_min)
     np.testing.assert_allclose(reg.map_weights, oreg.map_weights, rtol=1e-12)
-    for c in (0, 5, 14, 15):
+    for c in {16: (0, 5, 14, 15), 32: (0, 15, 16, 31), 128: (0, 63, 64, 127)}[C]:
         out = ref.myula_run(oop, oreg, lmda, delta, mu, 1, K - 1, 1, X0[c].astype(complex), lambda i: noise[i][c])
         got = Xk[c // 2].real if c % 2 == 0 else Xk[c // 2].imag
         gp = Pk[c // 2].real if c % 2 == 0 else Pk[c // 2].imag
@@ -145,9 +216,11 @@ def test_fused_myula_steps_match_oracle_L256_16chains(path):
         assert np.abs(gp - out["preds"].real).max() < 1e-9 * sp, (c, np.abs(gp - out["preds"].real).max() / sp)
 
 
-def test_fused_myula_complex_slots_match_oracle_L256():
+@pytest.mark.parametrize("C", [3, 16])
+def test_fused_myula_complex_slots_match_oracle_L256(C):
     """the reference layout (one complex128 slot per chain, complex data => complex-variance rule) at L=256:
-    ring-space + Gram step with a COMPLEX uniform inverse covariance, 3 chains (padding columns live)."""
+    ring-space + Gram step with a COMPLEX uniform inverse covariance; 3 chains (padding columns live) and 16
+    chains = 16 slots, the two-column-tile GEMM variant the bench's reference-layout leg times."""
     import torch
 
     from oracle import pxmcmc_np as ref
@@ -155,7 +228,7 @@ def test_fused_myula_complex_slots_match_oracle_L256():
     from pxmcmc_amd.forward import SphericalWaveletTransformOperator
     from pxmcmc_amd.prior import S2_Wavelets_L1
 
-    L, B, J_min, C, K = 256, 2, 2, 3, 2
+    L, B, J_min, K = 256, 2, 2, 2
     P = L * (2 * L - 1)
     truth, rng = _bandlimited_real_field(L, seed=4)
     data = (truth + 0.05 * rng.normal(size=P)).astype(complex)
@@ -173,7 +246,7 @@ def test_fused_myula_complex_slots_match_oracle_L256():
     T = ref.SphericalWaveletTransform(L, B, J_min)
     oop = ref.ForwardOperator(data, 0.05, "synthesis", T, ref.Identity(P, P), T.ncoefs)
     oreg = ref.S2_Wavelets_L1("synthesis", None, None, lmda * mu, L, B, J_min)
-    for c in (0, 2):
+    for c in {3: (0, 2), 16: (0, 7, 8, 15)}[C]:
         out = ref.myula_run(oop, oreg, lmda, delta, mu, 1, K - 1, 1, X0[c].astype(complex), lambda i: noise[i][c])
         assert np.abs(out["X"].imag).max() > 1e-6 * np.abs(out["X"]).max()  # the quirk makes the state complex
         assert np.abs(Xk[c] - out["X"]).max() < 1e-9 * np.abs(out["X"]).max()

@@ -588,6 +588,60 @@ def test_two_engines_interleaved_equal_separate_runs():
         s._engine_stop()
 
 
+def test_two_samplers_on_one_operator_do_not_share_a_counter():
+    """A plan holds ONE live Philox iteration counter (include/pxmcmc_amd.h: pxm_wav_set_iter_counter): a second
+    stepping engine on the same ForwardOperator is refused while the first is live -- it would redirect the first
+    one's noise stream --, a late release of the first counter never unregisters the second's, and run one after
+    the other on the shared operator the two samplers produce the chains they produce on private operators."""
+    from pxmcmc_amd._lib import PxmError
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    L, B, J_min, C = 16, 2, 2, 3
+    rng = np.random.default_rng(43)
+    P = L * (2 * L - 1)
+    data = rng.normal(size=P) + 1j * rng.normal(size=P)  # complex data: never pair-packed, both engines use op's own plan
+    reg = S2_Wavelets_L1("synthesis", None, None, 1e-3, L=L, B=B, J_min=J_min)
+    p = PxMCMCParams(lmda=1e-3, delta=5e-4, nsamples=1, nburn=0, ngap=1, verbosity=0)
+
+    def start(op, seed):
+        s = MYULA(op, reg, p, nchains=C, seed=seed)
+        s._prepare()
+        X, preds = _quiet(s._initial_sample, np.zeros(op.nparams))
+        s._engine_start(X, preds, 0)
+        return s
+
+    private = []
+    for seed in (60, 61):
+        s = start(SphericalWaveletTransformOperator(data, 0.2, "synthesis", L, B, J_min, max_chains=C), seed)
+        s._engine_advance(11)
+        private.append(s._engine_state()[0].cpu().numpy())
+        s._engine_stop()
+
+    shared = SphericalWaveletTransformOperator(data, 0.2, "synthesis", L, B, J_min, max_chains=C)
+    a = start(shared, 60)
+    a._engine_advance(11)
+    np.testing.assert_array_equal(a._engine_state()[0].cpu().numpy(), private[0])
+    # a second engine on the same plan is refused while the first is live (it would redirect a's Philox counter, and
+    # its set-up transforms run in the plan's workspace, where a's carried rings live)
+    with pytest.raises(PxmError, match="live iteration counter"):
+        start(shared, 61)
+    assert a._eng["cnt"].active
+    import ctypes
+
+    from pxmcmc_amd._lib import lib
+
+    cnt_a = a._eng["cnt"]
+    a._engine_stop()
+    b = start(shared, 61)
+    # a late release (close / __del__) of the first counter must not unregister the second
+    assert lib.pxm_wav_release_iter_counter(shared.transform._plan._h, ctypes.c_void_p(cnt_a.t.data_ptr())) == 0
+    b._engine_advance(11)
+    np.testing.assert_array_equal(b._engine_state()[0].cpu().numpy(), private[1])
+    b._engine_stop()
+
+
 def test_plan_teardown_during_capture_is_deferred():
     """hipFree inside a stream capture would invalidate it: a plan destroyed while a capture is in progress only
     queues its frees (include/pxmcmc_amd.h: pxm_capture_begin / pxm_capture_end), and the captured graph replays."""

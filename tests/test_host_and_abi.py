@@ -151,3 +151,53 @@ def test_philox_reference_vector():
     assert [hex(int(v)) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
     out = philox.philox4x32_10(np.array([0xFFFFFFFF] * 4, dtype=np.uint32), np.array([0xFFFFFFFF] * 2, dtype=np.uint32))
     assert [hex(int(v)) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+# ---- L = 512 table accuracy by routes independent of the three-term recursion ("Wigner-d
+#      stability at L=512"; the HIP host tables and the oracle's fast tables share the recursion algorithm) ----------
+_L512_MS = (0, 1, -1, 2, -2, 255, -255, 400, -400, 511, -511)
+
+
+def _d_eig_column(el, m, n, thetas):
+    """d^el_{m n}(thetas) from the eigen-decomposition of J_y (oracle/wigner.py), one (m, n) pair only."""
+    from oracle import wigner
+
+    return wigner.wigner_d_eig_pair(el, m, n, thetas)
+
+
+@pytest.mark.parametrize("spin", [0, 2])
+def test_host_ring_tables_L512_against_eigen_route(spin):
+    """B^m[t][l] = (-1)^s sqrt((2l+1)/4pi) d^l_{m,-s}(theta_t) (pyssht convention,
+    pxmcmc/measurements.py:223-239) at L = 512, spins 0 and 2, low / middle / extreme orders, against
+    d^l = exp(-i theta J_y) -- no recursion in l anywhere on the checking side."""
+    L = 512
+    lib = _lib().lib
+    th = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+    B = np.zeros((L, L))
+    worst = 0.0
+    for m in _L512_MS:
+        assert lib.pxm_host_sht_tables(L, spin, m, B.ctypes.data, None) == 0
+        assert np.isfinite(B).all()
+        lo = max(abs(m), abs(spin))
+        assert not B[:, :lo].any(), "entries below max(|m|, |s|) must be exact zeros"
+        for el in (2, 3, 300, 511):
+            if el < lo:
+                continue
+            want = (-1.0) ** spin * np.sqrt((2 * el + 1) / (4 * np.pi)) * _d_eig_column(el, m, -spin, th)
+            worst = max(worst, np.abs(B[:, el] - want).max())
+    assert worst < 2e-11, worst  # (the eigen route itself is good to ~1e-12 at l = 511)
+
+
+def test_host_ring_tables_L512_against_scipy_harmonics():
+    """spin 0: the same table columns against scipy.special.sph_harm_y (its own Legendre recursion in m / l)."""
+    from scipy.special import sph_harm_y
+
+    L = 512
+    lib = _lib().lib
+    th = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+    B = np.zeros((L, L))
+    for m in _L512_MS:
+        assert lib.pxm_host_sht_tables(L, 0, m, B.ctypes.data, None) == 0
+        for el in sorted({abs(m), min(abs(m) + 1, L - 1), max(abs(m), 300), max(abs(m), 450), 511}):
+            want = sph_harm_y(el, m, th, 0.0).real
+            np.testing.assert_allclose(B[:, el], want, rtol=0, atol=2e-11 * max(1.0, np.abs(want).max()), err_msg=f"m={m} l={el}")

@@ -142,3 +142,21 @@ def test_s2_wavelets_l1_weights_length():
     reg = ref.S2_Wavelets_L1("synthesis", None, None, 1.0, L, 2, 2)
     assert reg.map_weights.size == 528
     reg.proxf(np.ones(528))
+
+
+@pytest.mark.parametrize("spin", [0, 2, -2])
+def test_literal_spin_harmonic_helper_matches_fast_oracle(spin):
+    """oracle.wigner.spin_harmonic_literal (the checker of the large-L GPU tests) == the fast oracle's inverse
+    transform of a unit coefficient, every (l, m) of a small bandlimit."""
+    from oracle import ssht, wigner
+
+    L = 12
+    th, ph = ssht.sample_positions(L)
+    T = ssht.get_transform(L, spin)
+    for el in range(abs(spin), L):
+        for m in range(-el, el + 1):
+            flm = np.zeros(L * L, dtype=complex)
+            flm[el * el + el + m] = 1.0
+            want = T.inverse(flm).reshape(L, 2 * L - 1)
+            got = wigner.spin_harmonic_literal(el, m, spin, th, ph)
+            assert np.abs(got - want).max() < 1e-12, (el, m)
