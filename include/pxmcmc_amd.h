@@ -41,6 +41,12 @@ int pxm_version(void);
 /* precision of the Box-Muller step of the Philox noise stream this library was built with: 32 (default: f32
  * transcendental units, deviates ~1e-6 relative) or 64 (-DPXM_NOISE_F64 build; pxmcmc/mcmc.py:193 draws fp64) */
 int pxm_noise_bits(void);
+/* Host-only (no GPU) check that every global address a launch of the plans' GEMM task lists and DFT groups can form
+ * -- including the clamped / aliased loads whose values are discarded -- lies inside its buffer.  Builds the plans
+ * named by `what` (1: SHT plan (L, spin); 2: wavelet plan (L, B, J_min) + Gram lists; 4: + weak-lensing lists) in
+ * dry-run mode and returns the number of address ranges verified, < 0 on a violation (pxm_last_error names the task).
+ * The same check runs at every real plan creation. */
+int64_t pxm_host_check_address_ranges(int L, double B, int J_min, int spin, int max_chains, int what);
 const char* pxm_last_error(void);
 /* number of visible HIP devices (0 when none; never fails) */
 int pxm_device_count(void);

@@ -23,6 +23,7 @@ c_i64, c_u64, c_int, c_dbl, c_vp = C.c_int64, C.c_uint64, C.c_int, C.c_double, C
 SIGNATURES = {
     "pxm_version": (c_int, []),
     "pxm_noise_bits": (c_int, []),
+    "pxm_host_check_address_ranges": (c_i64, [c_int, c_dbl, c_int, c_int, c_int, c_int]),
     "pxm_last_error": (C.c_char_p, []),
     "pxm_device_count": (c_int, []),
     "pxm_capture_begin": (c_int, []),

@@ -37,6 +37,28 @@ void note_stream(hipStream_t st);  // every stream-taking entry point reports it
 bool capture_in_progress();
 int drain_deferred();  // frees what is queued unless a capture is in progress; returns the number still queued
 
+// ---- device allocations with an address-range registry (host_api.cpp) ---------------------------
+// Every device buffer a kernel argument can point into is allocated through dev_alloc and registered with its
+// extent; the host-side models of the kernels' address formation (check_gemm_task_ranges, the DFT group check)
+// assert that every load / store a launch can form -- including the clamped and aliased loads whose values are
+// discarded -- stays inside ONE registered allocation.  Dry-run mode (pxm_host_check_address_ranges, no GPU): the
+// same plan-creation code runs with fake addresses from a bump allocator, uploads and table kernels skipped, so
+// the CPU test suite exercises the real task builders.
+bool dry_run();
+void set_dry_run(bool on);
+int dev_alloc_bytes(void** p, size_t bytes, const char* what);
+template <class T>
+inline int dev_alloc(T** p, size_t bytes, const char* what) {
+  return dev_alloc_bytes(reinterpret_cast<void**>(p), bytes, what);
+}
+int dev_upload(void* dst, const void* src, size_t bytes);  // host -> device copy (skipped in dry-run mode)
+int dev_zero(void* p, size_t bytes);
+// [lo, hi) in bytes lies inside one registered allocation?  On failure *msg names the nearest allocation.
+bool dev_range_ok(const void* lo, const void* hi, std::string* msg);
+int64_t ranges_checked();          // spans verified since the last reset (all plans of this process)
+void ranges_checked_add(int64_t n);
+void ranges_checked_reset();
+
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int round_down(int x, int m) { return x / m * m; }
 

@@ -149,27 +149,28 @@ int make_dft_plan(int L, DftPlan* p) {
   p->lds = ((size_t)R * b.M + b.M / 2) * 16;
   int th = R * b.M / 2;
   p->threads = th < 64 ? 64 : (th > 1024 ? 1024 : th);
-  PXM_HIP(hipMalloc(&p->d_chirp, b.chirp.size() * sizeof(double)));
-  PXM_HIP(hipMalloc(&p->d_bhat, b.bhat.size() * sizeof(double)));
-  PXM_HIP(hipMalloc(&p->d_tw, b.tw.size() * sizeof(double)));
-  PXM_HIP(hipMemcpy(p->d_chirp, b.chirp.data(), b.chirp.size() * sizeof(double), hipMemcpyHostToDevice));
-  PXM_HIP(hipMemcpy(p->d_bhat, b.bhat.data(), b.bhat.size() * sizeof(double), hipMemcpyHostToDevice));
-  PXM_HIP(hipMemcpy(p->d_tw, b.tw.data(), b.tw.size() * sizeof(double), hipMemcpyHostToDevice));
+  int rc;
+  if ((rc = dev_alloc(&p->d_chirp, b.chirp.size() * sizeof(double), "Bluestein chirp"))) return rc;
+  if ((rc = dev_alloc(&p->d_bhat, b.bhat.size() * sizeof(double), "Bluestein filter spectrum"))) return rc;
+  if ((rc = dev_alloc(&p->d_tw, b.tw.size() * sizeof(double), "radix-2 twiddles"))) return rc;
+  if ((rc = dev_upload(p->d_chirp, b.chirp.data(), b.chirp.size() * sizeof(double)))) return rc;
+  if ((rc = dev_upload(p->d_bhat, b.bhat.data(), b.bhat.size() * sizeof(double)))) return rc;
+  if ((rc = dev_upload(p->d_tw, b.tw.data(), b.tw.size() * sizeof(double)))) return rc;
   // L <= 256: eight points per lane, a pair of waves per ring set (dft5.hip); PXM_DFT_NO_W=1: the radix-2 in-LDS
   // kernels of this file for every size (independent implementation, kept as the L > 512 path and as a cross-check)
   if (dft5_r0(b.n) && !getenv("PXM_DFT_NO_W")) {
-    int rc = dft5_make_tables(b.n, &p->t5);
+    rc = dft5_make_tables(b.n, &p->t5);
     if (rc) return rc;
     dft5_geometry(b.n, &p->R5, &p->TR5, &p->lds5);
     p->use5 = true;
   }
   if (b.n > 512 && b.n <= 1023 && !getenv("PXM_DFT_NO_W")) {
-    int rc = dft6_make_tables(b.n, &p->t6);  // 256 < L <= 512: four waves per ring, 8 points per lane
+    rc = dft6_make_tables(b.n, &p->t6);  // 256 < L <= 512: four waves per ring, 8 points per lane
     if (rc) return rc;
     p->use6 = true;
   }
   static bool attr_set = false;
-  if (!attr_set) {
+  if (!attr_set && !dry_run()) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -183,7 +184,9 @@ void free_dft_plan(DftPlan* p) {
   if (p->d_chirp) deferred_free(p->d_chirp);
   if (p->d_bhat) deferred_free(p->d_bhat);
   if (p->d_tw) deferred_free(p->d_tw);
-  p->d_chirp = p->d_bhat = p->d_tw = nullptr;
+  if (p->t5.d_all) deferred_free(p->t5.d_all);  // (the wave kernels' tables: leaked until round 3)
+  if (p->t6.d_all) deferred_free(p->t6.d_all);
+  p->d_chirp = p->d_bhat = p->d_tw = p->t5.d_all = p->t6.d_all = nullptr;
 }
 
 static DftArgs make_args(const DftPlan& p) {

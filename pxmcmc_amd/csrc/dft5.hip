@@ -95,6 +95,28 @@ __device__ __forceinline__ void d5_barrier() {
 #endif
 }
 
+// Synchronisation of the TWO waves of a ring set (the even- and odd-bin halves exchange their shares through LDS):
+// an LDS counter per wave pair instead of a workgroup barrier.  With s_barrier the four ring sets of a workgroup moved
+// in lock-step -- all eight waves hit the LDS in the same phase and the vector ALUs in the next -- although only the
+// pairs exchange anything between the staging barriers; decoupled, the pairs drift apart and one pair's transposes
+// overlap another's butterflies.  LDS operations of a wave are performed in order, so the ds_add behind the wave's
+// ds_writes publishes them; the spin is bounded (a lost partner would otherwise hang the GPU: the kernel then runs
+// on with wrong data instead, which the parity tests catch).  -DPXM_D5_NO_PAIR_SYNC: workgroup barriers as before.
+__device__ __forceinline__ void d5_pair_sync(unsigned* cnt, unsigned target, int lane) {
+#ifdef PXM_D5_NO_PAIR_SYNC
+  (void)cnt; (void)target; (void)lane;
+  d5_barrier();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  unsigned spins = 0;
+  while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (int)target &&
+         ++spins < (1u << 18))
+    __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ void d5_wave_sync() {
 #if PXM_D5_ABLATE & 4
   return;
@@ -275,19 +297,21 @@ __device__ __forceinline__ double2 d5_sel(int half, double2 a, double2 b) { retu
 // p = 4 half + u (always kept in x[0..4): register indices stay compile-time).
 // SLOT selects one of two disjoint exchange regions of the planes (two exchanges may be in flight).
 template <int SLOT>
-__device__ __forceinline__ void d5_exchange_sum(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half) {
+__device__ __forceinline__ void d5_exchange_sum(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half,
+                                                unsigned* pcnt, unsigned& epoch) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) plane[256 * SLOT + 64 * u + lane] = d5_sel(half, x[u], x[4 + u]);
-  d5_barrier();
+  d5_pair_sync(pcnt, epoch += 2, lane);
 #pragma unroll
   for (int u = 0; u < 4; ++u) x[u] = cadd(d5_sel(half, x[4 + u], x[u]), pplane[256 * SLOT + 64 * u + lane]);
 }
 // own elements x[0..4) -> partner; x <- all 8 elements of the ring in natural order (both waves then hold them)
 template <int SLOT>
-__device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half) {
+__device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half,
+                                                 unsigned* pcnt, unsigned& epoch) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) plane[256 * SLOT + 64 * u + lane] = x[u];
-  d5_barrier();
+  d5_pair_sync(pcnt, epoch += 2, lane);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const double2 o = pplane[256 * SLOT + 64 * u + lane], own = x[u];
@@ -323,7 +347,11 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
   double2* plane = lds5 + wave * D5_PLANE;                                                  \
   double2* pplane = lds5 + (wave ^ 1) * D5_PLANE;                                           \
   const double2* tw = lds5 + 2 * R * D5_PLANE;        /* twiddles of the transform passes (LDS copy) */ \
-  for (int i = threadIdx.x; i < D5_TW; i += blockDim.x) lds5[2 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : a.wt[i - 448];
+  /* (row a = 0 of the wt copy, tw[448 .. 455], is never read: it holds the pair counters of d5_pair_sync) */ \
+  unsigned* pcnt = reinterpret_cast<unsigned*>(lds5 + 2 * R * D5_PLANE + 448) + unit;       \
+  unsigned epoch = 0;                                                                       \
+  for (int i = threadIdx.x; i < D5_TW; i += blockDim.x)                                     \
+    lds5[2 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : (i < 456 ? double2{0.0, 0.0} : a.wt[i - 448]);
 #define PXM_D5_SLOT(RING, K, CH) ((((RING)*n + (K)) << lgR) + (((CH) + ((K) >> rsh)) & (R - 1)))
 
 // stage -> G rows of every ring of the workgroup.  ZFILL (pixels -> rings): chain groups without a live chain do
@@ -352,7 +380,7 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 // the transform of x (all 8 elements in every wave of the ring) -> the wave's own elements of the result in x[0 .. P1)
 #define PXM_D5_TRANSFORM(SLOT)                                            \
   d5_dft_half<R0>(x, plane, lane, q, jb, half, a, tw);                    \
-  d5_exchange_sum<SLOT>(x, plane, pplane, lane, half);
+  d5_exchange_sum<SLOT>(x, plane, pplane, lane, half, pcnt, epoch);
 // own elements of x -> stage (after every plane of the workgroup is dead)
 #define PXM_D5_TO_STAGE                                                   \
   d5_barrier();                                                        \
@@ -560,8 +588,8 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
   if (!RING_OUT) return;
   PXM_D5_STAMP(2)  // prox + update + noise done
   // ---- forward transform of the updated ring
-  d5_exchange_fill<1>(x, plane, pplane, lane, half);  // both waves of the ring set need all 8 elements
-  d5_barrier();                                    // ... and every exchange read is done before the planes are reused
+  d5_exchange_fill<1>(x, plane, pplane, lane, half, pcnt, epoch);  // both waves of the ring set need all 8 elements
+  d5_pair_sync(pcnt, epoch += 2, lane);            // ... and every exchange read is done before the planes are reused
   PXM_D5_TRANSFORM(0)
   PXM_D5_STAMP(3)  // forward transform done
   PXM_D5_TO_STAGE
@@ -975,8 +1003,9 @@ int dft5_make_tables(int n, Dft5Tables* t) {
     for (int k0 = 0; k0 < r0; ++k0)
       for (int lane = 0; lane < 64; ++lane) put(bhat[2 * ((lane >> 3) + 8 * (lane & 7) + 64 * k0) + w]);
   }
-  PXM_HIP(hipMalloc(&t->d_all, h.size() * sizeof(double)));
-  PXM_HIP(hipMemcpy(t->d_all, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (int rc = dev_alloc(&t->d_all, h.size() * sizeof(double), "phi-DFT tables (8 points per lane)")) return rc;
+  if (int rc = dev_upload(t->d_all, h.data(), h.size() * sizeof(double))) return rc;
+  t->bytes = h.size() * sizeof(double);
   t->r0 = r0;
   t->cE = t->d_all + o_cE;
   t->cO = t->d_all + o_cO;
@@ -1099,16 +1128,46 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
     out->px_elems = 0;
     return 1;
   }
+  // address ranges of a grouped launch (host model of the kernels' global accesses): the ring array of every entry
+  // -- rows (m, t) with t < L, all ncol columns: loads of dead rings / padding slots are predicated off or clamped
+  // INSIDE the array -- and the seven table views must each lie inside one registered allocation; the coefficient
+  // side (X, T, noise, output: caller-owned, chain_stride elements per chain) is checked against chain_stride at
+  // launch (ring_end below: the clamped loads of elements past a ring's end re-read the ring's element 0)
+  {
+    std::string why;
+    int64_t nchk = 0;
+    for (size_t i = 0; i < v.size(); ++i) {
+      const Dft5Group& g = v[i];
+      const int Mh = 64 * g.r0;
+      const int64_t ring_doubles = (int64_t)(2 * g.a.L - 1) * g.a.Rp * ncol;
+      ++nchk;
+      if (!dev_range_ok(ws_base + g.g_off, ws_base + g.g_off + ring_doubles, &why)) {
+        set_error("DFT group entry " + std::to_string(i) + ": ring array outside its buffer: " + why);
+        return -1;
+      }
+      const int64_t tsize[7] = {2 * Mh, 2 * Mh, 2 * Mh, 2 * 8 * 64, 2 * 64, 2 * g.r0 * 64, 2 * g.r0 * 64};
+      for (int k = 0; k < 7; ++k) {
+        ++nchk;
+        const double* tb = ws_base + g.tbase + g.toff[k];
+        if (!dev_range_ok(tb, tb + tsize[k], &why)) {
+          set_error("DFT group entry " + std::to_string(i) + ": table view " + std::to_string(k) + " outside its buffer: " + why);
+          return -1;
+        }
+      }
+      out->ring_end = std::max(out->ring_end, g.ring0 + (int64_t)g.a.L * g.a.n);
+    }
+    ranges_checked_add(nchk);
+  }
   out->n = (int)v.size();
   out->all = v.size() == plans.size();
   out->blocks = b0;
   out->lds = lds;
   out->five = true;
   out->threads = 128 * plans[order[0]]->R5;
-  PXM_HIP(hipMalloc(&out->d, v.size() * sizeof(Dft5Group)));
-  PXM_HIP(hipMemcpy(out->d, v.data(), v.size() * sizeof(Dft5Group), hipMemcpyHostToDevice));
+  if (int rc = dev_alloc(&out->d, v.size() * sizeof(Dft5Group), "DFT group entries")) return rc;
+  if (int rc = dev_upload(out->d, v.data(), v.size() * sizeof(Dft5Group))) return rc;
   static bool attr = false;
-  if (!attr) {
+  if (!attr && !dry_run()) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring_group5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1126,6 +1185,7 @@ void dft_group_destroy(DftGroupList* g) {
 int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st, Profiler* prof) {
   // algorithmic bytes: rings read + written (16 B per slot and coefficient, every padded slot), state read, new state
   // written (live slots), thresholds read once
+  PXM_REQUIRE(g.ring_end <= out.chain_stride, "dft5_group_launch: a scale's coefficient block ends past chain_stride");
   const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
@@ -1136,6 +1196,7 @@ int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& 
 }
 
 int dft5_group_px2ring(const DftGroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st) {
+  PXM_REQUIRE(in.gidx || g.ring_end <= in.chain_stride, "dft5_group_px2ring: a scale's coefficient block ends past chain_stride");
   hipLaunchKernelGGL(k_px2ring_group5, dim3(g.blocks), dim3(g.threads), g.lds, st, reinterpret_cast<const Dft5Group*>(g.d), g.n,
                      ws, ncol, in, C);
   PXM_HIP(hipGetLastError());
@@ -1143,6 +1204,7 @@ int dft5_group_px2ring(const DftGroupList& g, double* ws, int ncol, const PxIn& 
 }
 
 int dft5_group_ring2px(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
+  PXM_REQUIRE(out.gidx || g.ring_end <= out.chain_stride, "dft5_group_ring2px: a scale's coefficient block ends past chain_stride");
   hipLaunchKernelGGL(k_ring2px_group5<false>, dim3(g.blocks), dim3(g.threads), g.lds, st, reinterpret_cast<const Dft5Group*>(g.d),
                      g.n, ws, ncol, out, C);
   PXM_HIP(hipGetLastError());
@@ -1207,8 +1269,8 @@ int dft6_make_tables(int n, Dft6Tables* t) {
   for (int w = 0; w < 4; ++w)
     for (int k0 = 0; k0 < 8; ++k0)
       for (int lane = 0; lane < 64; ++lane) put(bhat[4 * ((lane >> 3) + 8 * (lane & 7) + 64 * k0) + w]);
-  PXM_HIP(hipMalloc(&t->d_all, h.size() * sizeof(double)));
-  PXM_HIP(hipMemcpy(t->d_all, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (int rc = dev_alloc(&t->d_all, h.size() * sizeof(double), "phi-DFT tables (four waves per ring)")) return rc;
+  if (int rc = dev_upload(t->d_all, h.data(), h.size() * sizeof(double))) return rc;
   t->cA = t->d_all + o[0];
   t->cB = t->d_all + o[1];
   t->dA = t->d_all + o[2];

@@ -1,6 +1,11 @@
 // C-ABI entry points that need no GPU: error reporting and setup helpers.
 #include <cmath>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstdio>
+#include <map>
 #include <mutex>
 
 #include "../../include/pxmcmc_amd.h"
@@ -51,8 +56,90 @@ bool capture_in_progress() {
   return false;
 }
 
+// ---- allocation registry / dry-run allocator ----------------------------------------------------
+namespace {
+struct Region {
+  uintptr_t hi;
+  std::string what;
+  bool fake;
+};
+std::mutex g_reg_mu;
+std::map<uintptr_t, Region> g_regions;  // by start address
+bool g_dry = false;
+uintptr_t g_fake_next = (uintptr_t)0x700000000000ull;  // far from anything the process maps
+std::atomic<int64_t> g_ranges{0};
+}  // namespace
+
+bool dry_run() { return g_dry; }
+void set_dry_run(bool on) { g_dry = on; }
+int64_t ranges_checked() { return g_ranges.load(); }
+void ranges_checked_add(int64_t n) { g_ranges += n; }
+void ranges_checked_reset() { g_ranges = 0; }
+
+int dev_alloc_bytes(void** p, size_t bytes, const char* what) {
+  *p = nullptr;
+  bool fake = g_dry;
+  if (fake) {
+    std::lock_guard<std::mutex> lock(g_reg_mu);
+    *p = reinterpret_cast<void*>(g_fake_next);
+    g_fake_next += (bytes + 4095) / 4096 * 4096 + (1u << 20);  // a guard gap: neighbours never look contiguous
+  } else {
+    PXM_HIP(hipMalloc(p, bytes));
+  }
+  // test aid (dry-run only): PXM_RANGE_SELFTEST="<text>:<bytes>" registers every allocation whose description
+  // contains <text> that many bytes SHORTER than it is -- the range checks must then refuse the plan
+  if (fake && what)
+    if (const char* e = getenv("PXM_RANGE_SELFTEST")) {
+      const std::string spec(e);
+      const size_t c = spec.rfind(':');
+      if (c != std::string::npos && std::string(what).find(spec.substr(0, c)) != std::string::npos)
+        bytes -= std::min(bytes, (size_t)atoll(spec.c_str() + c + 1));
+    }
+  std::lock_guard<std::mutex> lock(g_reg_mu);
+  g_regions[(uintptr_t)*p] = Region{(uintptr_t)*p + bytes, what ? what : "?", fake};
+  return 0;
+}
+int dev_upload(void* dst, const void* src, size_t bytes) {
+  if (g_dry) return 0;
+  PXM_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int dev_zero(void* p, size_t bytes) {
+  if (g_dry) return 0;
+  PXM_HIP(hipMemset(p, 0, bytes));
+  return 0;
+}
+bool dev_range_ok(const void* lo, const void* hi, std::string* msg) {
+  const uintptr_t a = (uintptr_t)lo, b = (uintptr_t)hi;
+  std::lock_guard<std::mutex> lock(g_reg_mu);
+  auto it = g_regions.upper_bound(a);
+  if (it != g_regions.begin()) {
+    --it;
+    if (a >= it->first && b <= it->second.hi && a <= b) return true;
+    if (msg) {
+      char buf[256];
+      snprintf(buf, sizeof buf, "bytes [%+lld, %+lld) relative to allocation '%s' of %lld bytes", (long long)(a - it->first),
+               (long long)(b - it->first), it->second.what.c_str(), (long long)(it->second.hi - it->first));
+      *msg = buf;
+    }
+    return false;
+  }
+  if (msg) *msg = "address below every registered allocation";
+  return false;
+}
+// true: p was a fake (dry-run) address -- nothing to give back to the runtime
+static bool unregister_region(void* p) {
+  std::lock_guard<std::mutex> lock(g_reg_mu);
+  auto it = g_regions.find((uintptr_t)p);
+  if (it == g_regions.end()) return false;
+  const bool fake = it->second.fake;
+  g_regions.erase(it);
+  return fake;
+}
+
 void deferred_free(void* p) {
   if (!p) return;
+  if (unregister_region(p)) return;
   std::lock_guard<std::mutex> lock(g_grave_mu);
   g_grave_mem.push_back(p);
 }

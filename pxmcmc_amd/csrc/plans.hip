@@ -10,6 +10,7 @@
 #include <map>
 #include <string>
 #include <memory>
+#include <mutex>
 
 namespace pxm {
 
@@ -26,8 +27,8 @@ struct TaskList {
   int flags = 0;         // bit 0: tasks sum a second operand in while staging; bit 1: per-row operand scale (kernel variant)
 };
 
-static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std::vector<int> bls,
-                        std::vector<int> los = {}) {
+static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std::vector<int> bls, int ncol,
+                        const double* ws_base, const char* name, std::vector<int> los = {}) {
   out->bls = bls;
   los.resize(bls.size(), 0);
   out->los = los;
@@ -128,9 +129,10 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
     if (t.ks_off[0] || t.ks_off[1]) out->flags |= 2;
   }
   if (v.empty()) return 0;
-  PXM_HIP(hipMalloc(&out->d, v.size() * sizeof(GemmTask)));
-  PXM_HIP(hipMemcpy(out->d, v.data(), v.size() * sizeof(GemmTask), hipMemcpyHostToDevice));
-  return 0;
+  // address ranges of every load / store the launches of this list can form (sht_gemm.hip: check_gemm_task_ranges)
+  if (int rc = check_gemm_task_ranges(v, out->nslab, out->flags, ncol, ws_base, name)) return rc;
+  if (int rc = dev_alloc(&out->d, v.size() * sizeof(GemmTask), "GEMM task list")) return rc;
+  return dev_upload(out->d, v.data(), v.size() * sizeof(GemmTask));
 }
 
 // run a task list over all chain groups (16 chains = 32 columns per launch)
@@ -187,7 +189,7 @@ int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht
   PXM_REQUIRE(L >= 1, "pxm_sht_plan_create: Bandlimit must be greater than 0");
   PXM_REQUIRE(std::abs(spin) < L || L == 1, "pxm_sht_plan_create: |spin| must be < L");
   PXM_REQUIRE(max_chains >= 1, "pxm_sht_plan_create: max_chains must be >= 1");
-  PXM_REQUIRE(pxm_device_count() > 0, "pxm_sht_plan_create: no HIP device visible (the HIP path is the only path)");
+  PXM_REQUIRE(dry_run() || pxm_device_count() > 0, "pxm_sht_plan_create: no HIP device visible (the HIP path is the only path)");
   drain_deferred();
   // (owned by a guard until it is complete: every error return below releases what was built so far)
   std::unique_ptr<pxm_sht_plan_s, int (*)(pxm_sht_plan_t)> guard(new pxm_sht_plan_s(), pxm_sht_plan_destroy);
@@ -208,14 +210,14 @@ int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht
   p->offH = sz;
   p->offS = 2 * sz;
   const size_t bytes = (size_t)(2 * sz + (int64_t)p->Rp * p->ncol) * sizeof(double);
-  PXM_HIP(hipMalloc(&p->ws, bytes));
-  PXM_HIP(hipMemset(p->ws, 0, bytes));
+  if ((rc = dev_alloc(&p->ws, bytes, "SHT plan workspace"))) return rc;
+  if ((rc = dev_zero(p->ws, bytes))) return rc;
   for (int k = 0; k < 4; ++k) {
     std::vector<GemmTask> v;
     const bool e2r = kind_el_to_ring(k);
     append_gemm_tasks(*p->T, k, p->ncol, e2r ? p->offH : p->offG, L, p->Rp, e2r ? p->offG : p->offH, L, p->Rp, nullptr,
                       p->offS, p->ws, v);
-    rc = upload_tasks(v, p->T->paired, &p->tl[k], {L});
+    rc = upload_tasks(v, p->T->paired, &p->tl[k], {L}, p->ncol, p->ws, "SHT stage");
     if (rc) return rc;
   }
   *plan = guard.release();
@@ -343,6 +345,11 @@ struct SidePool {
 static int side_pool(SidePool** out) {
   static SidePool pools[16];
   int dev = 0;
+  if (dry_run()) {  // no streams without a GPU: the plan runs nothing in dry-run mode
+    static SidePool none;
+    *out = &none;
+    return 0;
+  }
   PXM_HIP(hipGetDevice(&dev));
   SidePool& sp = pools[dev & 15];
   if (!sp.ev_fork) {
@@ -422,7 +429,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   PXM_REQUIRE(plan, "pxm_wav_plan_create: null plan pointer");
   PXM_REQUIRE(L >= 1 && B > 1.0 && J_min >= 0, "pxm_wav_plan_create: bad (L, B, J_min)");
   PXM_REQUIRE(max_chains >= 1, "pxm_wav_plan_create: max_chains must be >= 1");
-  PXM_REQUIRE(pxm_device_count() > 0, "pxm_wav_plan_create: no HIP device visible (the HIP path is the only path)");
+  PXM_REQUIRE(dry_run() || pxm_device_count() > 0, "pxm_wav_plan_create: no HIP device visible (the HIP path is the only path)");
   drain_deferred();
   // (owned by a guard until it is complete: every error return below releases what was built so far)
   std::unique_ptr<pxm_wav_plan_s, int (*)(pxm_wav_plan_t)> guard(new pxm_wav_plan_s(), pxm_wav_plan_destroy);
@@ -481,8 +488,8 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   }
   p->offG2 = w; w += arr_size(L, p->ncol);  // (spin-2 rings of the weak-lensing attachment: 1/8 or so of the workspace)
   p->offS = w; w += (int64_t)p->Rp * p->ncol;
-  PXM_HIP(hipMalloc(&p->ws, (size_t)w * sizeof(double)));
-  PXM_HIP(hipMemset(p->ws, 0, (size_t)w * sizeof(double)));
+  if ((rc = dev_alloc(&p->ws, (size_t)w * sizeof(double), "wavelet plan workspace"))) return rc;
+  if ((rc = dev_zero(p->ws, (size_t)w * sizeof(double)))) return rc;
   // wavelet kernels: synthesis f_lm = kappa0 W^phi + sqrt(2pi) sum_j kappa_j W^j; analysis W^j = kappa_j f / sqrt(2pi)
   std::vector<double> k0, kap;
   tiling_axisym(L, B, J_min, k0, kap);
@@ -494,10 +501,10 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
       kc_syn[(size_t)s * p->Rp + el] = (s == 0) ? k : cs * k;
       kc_ana[(size_t)s * p->Rp + el] = (s == 0) ? k : ca * k;
     }
-  PXM_HIP(hipMalloc(&p->d_kc_syn, kc_syn.size() * sizeof(double)));
-  PXM_HIP(hipMalloc(&p->d_kc_ana, kc_ana.size() * sizeof(double)));
-  PXM_HIP(hipMemcpy(p->d_kc_syn, kc_syn.data(), kc_syn.size() * sizeof(double), hipMemcpyHostToDevice));
-  PXM_HIP(hipMemcpy(p->d_kc_ana, kc_ana.data(), kc_ana.size() * sizeof(double), hipMemcpyHostToDevice));
+  if ((rc = dev_alloc(&p->d_kc_syn, kc_syn.size() * sizeof(double), "synthesis kernel rows c kappa [nsc][Rp]"))) return rc;
+  if ((rc = dev_alloc(&p->d_kc_ana, kc_ana.size() * sizeof(double), "analysis kernel rows c kappa [nsc][Rp]"))) return rc;
+  if ((rc = dev_upload(p->d_kc_syn, kc_syn.data(), kc_syn.size() * sizeof(double)))) return rc;
+  if ((rc = dev_upload(p->d_kc_ana, kc_ana.data(), kc_ana.size() * sizeof(double)))) return rc;
   // support cut per scale: first degree with a non-zero kernel (compact support of kappa_j)
   // sup_lo: the support itself (row masks of the fused combine: class buffers are shared by scales with disjoint
   // supports); el_lo: the rows / contraction steps actually skipped (PXM_NO_SUPPORT_CUT=1: none, for A/B timing)
@@ -556,29 +563,29 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   }
   p->table_bytes[0] += p->TL->bytes[TAB_INV];
   p->table_bytes[1] += p->TL->bytes[TAB_INV_ADJ];
-  if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl, el_lo))) return rc;
-  if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl, el_lo))) return rc;
-  if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl, el_lo))) return rc;
-  if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl, el_lo))) return rc;
+  if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl, p->ncol, p->ws, "synthesis forward (all scales)", el_lo))) return rc;
+  if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl, p->ncol, p->ws, "synthesis-adjoint forward-adjoint (all scales)", el_lo))) return rc;
+  if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl, p->ncol, p->ws, "analysis inverse (all scales)", el_lo))) return rc;
+  if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl, p->ncol, p->ws, "analysis-adjoint inverse-adjoint (all scales)", el_lo))) return rc;
   v.clear();
   GemmFuse sum2;
   sum2.x2_base = p->offHB;
   if (p->fused_combine) append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHA, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v, 0, sum2);
   else append_gemm_tasks(*p->TL, TAB_INV, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v);
-  if ((rc = upload_tasks(v, true, &p->syn_inv, {L}))) return rc;
+  if ((rc = upload_tasks(v, true, &p->syn_inv, {L}, p->ncol, p->ws, "synthesis inverse at L"))) return rc;
   v.clear();
   append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
-  if ((rc = upload_tasks(v, true, &p->adj_invadj, {L}))) return rc;
+  if ((rc = upload_tasks(v, true, &p->adj_invadj, {L}, p->ncol, p->ws, "inverse-adjoint at L"))) return rc;
   v.clear();
   append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGR, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
-  if ((rc = upload_tasks(v, true, &p->adj_invadj_R, {L}))) return rc;
+  if ((rc = upload_tasks(v, true, &p->adj_invadj_R, {L}, p->ncol, p->ws, "inverse-adjoint at L (residual rings)"))) return rc;
   v.clear();
   append_gemm_tasks(*p->TL, TAB_FWD, p->ncol, p->offGL, L, p->Rp, p->offHL, L, p->Rp, nullptr, p->offS, p->ws, v);
-  if ((rc = upload_tasks(v, true, &p->ana_fwd, {L}))) return rc;
+  if ((rc = upload_tasks(v, true, &p->ana_fwd, {L}, p->ncol, p->ws, "analysis forward at L"))) return rc;
   v.clear();
   if (p->fused_combine) append_gemm_tasks(*p->TL, TAB_FWD_ADJ, p->ncol, p->offHA, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v, 0, sum2);
   else append_gemm_tasks(*p->TL, TAB_FWD_ADJ, p->ncol, p->offHL, L, p->Rp, p->offGL, L, p->Rp, nullptr, p->offS, p->ws, v);
-  if ((rc = upload_tasks(v, true, &p->anadj_fwdadj, {L}))) return rc;
+  if ((rc = upload_tasks(v, true, &p->anadj_fwdadj, {L}, p->ncol, p->ws, "analysis-adjoint forward-adjoint at L"))) return rc;
   // combine descriptors
   CombineArgs c;
   c.nsc = p->nsc;
@@ -1023,11 +1030,10 @@ __global__ void k_ring_residual(const double2* __restrict__ GL, const double2* _
 }  // namespace pxm
 extern "C" {
 
-int pxm_wav_ring_set_data(pxm_wav_plan_t p, const void* data, pxm_stream_t stream) {
-  PXM_REQUIRE(p && data, "pxm_wav_ring_set_data: null argument");
-  hipStream_t st = (hipStream_t)stream;
+// Gram tables + the two extra task lists of the ring-space step (first pxm_wav_ring_set_data of a plan)
+static int wav_make_gram_lists(pxm_wav_plan_t p) {
   int rc;
-  if (p->use_gram && !p->gram.d) {  // first use: Gram tables + the two extra task lists
+  if (p->use_gram && !p->gram.d) {
     if ((rc = get_tables(p->L, 0, 1u << TAB_GRAM, &p->TL))) return rc;
     wav_hold(p, p->TL);
     std::vector<GemmTask> v;
@@ -1035,12 +1041,20 @@ int pxm_wav_ring_set_data(pxm_wav_plan_t p, const void* data, pxm_stream_t strea
     fz.x2_base = p->offHB;
     fz.hd_base = p->offHD;
     append_gemm_tasks(*p->TL, TAB_GRAM, p->ncol, p->offHA, p->L, p->Rp, p->offHL, p->L, p->Rp, nullptr, p->offS, p->ws, v, 0, fz);
-    if ((rc = upload_tasks(v, true, &p->gram, {p->L}))) return rc;
+    if ((rc = upload_tasks(v, true, &p->gram, {p->L}, p->ncol, p->ws, "Gram step"))) return rc;
     p->gram.gram = true;
     v.clear();
     append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGD, p->L, p->Rp, p->offHD, p->L, p->Rp, nullptr, p->offS, p->ws, v);
-    if ((rc = upload_tasks(v, true, &p->adj_invadj_D, {p->L}))) return rc;
+    if ((rc = upload_tasks(v, true, &p->adj_invadj_D, {p->L}, p->ncol, p->ws, "inverse-adjoint of the data rings"))) return rc;
   }
+  return 0;
+}
+
+int pxm_wav_ring_set_data(pxm_wav_plan_t p, const void* data, pxm_stream_t stream) {
+  PXM_REQUIRE(p && data, "pxm_wav_ring_set_data: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if ((rc = wav_make_gram_lists(p))) return rc;
   PxIn in;
   in.f = (const double*)data;
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
@@ -1150,18 +1164,18 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
     wav_hold(p, p->T2);
     std::vector<double> k((size_t)p->Rp, 0.0);
     for (int el = 2; el < p->L; ++el) k[el] = -std::sqrt(((el + 2.0) * (el - 1.0)) / ((el + 1.0) * el));
-    PXM_HIP(hipMalloc(&p->d_wlk, k.size() * sizeof(double)));
-    PXM_HIP(hipMemcpy(p->d_wlk, k.data(), k.size() * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = dev_alloc(&p->d_wlk, k.size() * sizeof(double), "weak-lensing harmonic kernel k_l [Rp]"))) return rc;
+    if ((rc = dev_upload(p->d_wlk, k.data(), k.size() * sizeof(double)))) return rc;
     std::vector<GemmTask> v;
     GemmFuse sum2;
     sum2.x2_base = p->offHB;
     append_gemm_tasks(*p->T2, TAB_INV, p->ncol, p->offHA, p->L, p->Rp, p->offG2, p->L, p->Rp, p->d_wlk, p->offS, p->ws, v, 0, sum2);
-    if ((rc = upload_tasks(v, false, &p->wl_inv, {p->L}))) return rc;
+    if ((rc = upload_tasks(v, false, &p->wl_inv, {p->L}, p->ncol, p->ws, "weak-lensing spin-2 inverse"))) return rc;
     v.clear();
     GemmFuse rs;
     rs.rscale = p->d_wlk;
     append_gemm_tasks(*p->T2, TAB_INV_ADJ, p->ncol, p->offG2, p->L, p->Rp, p->offHL, p->L, p->Rp, nullptr, p->offS, p->ws, v, 0, rs);
-    if ((rc = upload_tasks(v, false, &p->wl_invadj, {p->L}))) return rc;
+    if ((rc = upload_tasks(v, false, &p->wl_invadj, {p->L}, p->ncol, p->ws, "weak-lensing spin-2 inverse-adjoint"))) return rc;
   }
   p->wl_gidx = pix2data;
   p->wl_gw = weight;
@@ -1244,6 +1258,37 @@ int pxm_wav_analysis_adjoint(pxm_wav_plan_t p, const void* X, void* f, int C, px
 int64_t pxm_wav_table_bytes(pxm_wav_plan_t p, int op) {
   if (!p || op < 0 || op > 1) return -1;
   return p->table_bytes[op];
+}
+
+// Host-only check of the address ranges (no GPU): runs the REAL plan builders in dry-run mode -- fake device
+// addresses, uploads and table kernels skipped -- so that every GEMM task list and DFT group entry of an SHT plan
+// (what & 1: bandlimit L, spin) and / or a wavelet plan (what & 2: (L, B, J_min), its Gram lists, and with what & 4
+// its weak-lensing lists) goes through check_gemm_task_ranges / the group check.  Returns the number of address
+// ranges verified, < 0 (and pxm_last_error) if one leaves its buffer.  Test aid: PXM_RANGE_SELFTEST="<text>:<bytes>"
+// registers the dry-run allocations whose description contains <text> that much shorter (host_api.cpp) -- e.g. the
+// per-row scale vectors one row tile short, the round-2 fault -- and the check must then refuse the plan.
+int64_t pxm_host_check_address_ranges(int L, double B, int J_min, int spin, int max_chains, int what) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  PXM_REQUIRE(!capture_in_progress(), "pxm_host_check_address_ranges: not during a stream capture");
+  set_dry_run(true);
+  ranges_checked_reset();
+  int rc = 0;
+  if (what & 1) {
+    pxm_sht_plan_t sp = nullptr;
+    rc = pxm_sht_plan_create(L, spin, max_chains, 0, &sp);
+    if (sp) pxm_sht_plan_destroy(sp);
+  }
+  if (!rc && (what & 2)) {
+    pxm_wav_plan_t wp = nullptr;
+    rc = pxm_wav_plan_create(L, B, J_min, max_chains, 0, &wp);
+    if (!rc) rc = wav_make_gram_lists(wp);
+    if (!rc && (what & 4) && L >= 3) rc = pxm_wav_wl_attach(wp, nullptr, nullptr, (int64_t)L * (2 * L - 1));
+    if (wp) pxm_wav_plan_destroy(wp);
+  }
+  tables_trim();  // the dry-run table entries (fake addresses) never outlive the call
+  set_dry_run(false);
+  return rc ? -1 : ranges_checked();
 }
 
 }  // extern "C"

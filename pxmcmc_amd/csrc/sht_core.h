@@ -167,11 +167,16 @@ inline double gemm_alg_bytes(int L, bool paired, int C, int el_lo = 0) {
 }
 
 int gemm_rows_per_task(int ncol);
+// host model of every address k_sht_gemm forms for a task list (sht_gemm.hip); < 0 + error text when a range leaves
+// its allocation
+int check_gemm_task_ranges(const std::vector<GemmTask>& v, int nslab, int flags, int ncol, const double* ws_base,
+                           const char* list_name);
 
 // ---- DFT stage ---------------------------------------------------------------
 // device tables of the eight-points-per-lane path (dft5.hip): one allocation, typed views into it
 struct Dft5Tables {
   double* d_all = nullptr;
+  size_t bytes = 0;
   int r0 = 0;  // Mh / 64
   const double *cE = nullptr, *cO = nullptr, *dO = nullptr, *tw1 = nullptr, *wt = nullptr, *bE = nullptr, *bO = nullptr;
 };
@@ -246,6 +251,7 @@ struct DftGroupList {
   int n = 0, blocks = 0;
   size_t lds = 0;
   double px_elems = 0;  // sum over scales of bl (2 bl - 1): coefficients per chain slot
+  int64_t ring_end = 0; // largest ring0 + L n over the entries: the launches require it <= chain_stride
   std::vector<char> member;  // per scale: its rings <-> pixels launches are part of this group
   bool all = false;          // every scale is a member (needed by the fused rings -> X' -> rings step)
 };

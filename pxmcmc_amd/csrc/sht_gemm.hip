@@ -373,6 +373,65 @@ int profiler_read(Profiler::Pool* p, double* ms, int64_t* launches, double* byte
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Host model of the addresses k_sht_gemm forms.  KEEP IN STEP WITH THE KERNEL ABOVE: every global load and store of
+// the kernel has one line here, including the loads whose values are discarded (clamped chunk indices past the end
+// of a task, row tiles a wave does not own aliased to tile 0, a missing second operand / scale aliased to the
+// first operand).  Such a load faulted in round 2 (commit 0808422: the batched epilogue read the per-row scale of
+// tiles the wave did not own, past the end of the vector); a host check of task SHAPES could not see it, this
+// check of address RANGES does, without a GPU.  For every task and every column group run_tasks can launch, each
+// range must lie inside ONE registered device allocation (common.h: dev_alloc / dev_range_ok).
+// ---------------------------------------------------------------------------------------
+int check_gemm_task_ranges(const std::vector<GemmTask>& v, int nslab, int flags, int ncol, const double* ws_base,
+                           const char* list_name) {
+  int64_t n = 0;
+  std::string why;
+  auto bad = [&](size_t ti, const char* what, int col0) {
+    set_error(std::string("GEMM task address range outside its buffer: list '") + list_name + "', task " + std::to_string(ti) +
+              ", column group " + std::to_string(col0) + ", " + what + ": " + why);
+    return -1;
+  };
+  // [lo, hi] in doubles relative to the workspace base (the kernel's X / Y argument)
+  auto ok = [&](int64_t lo, int64_t hi) {
+    ++n;
+    return lo <= hi && dev_range_ok(ws_base + lo, ws_base + hi + 1, &why);
+  };
+  const bool TWO = flags & 1, SK = flags & 2;
+  for (size_t ti = 0; ti < v.size(); ++ti) {
+    const GemmTask& t = v[ti];
+    if (t.n_rt == 0) continue;  // padding entry: the workgroup exits before forming any address
+    const int nch = (t.k_end - t.k_beg) / KC;
+    // table stream: tab[r] + (2 cc + {0, 1}) * 64 double2, cc <= nch - 1, row tile <= n_rt - 1 (others alias tile 0),
+    // lane < 64, two doubles each
+    if (!ok(t.tab_off, t.tab_off + (int64_t)(t.n_rt - 1) * t.rt_stride + (int64_t)(2 * (nch - 1) + 1) * 128 + 127))
+      return bad(ti, "ring-table stream", 0);
+    for (int col0 = 0; col0 < ncol; col0 += 32) {
+      const int CT = (ncol - col0 >= 32) ? 2 : 1;
+      for (int slab = 0; slab < nslab; ++slab) {
+        // operand staging: X + x_off[slab] + col0 + cin + (k_beg + kr + cs KC) ncol, cin < 16 CT, kr < KC, cs <= nch - 1
+        const int64_t lo = col0 + (int64_t)t.k_beg * ncol, hi = col0 + 16 * CT - 1 + (int64_t)(t.k_end - 1) * ncol;
+        if (!ok(t.x_off[slab] + lo, t.x_off[slab] + hi)) return bad(ti, "operand staging", col0);
+        if (TWO && t.x2_off[slab] && !ok(t.x2_off[slab] + lo, t.x2_off[slab] + hi)) return bad(ti, "second operand staging", col0);
+        // per-k operand scale: X + ks_off[slab >> 1] + k_beg + kr + cs KC
+        if (SK && t.ks_off[slab >> 1] && !ok(t.ks_off[slab >> 1] + t.k_beg, t.ks_off[slab >> 1] + t.k_end - 1))
+          return bad(ti, "operand scale vector", col0);
+        // epilogue: rows row0 + 16 tile + kq + 4 q, tile <= n_rt - 1 (a tile the wave does not own: tile 0)
+        const int64_t r_lo = t.row0, r_hi = t.row0 + 16 * t.n_rt - 1;
+        if (t.hd_off[slab] && !ok(t.hd_off[slab] + r_lo * ncol, t.hd_off[slab] + r_hi * ncol + 1))
+          return bad(ti, "affine data term", col0);
+        if (t.rs_off[slab >> 1] && !ok(t.rs_off[slab >> 1] + r_lo, t.rs_off[slab >> 1] + r_hi))
+          return bad(ti, "per-row output scale", col0);
+        // stores: Y + y_off[slab] + col0 + cin + cl + row ncol for the owned rows inside [row_lo, row_hi)
+        const int64_t s_lo = std::max<int64_t>(r_lo, t.row_lo[slab >> 1]), s_hi = std::min<int64_t>(r_hi, (int64_t)t.row_hi[slab >> 1] - 1);
+        if (s_lo <= s_hi && !ok(t.y_off[slab] + col0 + s_lo * ncol, t.y_off[slab] + col0 + 16 * CT - 1 + s_hi * ncol))
+          return bad(ti, "result rows", col0);
+      }
+    }
+  }
+  ranges_checked_add(n);
+  return 0;
+}
+
 // GEMM workgroup geometry: 8 waves x 1 row tile per wave (a task covers 8 row tiles).  (4 waves x 1 and 4 x 2 were
 // A/B variants until round 2: 26.1 us and slower for the Gram launch, operand staged twice as often.)
 int gemm_rows_per_task(int ncol) {
@@ -552,7 +611,8 @@ static int build_kind(ShtTables& T, int kind, const double* d_B, const double* d
     total += (int64_t)((rows_el ? Rp - kb : Rp) / 16) * ((k_el ? Rp - kb : Rp) / 8) * 128;
   }
   T.bytes[kind] = (size_t)total * sizeof(double);
-  PXM_HIP(hipMalloc(&T.d_tab[kind], T.bytes[kind]));
+  if (int rc = dev_alloc(&T.d_tab[kind], T.bytes[kind], "ring table")) return rc;
+  if (dry_run()) return 0;  // layout only: no GPU to tile the tables on
   for (int i = 0; i < T.n_m; ++i) {
     const int kb = T.k_beg[kind][i];
     const double* src;
@@ -576,9 +636,12 @@ static int build_kind(ShtTables& T, int kind, const double* d_B, const double* d
 
 int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out) {
   std::lock_guard<std::mutex> lock(g_tab_mutex);
-  int dev = 0;
-  PXM_HIP(hipGetDevice(&dev));
-  auto key = std::make_pair(L * 8 + dev, spin);
+  int dev = 15;  // (dry-run entries -- fake addresses -- live under a device id no node has: never handed to a real plan)
+  if (!dry_run()) {
+    PXM_HIP(hipGetDevice(&dev));
+    PXM_REQUIRE(dev >= 0 && dev < 15, "get_tables: device index outside [0, 15)");
+  }
+  auto key = std::make_pair(L * 16 + dev, spin);
   ShtTables* T = nullptr;
   auto it = g_tab_cache.find(key);
   if (it != g_tab_cache.end()) T = it->second;
@@ -594,7 +657,13 @@ int get_tables(int L, int spin, unsigned kinds_mask, ShtTables** out) {
   unsigned missing = 0;
   for (int k = 0; k < TAB_KINDS; ++k)
     if ((kinds_mask >> k & 1u) && !T->d_tab[k]) missing |= 1u << k;
-  if (missing) {
+  if (missing && dry_run()) {
+    for (int k = 0; k < TAB_KINDS; ++k)
+      if (missing >> k & 1u) {
+        int rc = build_kind(*T, k, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+      }
+  } else if (missing) {
     const int Rp = T->Rp;
     const size_t dense = (size_t)T->n_m * Rp * Rp;
     std::vector<double> hB(dense, 0.0);

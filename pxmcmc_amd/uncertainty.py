@@ -16,17 +16,15 @@ def credible_interval_range(chain, alpha=0.05):
 
 
 def wavelet_credible_interval_range(chain, L, B, J_min, alpha=0.05):
-    """credible-interval maps per wavelet scale, MW (theta, phi) format (pxmcmc/uncertainty.py:19-40)"""
-    bls = _multires_bandlimits(L, B, J_min)
-    scale_start = 0
-    wav_ci_ranges = []
-    for bl in bls:
-        bl = int(bl)
-        scale_length = mw_size(bl)
-        wav = chain[:, scale_start : scale_start + scale_length]
-        wav_ci_ranges.append(credible_interval_range(wav, alpha).reshape((bl, 2 * bl - 1)))
-        scale_start += scale_length
-    return wav_ci_ranges
+    """credible-interval maps per wavelet scale, MW (theta, phi) format (pxmcmc/uncertainty.py:19-40): the quantile
+    range of every coefficient at once, cut at the block boundaries of the coefficient vector"""
+    bls = [int(bl) for bl in _multires_bandlimits(L, B, J_min)]
+    edges = np.cumsum([mw_size(bl) for bl in bls])
+    chain = np.asarray(chain)
+    if chain.shape[1] != edges[-1]:
+        raise ValueError("chain has %d parameters, the wavelet layout %d" % (chain.shape[1], edges[-1]))
+    blocks = np.split(credible_interval_range(chain, alpha), edges[:-1])
+    return [blk.reshape(bl, 2 * bl - 1) for blk, bl in zip(blocks, bls)]
 
 
 def credible_region_threshold(logpis, alpha=0.05):

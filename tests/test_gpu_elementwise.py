@@ -162,6 +162,46 @@ def test_philox_stream_matches_oracle():
     assert np.array_equal(a[2:], b)
 
 
+def test_noise_stream_moments_and_tails_over_1e8_draws():
+    """The production noise runs Box-Muller on the f32 transcendental units (csrc/philox.h: deviates ~1e-6 relative;
+    the reference draws fp64 randn, pxmcmc/mcmc.py:193).  Bound on what that can do to the chain: over 1.3e8 deviates
+    of the real stream (16 chains x 64 iterations) the first four moments, the |z| > 4 and |z| > 5 tail rates and the
+    lag-1 / cross-chain correlations match N(0,1) within 5 standard errors, and so does the complex stream."""
+    import torch
+
+    from pxmcmc_amd import ops
+
+    n, C, its = 1 << 17, 16, 64
+    N = n * C * its
+    assert N >= 1e8
+    acc = torch.zeros(8, dtype=torch.float64, device="cuda")  # sums of z, z^2, z^3, z^4, [|z|>4], [|z|>5], lag-1, cross-chain
+    for it in range(its):
+        z = ops.randn(n, C_=C, complex_=False, seed=2024, chain0=0, it=it)
+        z2 = z * z
+        acc += torch.stack([z.sum(), z2.sum(), (z2 * z).sum(), (z2 * z2).sum(), (z.abs() > 4).sum().double(),
+                            (z.abs() > 5).sum().double(), (z[:, 1:] * z[:, :-1]).sum(), (z[0::2] * z[1::2]).sum()])
+    a = acc.cpu().numpy()
+    m1, m2, m3, m4 = a[:4] / N
+    # standard errors of the sample moments of N(0,1): sqrt(var(z^k) / N), var(z)=1, var(z^2)=2, var(z^3)=15, var(z^4)=96
+    assert abs(m1) < 5 * np.sqrt(1 / N), m1
+    assert abs(m2 - 1) < 5 * np.sqrt(2 / N), m2
+    assert abs(m3) < 5 * np.sqrt(15 / N), m3
+    assert abs(m4 - 3) < 5 * np.sqrt(96 / N), m4
+    from scipy import stats
+
+    for k, thr in ((4, 4.0), (5, 5.0)):
+        p = 2 * stats.norm.sf(thr)
+        assert abs(a[k] - N * p) < 5 * np.sqrt(N * p) + 1, (thr, a[k], N * p)
+    assert abs(a[6] / (C * its * (n - 1))) < 5 / np.sqrt(C * its * (n - 1))  # neighbouring elements of a chain
+    assert abs(a[7] / (N / 2)) < 5 / np.sqrt(N / 2)                          # the two deviates of a chain pair
+    # complex stream (params.complex): real and imaginary parts of an element come from one Box-Muller pair
+    zc = ops.randn(1 << 22, C_=4, complex_=True, seed=7, chain0=3, it=5)
+    Nc = zc.numel()
+    assert abs(float(zc.real.mean())) < 5 / np.sqrt(Nc) and abs(float(zc.imag.mean())) < 5 / np.sqrt(Nc)
+    assert abs(float((zc.real ** 2).mean()) - 1) < 5 * np.sqrt(2 / Nc) and abs(float((zc.imag ** 2).mean()) - 1) < 5 * np.sqrt(2 / Nc)
+    assert abs(float((zc.real * zc.imag).mean())) < 5 / np.sqrt(Nc)
+
+
 def test_weaklensing_pieces_golden():
     from pxmcmc_amd.measurements import WeakLensing, WeakLensingHarmonic
 

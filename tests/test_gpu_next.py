@@ -159,6 +159,49 @@ def test_example_script_end_to_end(tmp_path):
     assert rel < 1.0  # after 400 iterations from zero the posterior mean already explains part of the signal
 
 
+def test_weaklensing_example_flow_and_operator_vs_oracle(tmp_path):
+    """examples/weaklensing_synthetic.py = experiments/weaklensing/main.py:85-147 on synthetic kappa:
+    the load_gammas-style preparation, build_mask, ngal = 30, WeakLensing + SphericalWaveletTransform,
+    PxMALA(tune_delta=True).  At L = 64 the operator the example builds -- fused synthesis + weak-lensing plan, on the
+    Euclid-like mask -- is compared with the oracle's literal composition (forward and calc_gradg), the prepared data
+    with the oracle's own preparation, and a short PxMALA run must adapt delta inside its clip range."""
+    import os
+    import runpy
+
+    from oracle import pxmcmc_np as ref
+    from oracle import ssht
+    from pxmcmc_amd.saving import load_mcmc
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mod = runpy.run_path(os.path.join(root, "examples", "weaklensing_synthetic.py"))
+    L, B, J_min = 64, 2, 2
+    out = _quiet(mod["main"], ["--L", str(L), "--algo", "pxmala", "--nsamples", "4", "--ngap", "5", "--nburn", "20", "--chains", "2",
+                               "--outdir", str(tmp_path)])
+    op, mask, gammas, mcmc = out["operator"], out["mask"], out["gammas"], out["mcmc"]
+    assert 0.2 < 1 - mask.mean() < 0.6  # two 20-degree-wide bands are masked
+    assert op._wl_plan() is not None  # the fused operator is the one that ran
+    # the data preparation against the oracle: beam in harmonic space, MW map, shear on the same mask
+    klm = mod["synthetic_kappa_lm"](L, 3)
+    oop_wl = ref.WeakLensing(L, mask=mask, ngal=np.full_like(mask, 30))
+    kappa = ssht.inverse(klm * mod["beam"](L), L, 0).ravel()
+    want = oop_wl.forward(kappa)
+    assert gammas.shape == want.shape and np.abs(gammas - want).max() < 1e-11 * np.abs(want).max()
+    # operator parity on that mask
+    T = ref.SphericalWaveletTransform(L, B, J_min)
+    oop = ref.ForwardOperator(want, 1 / oop_wl.inv_cov, "synthesis", T, oop_wl, T.ncoefs)
+    X = np.random.default_rng(0).normal(size=T.ncoefs) + 0j
+    fo = oop.forward(X)
+    go = oop.calc_gradg(fo)
+    f = op.forward(X)
+    assert np.abs(f - fo).max() < 1e-10 * np.abs(fo).max()
+    assert np.abs(op.calc_gradg(f) - go).max() < 1e-9 * np.abs(go).max()
+    # the run itself
+    data, attrs = load_mcmc(out["path"])
+    assert data["chain"].shape[:2] == (2, 4) and attrs["L"] == L and np.isfinite(data["chain"]).all()
+    d = np.asarray(mcmc.deltas_trace)[1:]
+    assert (d <= 1e-6 / 2 / 2 + 1e-20).all() and (d > 0).all()  # adapted delta <= lmda / 2, lmda = delta0 / 2 (mcmc.py:277-279)
+
+
 @pytest.mark.parametrize("kind", ["ndarray", "sparse", "torch"])
 def test_g12_full_covariance_matches_reference(kind):
     """a 2-D covariance is inverted on the host at set-up and applied by the HIP CSR SpMV in

@@ -201,3 +201,39 @@ def test_host_ring_tables_L512_against_scipy_harmonics():
         for el in sorted({abs(m), min(abs(m) + 1, L - 1), max(abs(m), 300), max(abs(m), 450), 511}):
             want = sph_harm_y(el, m, th, 0.0).real
             np.testing.assert_allclose(B[:, el], want, rtol=0, atol=2e-11 * max(1.0, np.abs(want).max()), err_msg=f"m={m} l={el}")
+
+
+# ---- address ranges of every load / store the GEMM task lists and DFT groups can form (no GPU: dry-run plans) ------
+@pytest.mark.parametrize("L", [10, 64, 256, 272, 300, 511, 512, 520])
+def test_address_ranges_of_every_task_list_stay_inside_their_buffers(L):
+    """The real plan builders in dry-run mode (include/pxmcmc_amd.h: pxm_host_check_address_ranges): for spins 0 / 2
+    and chain capacities 1, 3, 16, 33 every global address a GEMM launch (operand / second operand / scale / table /
+    affine term / row scale / result, with the kernel's clamped chunk indices and aliased row tiles) or a grouped DFT
+    launch (ring arrays, table views) can form lies inside one allocation.  This is the check that catches the
+    round-2 fault (a discarded-value load past the end of the per-row scale vector) without a GPU."""
+    lib = _lib().lib
+    B, J_min = (1.5, 2) if L == 64 else (2.0, 2)
+    for C in (1, 3, 16, 33):
+        n = lib.pxm_host_check_address_ranges(L, B, J_min, 0, C, 1 | 2 | 4)
+        assert n > 0, lib.pxm_last_error().decode()
+        n2 = lib.pxm_host_check_address_ranges(L, B, J_min, 2, C, 1)
+        assert n2 > 0, lib.pxm_last_error().decode()
+
+
+@pytest.mark.parametrize("spec,what,expect", [
+    ("kernel rows:128", 2, "scale"),                       # c kappa rows one row tile short: the round-2 fault
+    ("weak-lensing harmonic kernel:128", 7, "scale"),      # k_l vector one row tile short
+    ("ring table:2048", 1, "ring-table stream"),           # a table one k-chunk short
+    ("workspace:8", 3, "GEMM task address range"),         # the last double of the workspace missing
+    ("phi-DFT tables:16", 2, "DFT group entry"),           # the last complex of a DFT table missing
+])
+def test_address_range_check_refuses_short_buffers(spec, what, expect, monkeypatch):
+    """negative control: with one class of buffers registered shorter than it is the check must fail, naming the access"""
+    lib = _lib().lib
+    assert lib.pxm_host_check_address_ranges(64, 2.0, 2, 0, 3, what) > 0
+    monkeypatch.setenv("PXM_RANGE_SELFTEST", spec)
+    assert lib.pxm_host_check_address_ranges(64, 2.0, 2, 0, 3, what) < 0
+    msg = lib.pxm_last_error().decode()
+    assert expect in msg, msg
+    monkeypatch.delenv("PXM_RANGE_SELFTEST")
+    assert lib.pxm_host_check_address_ranges(64, 2.0, 2, 0, 3, what) > 0  # and nothing of the failed plan lingers
