@@ -33,8 +33,10 @@ def philox4x32_10(ctr, key):
     return np.stack(c, axis=-1)
 
 
-def normal_pairs(seed, chain, index, it):
-    """two N(0,1) draws per counter: arrays z0, z1 shaped like ``index``."""
+def normal_pairs(seed, chain, index, it, bits=32):
+    """two N(0,1) draws per counter: arrays z0, z1 shaped like ``index``.  ``bits``: the Box-Muller precision of the
+    library under test (pxm_noise_bits): 32 = the f32 transcendental units of the default build, mirrored in float32;
+    64 = the -DPXM_NOISE_F64 build, evaluated here with numpy's own float64 log / sqrt / cos / sin."""
     index = np.asarray(index, dtype=np.uint64)
     with np.errstate(over="ignore"):
         key = np.uint64(seed) + np.uint64(chain) * np.uint64(0x9E3779B97F4A7C15)
@@ -53,6 +55,9 @@ def normal_pairs(seed, chain, index, it):
     b = ((r[..., 3] << np.uint64(32)) | r[..., 2]) >> np.uint64(11)
     u1 = (a.astype(np.float64) + 0.5) * 2.0 ** -53
     u2 = (b.astype(np.float64) + 0.5) * 2.0 ** -53
+    if bits == 64:
+        rad = np.sqrt(-2.0 * np.log(u1))
+        return rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)
     # the device evaluates Box-Muller on its float transcendental units (csrc/philox.h box_muller_fast):
     # the exponent of u1 exactly, log2 of the mantissa / sqrt / sin / cos in float32.  Mirrored here in
     # float32; the hardware units differ from numpy's by a few float ulps (tests allow 2e-5 absolute).
@@ -67,15 +72,15 @@ def normal_pairs(seed, chain, index, it):
 REAL_TWEAK = 0xD1B54A32D192ED03
 
 
-def randn_real(n, seed, chain, it):
+def randn_real(n, seed, chain, it, bits=32):
     """real stream: chain ch takes draw (ch & 1) of the pair keyed (seed + tweak, ch >> 1) at counter (e, it)."""
     e = np.arange(n, dtype=np.uint64)
     with np.errstate(over="ignore"):
         s = np.uint64(seed) + np.uint64(REAL_TWEAK)
-    z0, z1 = normal_pairs(s, int(chain) >> 1, e, it)
+    z0, z1 = normal_pairs(s, int(chain) >> 1, e, it, bits)
     return z1 if (int(chain) & 1) else z0
 
 
-def randn_complex(n, seed, chain, it):
-    z0, z1 = normal_pairs(seed, chain, np.arange(n, dtype=np.uint64), it)
+def randn_complex(n, seed, chain, it, bits=32):
+    z0, z1 = normal_pairs(seed, chain, np.arange(n, dtype=np.uint64), it, bits)
     return z0 + 1j * z1

@@ -37,6 +37,13 @@
 #ifndef PXM_D5_ABLATE
 #define PXM_D5_ABLATE 0
 #endif
+// update epilogue of the fused kernel: Philox + Box-Muller of a lane's four elements ahead of the operand loads (1,
+// default: 124 VGPR, no spills, 66.6 us per grouped launch), between the loads and their use (0: 8 spilled registers,
+// one of them a freshly loaded threshold, i.e. an s_waitcnt vmcnt(0) right behind the loads: 68.4 us) or behind the
+// loads as a block (2: 12 spills)
+#ifndef PXM_D5_PHILOX_FIRST
+#define PXM_D5_PHILOX_FIRST 1
+#endif
 
 namespace pxm {
 
@@ -509,6 +516,18 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
       double2 xs[4], wn[4];
       double Ts[4];
       int64_t eo[4];  // element offset from e0 (or to the ring's element 0)
+#if PXM_D5_PHILOX_FIRST == 1
+      // The noise of the four elements BEFORE the operand loads, one element at a time: the fp64 Box-Muller keeps ~40
+      // registers live, and evaluated between the loads and their use (beside xs / Ts / the addresses) it cost 250
+      // spilled registers in this kernel (93 instead of 70 us per launch).
+      double2 wph[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        wph[u] = double2{0.0, 0.0};
+        if (!out.noise) wph[u] = px_noise_philox(out, ch, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int p = g0 + u;
@@ -531,6 +550,16 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
 #pragma unroll
         for (int u = 0; u < 4; ++u) wn[u] = double2{0.0, 0.0};
       }
+#if PXM_D5_PHILOX_FIRST == 2
+      double2 wph[4];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        wph[u] = double2{0.0, 0.0};
+        if (!out.noise) wph[u] = px_noise_philox(out, ch, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int p = g0 + u;
@@ -541,7 +570,9 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
         const int64_t off = (int64_t)(8 * R0) * p;
         const double2 y{x[p].x, -x[p].y};
         double2 w = wn[u];
-#if !(PXM_D5_ABLATE & 1)
+#if PXM_D5_PHILOX_FIRST
+        if (!out.noise) w = wph[u];
+#elif !(PXM_D5_ABLATE & 1)
         if (!out.noise) w = px_noise_philox(out, ch, e0 + off, it_eff);
 #endif
         x[p] = px_update(out, xs[u], Ts[u], y, w);

@@ -16,9 +16,15 @@ __host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+    // three-input xor in one VALU operation (v_bitop3_b32, truth table 0x96): two instead of four per round
+    const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c[1], k0, 0x96);
+    const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c[3], k1, 0x96);
+#else
     const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n1 = (uint32_t)p1;
     const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+#endif
+    const uint32_t n1 = (uint32_t)p1;
     const uint32_t n3 = (uint32_t)p0;
     c[0] = n0;
     c[1] = n1;
@@ -43,14 +49,67 @@ __device__ inline NormalPair box_muller_fast(double u1, double u2) {
   return NormalPair{(double)(r * __builtin_amdgcn_cosf(turns)), (double)(r * __builtin_amdgcn_sinf(turns))};
 }
 
-// The same transform in double precision (build switch -DPXM_NOISE_F64: log / sincospi / sqrt of the fp64 math
-// library; deviates to fp64 round-off, like the reference's numpy randn).  pxm_noise_bits() reports which one a
-// library was built with; BASELINE.md gives the step time both ways.
+// The same transform in double precision (build switch -DPXM_NOISE_F64; pxm_noise_bits() reports which one a
+// library was built with, BASELINE.md gives the step time both ways): branch-free, no tables, ~75 fp64 instructions
+// per pair against ~20 for the f32 units (the math library's log + sincospi + sqrt cost five times that in the fused
+// DFT kernel).  Deviates agree with numpy's float64 evaluation of the same formulae to ~1e-15 (oracle/philox.py).
+//   ln u1 = e ln 2 + 2 atanh(s), u1 = m 2^e with m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), |s| <= 0.172:
+//           ten terms of the odd series; the division by Newton iterations on v_rcp_f64 (the divisor lies in
+//           [1.7, 2.42): no scaling, no special cases);
+//   sqrt    by v_rsq_f64 + two coupled Newton steps (the argument -2 ln u1 lies in [1e-16, 75]);
+//   angle   2 pi u2 = k pi / 2 + a, k = rint(4 u2), |a| <= pi / 4: Taylor polynomials of sin / cos (nine terms each),
+//           quadrant by swapping and sign flips.
 __device__ inline NormalPair box_muller_f64(double u1, double u2) {
-  const double r = sqrt(-2.0 * log(u1));
-  double s, c;
-  sincospi(2.0 * u2, &s, &c);
-  return NormalPair{r * c, r * s};
+  int ex = __builtin_amdgcn_frexp_exp(u1);
+  double m = __builtin_amdgcn_frexp_mant(u1);  // [0.5, 1)
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? 2.0 * m : m;
+  ex = lo ? ex - 1 : ex;
+  const double num = m - 1.0, den = m + 1.0;
+  double rc = __builtin_amdgcn_rcp(den);
+  rc = fma(fma(-den, rc, 1.0), rc, rc);
+  rc = fma(fma(-den, rc, 1.0), rc, rc);
+  double s = num * rc;
+  s = fma(fma(-den, s, num), rc, s);
+  const double z = s * s;
+  double p = 1.0 / 19.0;
+  p = fma(p, z, 1.0 / 17.0);
+  p = fma(p, z, 1.0 / 15.0);
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  p = fma(p, z, 1.0);
+  // -2 ln u1 = -2 e ln 2 - 4 s p  (ln 2 split so that e * hi is exact for |e| <= 54)
+  const double e = (double)ex;
+  const double x = fma(e, -2.0 * 0.693147180369123816490, fma(-4.0 * s, p, e * (-2.0 * 1.90821492927058770002e-10)));
+  double h = __builtin_amdgcn_rsq(x);
+  double g = x * h;
+  h *= 0.5;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);  // sqrt(x)
+  const double t = 4.0 * u2;
+  const double k = __builtin_rint(t);
+  const double a = (t - k) * 1.57079632679489661923;  // the angle is k pi / 2 + a, |a| <= pi / 4
+  const double a2 = a * a;
+  double ps = 1.0 / 355687428096000.0, pc = 1.0 / 20922789888000.0;  // 1/17!, 1/16!
+  ps = fma(ps, a2, -1.0 / 1307674368000.0);  pc = fma(pc, a2, -1.0 / 87178291200.0);   // 1/15!, 1/14!
+  ps = fma(ps, a2, 1.0 / 6227020800.0);      pc = fma(pc, a2, 1.0 / 479001600.0);      // 1/13!, 1/12!
+  ps = fma(ps, a2, -1.0 / 39916800.0);       pc = fma(pc, a2, -1.0 / 3628800.0);       // 1/11!, 1/10!
+  ps = fma(ps, a2, 1.0 / 362880.0);          pc = fma(pc, a2, 1.0 / 40320.0);          // 1/9!,  1/8!
+  ps = fma(ps, a2, -1.0 / 5040.0);           pc = fma(pc, a2, -1.0 / 720.0);           // 1/7!,  1/6!
+  ps = fma(ps, a2, 1.0 / 120.0);             pc = fma(pc, a2, 1.0 / 24.0);             // 1/5!,  1/4!
+  ps = fma(ps, a2, -1.0 / 6.0);              pc = fma(pc, a2, -0.5);
+  const double sn = fma(ps * a2, a, a), cs = fma(pc, a2, 1.0);
+  const int q = (int)k;  // 0 .. 4: angle = q pi / 2 + a
+  const bool odd = q & 1;
+  const double ss = odd ? cs : sn, cc = odd ? sn : cs;
+  const double S = (q & 2) ? -ss : ss, C = ((q + 1) & 2) ? -cc : cc;
+  return NormalPair{g * C, g * S};
 }
 
 #ifdef PXM_NOISE_F64
