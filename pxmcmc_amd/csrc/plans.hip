@@ -23,7 +23,8 @@ struct TaskList {
   std::vector<int> bls;  // bandlimits of the transforms grouped in this launch (roofline accounting)
   std::vector<int> los;  // their support cuts el_lo (0 = none)
   double mfma_units = 0; // sum over tasks of row tiles x k-steps x slabs: MFMAs per column tile
-  bool gram = false;     // Gram launch: table sum_m (L-m)^2 entries, harmonic side read and written
+  bool gram = false;     // Gram launch: the stored Gram tiles, TWO harmonic operand arrays read, one written, the data term
+  double gram_table_bytes = 0;  // bytes of the Gram table as stored (16-row / 16-k tiles from round_down(m, 16))
   int flags = 0;         // bit 0: tasks sum a second operand in while staging; bit 1: per-row operand scale (kernel variant)
 };
 
@@ -146,7 +147,9 @@ static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, i
     double bytes = 0;
     for (size_t i = 0; i < tl.bls.size(); ++i) {
       const double Ld = tl.bls[i];
-      if (tl.gram) bytes += 8.0 * Ld * (Ld + 1) * (2 * Ld + 1) / 6 + 2 * 16.0 * cg * Ld * Ld;
+      // Gram launch: the table as stored; the operand is the sum of the TWO class buffers (both read), one result
+      // array, (l, m) entries with l >= |m| only (16 B each: L^2 per array and chain slot), and the data term of chain 0
+      if (tl.gram) bytes += tl.gram_table_bytes + 3 * 16.0 * cg * Ld * Ld + 16.0 * Ld * Ld;
       else bytes += gemm_alg_bytes(tl.bls[i], tl.paired, cg, tl.los[i]);
     }
     GemmAffine a = aff;
@@ -1043,6 +1046,7 @@ static int wav_make_gram_lists(pxm_wav_plan_t p) {
     append_gemm_tasks(*p->TL, TAB_GRAM, p->ncol, p->offHA, p->L, p->Rp, p->offHL, p->L, p->Rp, nullptr, p->offS, p->ws, v, 0, fz);
     if ((rc = upload_tasks(v, true, &p->gram, {p->L}, p->ncol, p->ws, "Gram step"))) return rc;
     p->gram.gram = true;
+    p->gram.gram_table_bytes = (double)p->TL->bytes[TAB_GRAM];
     v.clear();
     append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGD, p->L, p->Rp, p->offHD, p->L, p->Rp, nullptr, p->offS, p->ws, v);
     if ((rc = upload_tasks(v, true, &p->adj_invadj_D, {p->L}, p->ncol, p->ws, "inverse-adjoint of the data rings"))) return rc;
