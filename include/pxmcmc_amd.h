@@ -114,6 +114,11 @@ int64_t pxm_wav_table_bytes(pxm_wav_plan_t plan, int op /*0 synthesis,1 synthesi
 int pxm_wav_set_iter_counter(pxm_wav_plan_t plan, uint64_t* counter_dev);
 int pxm_wav_release_iter_counter(pxm_wav_plan_t plan, const uint64_t* counter_dev);
 int pxm_wav_iter_counter_add(pxm_wav_plan_t plan, uint64_t inc, pxm_stream_t stream);
+/* With PXM_FLOW=1 (read when a plan's Gram lists are built) the ring-space step launches its Gram and forward-adjoint
+ * GEMM tasks in one grid with per-order counters between them.  A wait that is never satisfied raises a flag instead
+ * of hanging the GPU:
+ * 0 = every wait of this plan's launches so far was satisfied, 1 = one timed out (results invalid).  Synchronises. */
+int pxm_wav_flow_status(pxm_wav_plan_t plan, pxm_stream_t stream);
 
 /* Live kernel timing of one plan (bench.py roofline leg).  pxm_wav_profile_enable(plan, n) with n > 0 creates
  * n event pairs per kernel class; while enabled every SHT ring-GEMM launch and every grouped phi-DFT launch of

@@ -33,6 +33,7 @@ SIGNATURES = {
     "pxm_wav_set_iter_counter": (c_int, [c_vp, c_vp]),
     "pxm_wav_release_iter_counter": (c_int, [c_vp, c_vp]),
     "pxm_wav_iter_counter_add": (c_int, [c_vp, c_u64, c_vp]),
+    "pxm_wav_flow_status": (c_int, [c_vp, c_vp]),
     "pxm_wav_profile_enable": (c_int, [c_vp, c_int]),
     "pxm_wav_profile_read": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pxm_wav_profile_read_launches": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),

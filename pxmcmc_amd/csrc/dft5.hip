@@ -693,11 +693,15 @@ extern "C" int pxm_debug_set_dft_trace(unsigned long long* buf) {
 template <bool RING_OUT>
 __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5Group* __restrict__ ents, int nent,
                                                                                        double* __restrict__ ws, int ncol, PxOut out,
-                                                                                       int C) {
+                                                                                       int C, unsigned* __restrict__ zero_words,
+                                                                                       int n_zero) {
   extern __shared__ double2 lds5[];
 #ifdef PXM_D5_TRACE
   const unsigned long long trace_t0 = wall_clock64();
 #endif
+  // (the per-m counters of the dataflow GEMM launch that follows this kernel in a stepping loop: plans.hip)
+  if (zero_words && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0;
   PXM_D5_GROUP_DECODE
   out.ring0 = g.ring0;
   switch (g.r0) {
@@ -1213,7 +1217,8 @@ void dft_group_destroy(DftGroupList* g) {
   g->n = 0;
 }
 
-int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st, Profiler* prof) {
+int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st, Profiler* prof,
+                      unsigned* zero_words, int n_zero) {
   // algorithmic bytes: rings read + written (16 B per slot and coefficient, every padded slot), state read, new state
   // written (live slots), thresholds read once
   PXM_REQUIRE(g.ring_end <= out.chain_stride, "dft5_group_launch: a scale's coefficient block ends past chain_stride");
@@ -1221,7 +1226,7 @@ int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& 
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
   hipExtLaunchKernelGGL(k_ring2px_group5<true>, dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
-                        reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C);
+                        reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -1237,7 +1242,7 @@ int dft5_group_px2ring(const DftGroupList& g, double* ws, int ncol, const PxIn& 
 int dft5_group_ring2px(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
   PXM_REQUIRE(out.gidx || g.ring_end <= out.chain_stride, "dft5_group_ring2px: a scale's coefficient block ends past chain_stride");
   hipLaunchKernelGGL(k_ring2px_group5<false>, dim3(g.blocks), dim3(g.threads), g.lds, st, reinterpret_cast<const Dft5Group*>(g.d),
-                     g.n, ws, ncol, out, C);
+                     g.n, ws, ncol, out, C, (unsigned*)nullptr, 0);
   PXM_HIP(hipGetLastError());
   return 0;
 }

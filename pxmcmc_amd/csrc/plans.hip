@@ -29,7 +29,7 @@ struct TaskList {
 };
 
 static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std::vector<int> bls, int ncol,
-                        const double* ws_base, const char* name, std::vector<int> los = {}) {
+                        const double* ws_base, const char* name, std::vector<int> los = {}, bool keep_order = false) {
   out->bls = bls;
   los.resize(bls.size(), 0);
   out->los = los;
@@ -46,10 +46,10 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
   // (almost) resident at once and the per-CU bins win (L=256: 24.5 vs 26.5 us Gram, 31.4 vs 32.1 us groups); with
   // many rounds per slot the queues win (L=512: 200 vs 218 us, 218 vs 231 us).
   const char* order_env = getenv("PXM_GEMM_ORDER");
-  const std::string order = order_env ? order_env : (v.size() > 2048 ? "xcd" : "bins");
+  const std::string order = keep_order ? "kept" : (order_env ? order_env : (v.size() > 2048 ? "xcd" : "bins"));
   const int64_t fixed = order == "xcd" ? 32 : 0;  // start-up / drain of a task in contraction steps
   auto work = [fixed](const GemmTask& a) { return (int64_t)(a.k_end - a.k_beg + fixed) * a.n_rt; };
-  std::stable_sort(v.begin(), v.end(), [&](const GemmTask& a, const GemmTask& b) { return work(a) > work(b); });
+  if (!keep_order) std::stable_sort(v.begin(), v.end(), [&](const GemmTask& a, const GemmTask& b) { return work(a) > work(b); });
   if (order == "xcd" && !v.empty()) {
     constexpr int NQ = 8;  // XCDs of gfx950
     std::map<int64_t, int> unit_of;
@@ -136,6 +136,19 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
   return dev_upload(out->d, v.data(), v.size() * sizeof(GemmTask));
 }
 
+// algorithmic bytes of one launch of a list for cg live chain slots
+static double tasklist_bytes(const TaskList& tl, int cg) {
+  double bytes = 0;
+  for (size_t i = 0; i < tl.bls.size(); ++i) {
+    const double Ld = tl.bls[i];
+    // Gram launch: the table as stored; the operand is the sum of the TWO class buffers (both read), one result
+    // array, (l, m) entries with l >= |m| only (16 B each: L^2 per array and chain slot), and the data term of chain 0
+    if (tl.gram) bytes += tl.gram_table_bytes + 3 * 16.0 * cg * Ld * Ld + 16.0 * Ld * Ld;
+    else bytes += gemm_alg_bytes(tl.bls[i], tl.paired, cg, tl.los[i]);
+  }
+  return bytes;
+}
+
 // run a task list over all chain groups (16 chains = 32 columns per launch)
 static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, int C, hipStream_t st,
                      const GemmAffine& aff = GemmAffine(), Profiler* prof = nullptr) {
@@ -144,14 +157,7 @@ static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, i
     const int ct = (ncol - col0 >= 32) ? 2 : 1;
     const int cg = std::max(0, std::min(C - col0 / 2, 8 * ct));  // live chains in this column group
     if (cg == 0) break;  // column groups of padding chains only: nothing reads them
-    double bytes = 0;
-    for (size_t i = 0; i < tl.bls.size(); ++i) {
-      const double Ld = tl.bls[i];
-      // Gram launch: the table as stored; the operand is the sum of the TWO class buffers (both read), one result
-      // array, (l, m) entries with l >= |m| only (16 B each: L^2 per array and chain slot), and the data term of chain 0
-      if (tl.gram) bytes += tl.gram_table_bytes + 3 * 16.0 * cg * Ld * Ld + 16.0 * Ld * Ld;
-      else bytes += gemm_alg_bytes(tl.bls[i], tl.paired, cg, tl.los[i]);
-    }
+    const double bytes = tasklist_bytes(tl, cg);
     GemmAffine a = aff;
     if (col0) a.bump = nullptr;  // the iteration counter advances once per call, not once per column group
     a.ncol_live = 2 * C;
@@ -415,6 +421,14 @@ struct pxm_wav_plan_s {
   const double* wl_gw = nullptr;       // [ndata] covariance weight (caller-owned) or null
   int64_t wl_ndata = 0;
   std::vector<ShtTables*> held;  // table-cache entries this plan retains (each once)
+  // dataflow launch of the ring-space step: Gram + forward-adjoint tasks in one grid, per-m counters instead of a
+  // launch boundary (sht_gemm.hip: k_sht_gemm_flow).  Opt-in (PXM_FLOW=1): bit-identical to the two launches and one
+  // kernel fewer per iteration, but not faster -- 55.4 us against 22.2 + 33.3 us
+  bool use_flow = false;
+  TaskList flow;
+  std::vector<GemmTask> h_adj_fwdadj;  // host copy of the forward-adjoint tasks (the flow list is built with the Gram list)
+  unsigned* d_flow_flags = nullptr;    // [L] per-m counters + [1] time-out flag
+  double flow_bytes = 0, flow_mfma = 0;
   uint64_t* iter_dev = nullptr;  // device-resident Philox iteration counter of THIS plan (pxm_wav_set_iter_counter)
   Profiler prof;                 // live kernel timing of THIS plan (pxm_wav_profile_*)
 };
@@ -567,6 +581,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   p->table_bytes[0] += p->TL->bytes[TAB_INV];
   p->table_bytes[1] += p->TL->bytes[TAB_INV_ADJ];
   if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl, p->ncol, p->ws, "synthesis forward (all scales)", el_lo))) return rc;
+  p->h_adj_fwdadj = v_adj_fwdadj;
   if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl, p->ncol, p->ws, "synthesis-adjoint forward-adjoint (all scales)", el_lo))) return rc;
   if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl, p->ncol, p->ws, "analysis inverse (all scales)", el_lo))) return rc;
   if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl, p->ncol, p->ws, "analysis-adjoint inverse-adjoint (all scales)", el_lo))) return rc;
@@ -640,9 +655,10 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   deferred_free(p->d_kc_syn);
   deferred_free(p->d_kc_ana);
   deferred_free(p->d_wlk);
+  deferred_free(p->d_flow_flags);
   // (side streams / events belong to the per-device pool)
   TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj, &p->adj_invadj_R, &p->gram, &p->adj_invadj_D,
-                     &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj, &p->wl_inv, &p->wl_invadj};
+                     &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj, &p->wl_inv, &p->wl_invadj, &p->flow};
   for (TaskList* t : tls) free_tasks(t);
   profiler_release(&p->prof);
   for (ShtTables* T : p->held) release_tables(T);
@@ -724,6 +740,16 @@ int64_t pxm_wav_workspace_nonfinite(pxm_wav_plan_t p, pxm_stream_t stream) {
   PXM_HIP(hipStreamSynchronize(st));
   PXM_HIP(hipMemsetAsync(cnt, 0, sizeof(*cnt), st));
   return (int64_t)h;
+}
+
+// 0: every wait of the dataflow launches of this plan was satisfied; 1: one timed out (results invalid); synchronises
+int pxm_wav_flow_status(pxm_wav_plan_t p, pxm_stream_t stream) {
+  PXM_REQUIRE(p, "pxm_wav_flow_status: null plan");
+  if (!p->d_flow_flags) return 0;
+  unsigned h = 0;
+  PXM_HIP(hipMemcpyAsync(&h, p->d_flow_flags + p->L, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  PXM_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return h ? 1 : 0;
 }
 
 int pxm_tables_trim(void) {
@@ -862,7 +888,9 @@ static bool wav_can_fuse_dft(pxm_wav_plan_t p) {
 static int wav_rings_update_rings(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
   if (p->dft_group.d && p->dft_group.all) {  // one grid for every scale, small scales first
     proto.chain_stride = p->ncoefs;
-    return dft5_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof);
+    // (it also zeroes the counters of the dataflow GEMM launch: it runs between two of them in a stepping loop)
+    return dft5_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof, p->use_flow ? p->d_flow_flags : nullptr,
+                             p->use_flow ? p->L : 0);
   }
   bool used[pxm_wav_plan_s::NSIDE];
   int rc = wav_fork(p, st, used);
@@ -1050,6 +1078,48 @@ static int wav_make_gram_lists(pxm_wav_plan_t p) {
     v.clear();
     append_gemm_tasks(*p->TL, TAB_INV_ADJ, p->ncol, p->offGD, p->L, p->Rp, p->offHD, p->L, p->Rp, nullptr, p->offS, p->ws, v);
     if ((rc = upload_tasks(v, true, &p->adj_invadj_D, {p->L}, p->ncol, p->ws, "inverse-adjoint of the data rings"))) return rc;
+    // dataflow list: [Gram tasks, longest first | forward-adjoint tasks of every scale, longest first]; a
+    // forward-adjoint task of order m waits until the Gram tasks of m (one per block of 128 rows) have signalled
+    const char* fe = getenv("PXM_FLOW");
+    if (p->ncol <= 32 && p->fused_combine && wav_can_fuse_dft(p) && p->dft_group.d && p->dft_group.all && fe && atoi(fe) != 0) {
+      std::vector<GemmTask> gv, av = p->h_adj_fwdadj, fl;
+      GemmFuse fz2;
+      fz2.x2_base = p->offHB;
+      fz2.hd_base = p->offHD;
+      append_gemm_tasks(*p->TL, TAB_GRAM, p->ncol, p->offHA, p->L, p->Rp, p->offHL, p->L, p->Rp, nullptr, p->offS, p->ws, gv, 0, fz2);
+      auto work = [](const GemmTask& a) { return (int64_t)(a.k_end - a.k_beg) * a.n_rt; };
+      std::stable_sort(gv.begin(), gv.end(), [&](const GemmTask& a, const GemmTask& b) { return work(a) > work(b); });
+      // consumers in the order their producers finish (PXM_FLOW_ORDER=ready, default): high orders first -- their
+      // Gram chains are the short ones; =lpt: longest first, which parks the tasks of m < 16 in the slots until the
+      // 16-chunk Gram chains are through
+      const char* fo = getenv("PXM_FLOW_ORDER");
+      if (fo && std::string(fo) == "lpt")
+        std::stable_sort(av.begin(), av.end(), [&](const GemmTask& a, const GemmTask& b) { return work(a) > work(b); });
+      else
+        std::stable_sort(av.begin(), av.end(), [&](const GemmTask& a, const GemmTask& b) {
+          return a.m_unit / 16 != b.m_unit / 16 ? a.m_unit / 16 > b.m_unit / 16 : work(a) > work(b);
+        });
+      std::vector<int> n_gram(p->L, 0);
+      for (GemmTask& t : gv) {
+        PXM_REQUIRE(t.m_unit >= 0 && t.m_unit < p->L, "flow list: Gram task order outside [0, L)");
+        t.variant = 1;
+        t.signal_idx = t.m_unit;
+        ++n_gram[t.m_unit];
+      }
+      for (GemmTask& t : av) {
+        PXM_REQUIRE(t.m_unit >= 0 && t.m_unit < p->L && n_gram[t.m_unit] > 0, "flow list: forward-adjoint task without a Gram producer");
+        t.variant = 2;
+        t.wait_idx = t.m_unit;
+        t.wait_target = n_gram[t.m_unit];
+      }
+      fl = gv;
+      fl.insert(fl.end(), av.begin(), av.end());
+      // (upload_tasks re-sorts by work: the list keeps its two parts because the order is forced to "flow")
+      if ((rc = upload_tasks(fl, true, &p->flow, p->bl, p->ncol, p->ws, "dataflow Gram + forward-adjoint", {}, true))) return rc;
+      if ((rc = dev_alloc(&p->d_flow_flags, (size_t)(p->L + 1) * sizeof(unsigned), "dataflow counters"))) return rc;
+      if ((rc = dev_zero(p->d_flow_flags, (size_t)(p->L + 1) * sizeof(unsigned)))) return rc;
+      p->use_flow = true;
+    }
   }
   return 0;
 }
@@ -1111,7 +1181,19 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
     aff.wr = w_re;
     aff.wi = w_im;
     aff.bump = p->iter_dev;  // the step's iteration number = counter after this bump
-    if ((rc = run_tasks(p->gram, p->ws, p->ws, p->ncol, C, st, aff, &p->prof))) return rc;
+    if (p->use_flow) {  // Gram + forward-adjoint tasks of every scale in ONE grid, per-m counters between them
+      note_stream(st);
+      aff.ncol_live = 2 * C;
+      const int ct = p->ncol >= 32 ? 2 : 1, cg = std::min(C, 8 * ct);
+      rc = launch_gemm_flow(p->flow.d, p->flow.n, 2, p->ws, p->ws, p->ncol, ct,
+                            tasklist_bytes(p->gram, cg) + tasklist_bytes(p->adj_fwdadj, cg),
+                            (p->gram.mfma_units + p->adj_fwdadj.mfma_units) * ct * 2048.0, st, aff, p->d_flow_flags,
+                            p->d_flow_flags + p->L, &p->prof);
+      if (rc) return rc;
+    } else {
+      if ((rc = run_tasks(p->gram, p->ws, p->ws, p->ncol, C, st, aff, &p->prof))) return rc;
+      if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
+    }
   } else {
     if (p->iter_dev && (rc = pxm_wav_iter_counter_add(p, 1, stream))) return rc;
     const int Cp = p->ncol / 2;
@@ -1121,8 +1203,8 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
                        total, Cp, (double)(2 * p->L - 1), double2{w_re, w_im});
     PXM_HIP(hipGetLastError());
     if ((rc = run_tasks(p->adj_invadj_R, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
+    if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   }
-  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   PxOut out;
   out.f = (double*)X_out;
   out.X = (const double*)X;

@@ -46,6 +46,11 @@ struct GemmTask {
   int n_rt;            // row tiles in this task (1..8)
   int nslab;           // live slabs: 1 (all m stored) or 2 (+-m pair)
   double sign1;        // factor on the -m outputs ((-1)^m)
+  // dataflow launch (k_sht_gemm_flow): kernel variant of this task (1 = Gram: two operands + affine epilogue,
+  // 2 = forward-adjoint: per-k operand scale), the counter it waits for (index, value; -1 = none) and the one it
+  // increments when its rows are stored (-1 = none); ignored by the ordinary launches
+  int variant, wait_idx, wait_target, signal_idx;
+  int m_unit;          // the order this task belongs to: m (paired tables: m >= 0 serves +-m) or m + L - 1
 };
 
 // affine epilogue of the Gram launch: out = w * (ns * acc - hd[row]) as a complex product per chain
@@ -167,6 +172,10 @@ inline double gemm_alg_bytes(int L, bool paired, int C, int el_lo = 0) {
 }
 
 int gemm_rows_per_task(int ncol);
+// dataflow launch of a [Gram tasks | forward-adjoint tasks] list over ONE column group (sht_gemm.hip: k_sht_gemm_flow)
+int launch_gemm_flow(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X, double* Y, int ncol, int ct,
+                     double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff, unsigned* flags,
+                     unsigned* err, Profiler* prof);
 // host model of every address k_sht_gemm forms for a task list (sht_gemm.hip); < 0 + error text when a range leaves
 // its allocation
 int check_gemm_task_ranges(const std::vector<GemmTask>& v, int nslab, int flags, int ncol, const double* ws_base,
@@ -266,7 +275,7 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
                       const std::vector<int64_t>& ring0, int ncol, const double* ws_base,
                       DftGroupList* out);  // 1 = not available
 int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
-                      Profiler* prof = nullptr);
+                      Profiler* prof = nullptr, unsigned* zero_words = nullptr, int n_zero = 0);
 // the plain transforms of every member scale in one grid each (blocks <-> rings of the generic wavelet operators)
 int dft5_group_px2ring(const DftGroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st);
 int dft5_group_ring2px(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st);

@@ -63,28 +63,45 @@ __device__ __forceinline__ double stage_scale(double a, double sc) { return a * 
 __device__ __forceinline__ double2 stage_scale(double2 a, double sc) { return double2{a.x * sc, a.y * sc}; }
 // TWO: the tasks of the launch sum a second operand in while staging; SK: they scale the operand per contraction row
 // (compile-time, so that the launches without them issue no loads for them)
-template <int CT, int NSLAB, int NW, int RT, int NSET, bool TWO, bool SK>
-__global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict__ tasks,
-                                                      const double* __restrict__ X, double* __restrict__ Y,
-                                                      int ncol, int col0, GemmAffine aff) {
+// FLOW (dataflow launch, k_sht_gemm_flow below): 0 = none; 1 = producer: the result rows are written with agent-scope
+// (write-through) stores, so that a consumer workgroup on another XCD -- another L2 -- can read them inside the same
+// launch; 2 = consumer: the operand is staged with agent-scope loads (they do not hit a stale line of this XCD's L2).
+template <class T>
+__device__ __forceinline__ T ld_agent(const T* p);
+template <>
+__device__ __forceinline__ double ld_agent<double>(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <>
+__device__ __forceinline__ double2 ld_agent<double2>(const double2* p) {
+  const double* q = reinterpret_cast<const double*>(p);
+  return double2{ld_agent(q), ld_agent(q + 1)};
+}
+template <int CT, int NSLAB>
+struct GemmGeom {
+  static constexpr int NCT = CT * NSLAB;
+  static constexpr int COLS = 16 * NCT;                       // staged operand columns
+  static constexpr int PITCH = COLS + (COLS == 16 ? 0 : 16);  // doubles; PITCH*8 = 128 (mod 256)
+};
+template <int CT, int NSLAB, int NW, int RT, int NSET, bool TWO, bool SK, int FLOW>
+__device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks, const int bid,
+                                              const double* __restrict__ X, double* __restrict__ Y, int ncol, int col0,
+                                              const GemmAffine& aff, double (*xs)[KC][GemmGeom<CT, NSLAB>::PITCH]) {
   constexpr int NCT = CT * NSLAB;
   // all B-fragment LDS reads of a chunk ahead of its MFMAs (one LDS round trip per chunk instead of four): pays in the
   // Gram launch (1.5 workgroups per CU, nothing else to hide the latency: 22.3 -> 21.8 us), costs 6-10 VGPRs and with
   // them the eighth wave per SIMD in the streaming launches (32.0 -> 32.7 us) -- on for the two-operand variants only
   constexpr bool HOIST = TWO;
-  constexpr int COLS = 16 * NCT;                          // staged operand columns
-  constexpr int PITCH = COLS + (COLS == 16 ? 0 : 16);     // doubles; PITCH*8 = 128 (mod 256)
+  constexpr int COLS = GemmGeom<CT, NSLAB>::COLS;
+  constexpr int PITCH = GemmGeom<CT, NSLAB>::PITCH;
   constexpr int NT = 64 * NW;                             // threads per workgroup
   // staging unit: a double2 per thread where the chunk has at least one for everybody, otherwise a double (so that
   // every thread of the workgroup stages the same amount and nobody loads twice)
   constexpr int VW = (KC * COLS / 2 >= NT) ? 2 : 1;       // doubles per staging load
   constexpr int NV = KC * COLS / VW;                      // staging units per chunk
   constexpr int IT = (NV + NT - 1) / NT;                  // staging loads per thread per chunk
-  __shared__ double xs[2][KC][PITCH];
-
-  const GemmTask t = tasks[blockIdx.x];
+  const GemmTask t = tasks[bid];
   const int tid = threadIdx.x, lane = tid & 63;
-  if (aff.bump && blockIdx.x == 0 && tid == 0) *aff.bump += 1;  // Philox iteration counter of the ring-space step
   if (t.n_rt == 0) return;  // padding entry of the XCD-queue order (plans.hip: upload_tasks)
 #ifdef PXM_GEMM_TRACE
   const unsigned long long trace_t0 = wall_clock64();
@@ -119,16 +136,16 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     sv[i] = q0 < NV;
     // (per-thread slab: read from the task in memory -- a runtime index into the register copy would push
     // the whole struct into scratch)
-    const int64_t xo = tasks[blockIdx.x].x_off[slab];
+    const int64_t xo = tasks[bid].x_off[slab];
     sp[i] = X + xo + col0 + cin + (int64_t)(t.k_beg + kr) * ncol;
     sp2[i] = sp[i];
     skp[i] = sp[i];
     if (TWO) {  // a task of a TWO launch without a second operand (x2_off = 0) re-reads the first and adds zero
-      const int64_t x2o = tasks[blockIdx.x].x2_off[slab];
+      const int64_t x2o = tasks[bid].x2_off[slab];
       if (x2o) sp2[i] = sp[i] + (x2o - xo);
     }
     if (SK) {
-      const int64_t ks = tasks[blockIdx.x].ks_off[slab >> 1];
+      const int64_t ks = tasks[bid].ks_off[slab >> 1];
       if (ks) skp[i] = X + ks + t.k_beg + kr;
     }
     so[i] = kr * PITCH + col;
@@ -142,7 +159,8 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   {                                                                                                 \
     const int cs = min((CH), nch - 1);                                                              \
     _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                                \
-      st[SET][i] = *reinterpret_cast<const stage_t*>(sp[i] + (int64_t)cs * KC * ncol);              \
+      st[SET][i] = FLOW == 2 ? ld_agent(reinterpret_cast<const stage_t*>(sp[i] + (int64_t)cs * KC * ncol))  \
+                             : *reinterpret_cast<const stage_t*>(sp[i] + (int64_t)cs * KC * ncol);  \
       if (TWO) st2[SET][i] = *reinterpret_cast<const stage_t*>(sp2[i] + (int64_t)cs * KC * ncol);   \
       if (SK) ssc[SET][i] = skp[i][cs * KC];                                                        \
     }                                                                                               \
@@ -294,7 +312,10 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
           v = (cl & 1) ? (aff.wr * u + aff.wi * pu) : (aff.wr * u - aff.wi * pu);
           if (col0 + cin + cl >= aff.ncol_live) v = 0.0;  // padding chains stay at zero (they have no prox / damping)
         }
-        if (row >= t.row_lo[grp] && row < t.row_hi[grp]) yb[(int64_t)(4 * q) * ncol] = sgn * rsv[r][grp][q] * v;
+        if (row >= t.row_lo[grp] && row < t.row_hi[grp]) {
+          if (FLOW == 1) __hip_atomic_store(yb + (int64_t)(4 * q) * ncol, sgn * rsv[r][grp][q] * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else yb[(int64_t)(4 * q) * ncol] = sgn * rsv[r][grp][q] * v;
+        }
       }
     }
   }
@@ -317,6 +338,62 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
     }
   }
 #endif
+}
+
+template <int CT, int NSLAB, int NW, int RT, int NSET, bool TWO, bool SK>
+__global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict__ tasks,
+                                                      const double* __restrict__ X, double* __restrict__ Y,
+                                                      int ncol, int col0, GemmAffine aff) {
+  __shared__ double xs[2][KC][GemmGeom<CT, NSLAB>::PITCH];
+  if (aff.bump && blockIdx.x == 0 && threadIdx.x == 0) *aff.bump += 1;  // Philox iteration counter of the ring-space step
+  sht_gemm_body<CT, NSLAB, NW, RT, NSET, TWO, SK, 0>(tasks, blockIdx.x, X, Y, ncol, col0, aff, xs);
+}
+
+// ---------------------------------------------------------------------------------------
+// Dataflow launch of the ring-space step: the Gram tasks and the forward-adjoint tasks of EVERY scale in one grid.
+// A forward-adjoint task (m, scale, row block) reads H'[m], which the one or two Gram tasks of that m write: it waits
+// on a per-m counter the Gram tasks increment when their rows are stored, instead of on a launch boundary -- the
+// forward-adjoint tasks of the orders whose (short) Gram tasks are done fill the CUs the long Gram chains (m < 16:
+// 16 dependent chunks) leave idle.  Deadlock-free by construction: the Gram tasks come first in the grid, so every
+// one of them has been dispatched before the first waiting task, and they wait for nothing; the wait is bounded
+// all the same (a counter that never arrives raises *err instead of hanging the GPU).  Visibility across XCDs (one
+// L2 each): the producers store their rows write-through (agent scope) and signal after s_waitcnt vmcnt(0); the
+// consumers stage the operand with agent-scope loads (sht_gemm_body: FLOW).  The counters are zeroed by the grouped
+// DFT launch that runs between two dataflow launches of a stepping loop.
+// ---------------------------------------------------------------------------------------
+template <int CT, int NSLAB, int NW, int RT, int NSET>
+__global__ __launch_bounds__(64 * NW) void k_sht_gemm_flow(const GemmTask* __restrict__ tasks, const double* __restrict__ X,
+                                                           double* __restrict__ Y, int ncol, int col0, GemmAffine aff,
+                                                           unsigned* __restrict__ flags, unsigned* __restrict__ err) {
+  __shared__ double xs[2][KC][GemmGeom<CT, NSLAB>::PITCH];
+  if (aff.bump && blockIdx.x == 0 && threadIdx.x == 0) *aff.bump += 1;
+  const int variant = tasks[blockIdx.x].variant, wait_idx = tasks[blockIdx.x].wait_idx,
+            wait_target = tasks[blockIdx.x].wait_target, signal_idx = tasks[blockIdx.x].signal_idx;
+  if (wait_idx >= 0) {
+    if (threadIdx.x == 0) {
+      unsigned spins = 0;
+      while ((int)__hip_atomic_load(flags + wait_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_target) {
+        if (++spins > (1u << 22)) {  // (~1 s: the producers of a live launch arrive within tens of microseconds)
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
+  }
+  if (variant == 1) {
+    sht_gemm_body<CT, NSLAB, NW, RT, NSET, true, false, 1>(tasks, blockIdx.x, X, Y, ncol, col0, aff, xs);
+  } else {
+    GemmAffine none;
+    none.ncol_live = aff.ncol_live;
+    sht_gemm_body<CT, NSLAB, NW, RT, NSET, false, true, 2>(tasks, blockIdx.x, X, Y, ncol, col0, none, xs);
+  }
+  if (signal_idx >= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(flags + signal_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // ---- live profiler: event pairs around GEMM / grouped-DFT launches, owned by a plan ----------------
@@ -474,6 +551,22 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, int flags, cons
   return 0;
 }
 
+int launch_gemm_flow(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X, double* Y, int ncol, int ct,
+                     double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff, unsigned* flags,
+                     unsigned* err, Profiler* prof) {
+  if (n_tasks == 0) return 0;
+  PXM_REQUIRE(nslab == 2 && (ct == 1 || ct == 2), "launch_gemm_flow: +-m paired tables, one or two column tiles");
+  dim3 grid(n_tasks), block(512);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (prof) prof->next(prof->gemm, &ev0, &ev1, alg_bytes, flops, n_tasks);
+  if (ct == 1)
+    hipExtLaunchKernelGGL((k_sht_gemm_flow<1, 2, 8, 1, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, 0, aff, flags, err);
+  else
+    hipExtLaunchKernelGGL((k_sht_gemm_flow<2, 2, 8, 1, 2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, 0, aff, flags, err);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // Task lists
 // ---------------------------------------------------------------------------------------
@@ -533,6 +626,10 @@ static void append_tasks_impl(const ShtTables& T, int kind, int ncol, const Gemm
     const int n_rt_total = (Rp - row_beg) / 16;
     for (int rt = 0; rt < n_rt_total; rt += rpt) {
       GemmTask g;
+      g.variant = 0;
+      g.wait_idx = g.signal_idx = -1;
+      g.wait_target = 0;
+      g.m_unit = T.paired ? m : m + T.L - 1;
       g.tab_off = (T.d_tab[kind] + T.m_off[kind][i] + tab_skip + (int64_t)rt * rt_stride) - ws_base;
       g.rt_stride = rt_stride;
       for (int s = 0; s < 2; ++s) fill_side(g, s, T, kind, m, ncol, side, scratch_off, ws_base);  // (slab groups 0 and 1 alike)

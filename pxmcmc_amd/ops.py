@@ -538,6 +538,10 @@ class WavPlan:
     def table_bytes(self, op):
         return int(lib.pxm_wav_table_bytes(self._h, op))
 
+    def flow_status(self):
+        """0: every wait of the dataflow GEMM launches of this plan was satisfied (include/pxmcmc_amd.h); synchronises"""
+        return int(check(lib.pxm_wav_flow_status(self._h, _stream())))
+
     # ---- weak-lensing measurement fused with the synthesis (pxm_wav_wl_*) ----
     def wl_attach(self, pix2data, weight, ndata):
         """pix2data: int32 [npix] pixel -> index in the masked data vector (< 0 masked) or None; weight: float64

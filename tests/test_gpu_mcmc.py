@@ -642,6 +642,47 @@ def test_two_samplers_on_one_operator_do_not_share_a_counter():
     b._engine_stop()
 
 
+@pytest.mark.parametrize("L,C", [(32, 3), (64, 8), (256, 16)])
+def test_dataflow_gemm_launch_equals_two_launches(L, C, monkeypatch):
+    """With PXM_FLOW=1 the ring-space step launches its Gram and forward-adjoint GEMM tasks in ONE grid with per-order
+    counters between them (csrc/sht_gemm.hip: k_sht_gemm_flow); the default keeps the two launches.  Same tasks, same arithmetic: the
+    states after K iterations with injected noise are bit-identical, in real-pair and in complex-slot mode, and no wait
+    timed out."""
+    import torch
+
+    from pxmcmc_amd import ops
+
+    B, J_min, K = 2.0, 2, 6
+    rng = np.random.default_rng(L)
+    P = L * (2 * L - 1)
+    data = rng.normal(size=P)
+    res = {}
+    for flow in ("1", "0"):
+        monkeypatch.setenv("PXM_FLOW", flow)
+        for pairs in (True, False):
+            slots = (C + 1) // 2 if pairs else C
+            plan = ops.WavPlan(L, B, J_min, max_chains=slots)
+            N = plan.ncoefs
+            r2 = np.random.default_rng(7)
+            X0 = r2.normal(size=(2 * slots if pairs else slots, N)) * 1e-2
+            noise = r2.normal(size=(K, X0.shape[0], N))
+            T = ops.as_device(np.full(N, 1e-4), torch.float64)
+            d = ops.as_device(data, torch.float64)
+            plan.ring_set_data(torch.complex(d, d if pairs else torch.zeros_like(d)).contiguous())
+            X = torch.complex(ops.as_device(X0[0::2]), ops.as_device(X0[1::2])) if pairs else ops.as_device(X0, torch.complex128)
+            out = torch.empty_like(X)
+            plan.ring_init(X)
+            for k in range(K):
+                plan.ring_step(X, complex(4.0, 0.0), T, 1e-4, 2e-3, noise=ops.as_device(noise[k]), out=out, pairs=pairs)
+                X, out = out, X
+            assert plan.flow_status() == 0
+            res[(flow, pairs)] = (X.cpu().numpy(), plan.ring_preds(X.shape[0]).cpu().numpy())
+    for pairs in (True, False):
+        np.testing.assert_array_equal(res[("1", pairs)][0], res[("0", pairs)][0])
+        np.testing.assert_array_equal(res[("1", pairs)][1], res[("0", pairs)][1])
+        assert np.isfinite(res[("1", pairs)][0]).all()
+
+
 def test_plan_teardown_during_capture_is_deferred():
     """hipFree inside a stream capture would invalidate it: a plan destroyed while a capture is in progress only
     queues its frees (include/pxmcmc_amd.h: pxm_capture_begin / pxm_capture_end), and the captured graph replays."""
