@@ -333,7 +333,7 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 // (consecutive k, one chain) spread over the banks.
 #define PXM_D5_GEOMETRY                                                                     \
   constexpr int RPW = 8 / R0;                                                               \
-  const int lgR = a.lgR, R = 1 << lgR;                /* chains per workgroup; one ring set per unit */ \
+  constexpr int lgR = 2, R = 4;                       /* chains per workgroup (compile-time: index arithmetic folds) */ \
   const int n = a.n;                                                                        \
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                               \
   const int half = wave & 1, unit = wave >> 1;        /* two waves per ring set */          \
@@ -357,7 +357,7 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
   /* (row a = 0 of the wt copy, tw[448 .. 455], is never read: it holds the pair counters of d5_pair_sync) */ \
   unsigned* pcnt = reinterpret_cast<unsigned*>(lds5 + 2 * R * D5_PLANE + 448) + unit;       \
   unsigned epoch = 0;                                                                       \
-  for (int i = threadIdx.x; i < D5_TW; i += blockDim.x)                                     \
+  for (int i = threadIdx.x; i < D5_TW; i += 512)                                     \
     lds5[2 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : (i < 456 ? double2{0.0, 0.0} : a.wt[i - 448]);
 #define PXM_D5_SLOT(RING, K, CH) ((((RING)*n + (K)) << lgR) + (((CH) + ((K) >> rsh)) & (R - 1)))
 
@@ -366,7 +366,7 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 // ring arrays keep zero padding columns and every 128-B line is written whole.
 #define PXM_D5_STORE_RINGS(ZFILL)                                                                              \
   {                                                                                                            \
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;                 \
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (512 >> lgR) /* workgroups of 512 threads */;                 \
     const int mstride = a.Rp * Cp; /* complex elements between consecutive m */                                \
     double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;                                                     \
     const bool zf = (ZFILL) && c0 + R >= C;                                                                    \
@@ -400,7 +400,7 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 template <int R0>
 __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in, double* __restrict__ G, int ncol, int C,
                                               int bx, int by, double2* lds5) {
-  if ((by << a.lgR) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
+  if ((by << 2) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
   PXM_D5_GEOMETRY
   // each wave of the pair fetches half of the ring set (its four p) and the two share it through the stage
   {  // the wave's four elements: batched loads (elements past the ring end / dead rings re-read a valid element)
@@ -451,14 +451,14 @@ template <int R0, bool RING_OUT>
 __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restrict__ G, int ncol, const PxOut& out, int C,
                                               int bx, int by, double2* lds5) {
   // chain groups without a live chain do nothing (see run_tasks / GemmAffine::ncol_live: nothing iterates on them)
-  if ((by << a.lgR) >= C) return;
+  if ((by << 2) >= C) return;
 #ifdef PXM_D5_TRACE
   unsigned long long d5_stamp[4] = {0, 0, 0, 0};
   const unsigned long long d5_t0 = wall_clock64();
 #endif
   PXM_D5_GEOMETRY
   {  // rings of the workgroup -> stage; thread -> (chain rr, k), k advances by threads / R: no integer division
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (512 >> lgR) /* workgroups of 512 threads */;
     const int mstride = a.Rp * Cp;  // complex elements between consecutive m
     const double2* Gc = reinterpret_cast<const double2*>(G) + c0 + rr;
     const bool cv = c0 + rr < Cp;
@@ -701,7 +701,7 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5G
 #endif
   // (the per-m counters of the dataflow GEMM launch that follows this kernel in a stepping loop: plans.hip)
   if (zero_words && blockIdx.x == 0)
-    for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0;
+    for (int i = threadIdx.x; i < n_zero; i += 512) zero_words[i] = 0;
   PXM_D5_GROUP_DECODE
   out.ring0 = g.ring0;
   switch (g.r0) {
@@ -760,7 +760,8 @@ struct Dft6Args {
 };
 
 #define PXM_D6_GEOMETRY                                                                      \
-  const int lgR = a.lgR, R = 1 << lgR, n = a.n;                                              \
+  constexpr int lgR = 1, R = 2;                     /* chains per workgroup: compile-time */ \
+  const int n = a.n;                                                                         \
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                                \
   const int w = wave & 3, r = wave >> 2;            /* bin class of the wave, chain of the workgroup */ \
   const D5Lane q{lane & 7, lane >> 3};                                                       \
@@ -774,7 +775,7 @@ struct Dft6Args {
   const double2* pp1 = lds5 + (wave ^ 1) * D5_PLANE;                                         \
   const double2* pp2 = lds5 + (wave ^ 2) * D5_PLANE;                                         \
   const double2* tw = lds5 + 4 * R * D5_PLANE;                                               \
-  for (int i = threadIdx.x; i < D5_TW; i += blockDim.x) lds5[4 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : a.wt[i - 448];
+  for (int i = threadIdx.x; i < D5_TW; i += 512) lds5[4 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : a.wt[i - 448];
 #define PXM_D6_SLOT(K, CH) (((K) << lgR) + (((CH) + ((K) >> rsh)) & (R - 1)))
 
 // xl[p] = element lane + 64 p, xh[p] = element lane + 64 p + 512 of the ring (zeros past n) -> fo[ii][q]: the
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
   extern __shared__ double2 lds5[];
   if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
   const int bx = blockIdx.x, by = blockIdx.y;
-  if ((by << a.lgR) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
+  if ((by << 1) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
   PXM_D6_GEOMETRY
   // every wave fetches a quarter of the ring (its two p, both halves) and the four share it through the stage
   {  // batched loads of the wave's four elements (elements past the ring end re-read element 0 of the ring)
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
     }
   d5_barrier();
   {
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (512 >> lgR) /* workgroups of 512 threads */;
     const int mstride = a.Rp * Cp;
     double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;
 #if PXM_D5_ABLATE & 8
@@ -894,10 +895,10 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
 __global__ __launch_bounds__(512, 4) void k_ring2px6(Dft6Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
   extern __shared__ double2 lds5[];
   const int bx = blockIdx.x, by = blockIdx.y;
-  if ((by << a.lgR) >= C) return;
+  if ((by << 1) >= C) return;
   PXM_D6_GEOMETRY
   {  // the ring of the workgroup's chains -> stage (conjugated: inverse DFT by conjugation)
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (int)blockDim.x >> lgR;
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (512 >> lgR) /* workgroups of 512 threads */;
     const int mstride = a.Rp * Cp;
     const double2* Gc = reinterpret_cast<const double2*>(G) + c0 + rr;
     const bool cv = c0 + rr < Cp;
@@ -1054,11 +1055,10 @@ int dft5_make_tables(int n, Dft5Tables* t) {
 
 void dft5_geometry(int n, int* R, int* TR, size_t* lds) {
   const int r0 = dft5_r0(n), rpw = 8 / r0;
-  // chains per workgroup: 4 = 64-B segments of the ring arrays; PXM_DFT_R=1|2: smaller workgroups (one ring set
-  // is then two waves), whose barriers synchronise fewer waves, at the price of 16 / 32-B segments
-  const char* e = getenv("PXM_DFT_R");
-  const int r = e ? atoi(e) : D5_RMAX;
-  *R = (r == 1 || r == 2) ? r : D5_RMAX;
+  // chains per workgroup: 4 = 64-B segments of the ring arrays, a compile-time constant of the kernels (index
+  // arithmetic of the staging folds).  (Until round 3 PXM_DFT_R=1|2 selected smaller workgroups for A/B runs: 79 / 92 us
+  // against 72 for the grouped launch -- fewer waves per barrier do not pay for 16 / 32-B segments.)
+  *R = D5_RMAX;
   *TR = 1;
   const size_t planes = (size_t)(*R) * 2 * D5_PLANE * 16, stage = (size_t)rpw * n * (*R) * 16;
   // the planes (aliased by the stage) and behind them the LDS copy of the pass twiddles; with R = 4:

@@ -45,5 +45,9 @@ int main() {
   run<8>(1, 4);
   run<4>(2, 4);
   run<8>(2, 4);
+  run<2>(4, 4);  // 4 and 8 waves per SIMD (the GEMM launches run 6-8 with two accumulators each)
+  run<4>(4, 4);
+  run<2>(8, 4);
+  run<8>(4, 4);
   return 0;
 }
