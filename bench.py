@@ -455,6 +455,10 @@ def main():
                            hbm_GBs=by_wgs[g["workgroups"]]["hbm_MB"] / g["avg_us"] * 1e3) for g in gemm_classes]
             tb = sum(c["hbm_MB"] * 1e6 * g["launches"] for c, g in zip(joined, gemm_classes))
             tt = sum(g["avg_us"] * 1e-6 * g["launches"] for g in gemm_classes)
+            # roofline.traffic: HBM bytes per launch of the timed iteration's launches only (the child passes also see
+            # the set-up transforms of the power iteration: other launch classes, dropped by the join)
+            traffic = tb / sum(g["launches"] for g in gemm_classes)
+            traffic_src += "; averaged over the launch classes of the timed iteration (joined on the workgroup count)"
             measured = {"hbm_GBs": tb / tt / 1e9, "hbm_frac": tb / tt / 1e9 / HBM_PEAK_GBS,
                         "what": "PMC bytes (FETCH_SIZE x2 + WRITE_SIZE, child passes) of each per-step launch class, joined "
                                 "on the workgroup count, / the live event time of the same class in this process",
