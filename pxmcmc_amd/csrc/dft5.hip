@@ -507,6 +507,9 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
   const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
   if (act && out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50)
     const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
+    // (the chain slot is the same for every lane of a wave: as a scalar, the Philox key -- seed + chain * odd constant,
+    // a 64-bit multiply -- is computed once on the scalar unit instead of per lane and per element)
+    const int ch_s = __builtin_amdgcn_readfirstlane(ch);
 #pragma unroll
     for (int g0 = 0; g0 < P1; g0 += 4) {  // all loads of a group first (independent), then its arithmetic
       // The loads are unconditional (elements past the ring end re-read the ring's element 0 and are dropped below;
@@ -524,7 +527,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         wph[u] = double2{0.0, 0.0};
-        if (!out.noise) wph[u] = px_noise_philox(out, ch, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
+        if (!out.noise) wph[u] = px_noise_philox(out, ch_s, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
@@ -556,7 +559,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         wph[u] = double2{0.0, 0.0};
-        if (!out.noise) wph[u] = px_noise_philox(out, ch, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
+        if (!out.noise) wph[u] = px_noise_philox(out, ch_s, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
