@@ -45,7 +45,8 @@ int pxm_noise_bits(void);
  * -- including the clamped / aliased loads whose values are discarded -- lies inside its buffer.  Builds the plans
  * named by `what` (1: SHT plan (L, spin); 2: wavelet plan (L, B, J_min) + Gram lists; 4: + weak-lensing lists) in
  * dry-run mode and returns the number of address ranges verified, < 0 on a violation (pxm_last_error names the task).
- * The same check runs at every real plan creation. */
+ * The same check runs at every real plan creation.  Not to be called while another thread creates plans (the dry-run
+ * switch is process-wide) nor during a stream capture. */
 int64_t pxm_host_check_address_ranges(int L, double B, int J_min, int spin, int max_chains, int what);
 const char* pxm_last_error(void);
 /* number of visible HIP devices (0 when none; never fails) */

@@ -816,7 +816,8 @@ int64_t tables_trim() {
   int64_t freed = 0;
   for (auto it = g_tab_cache.begin(); it != g_tab_cache.end();) {
     ShtTables* T = it->second;
-    if (T->refs > 0) {
+    // (a dry-run pass only drops its own entries -- device id 15 -- and leaves the real cache alone)
+    if (T->refs > 0 || (dry_run() && it->first.first % 16 != 15)) {
       ++it;
       continue;
     }
