@@ -335,6 +335,8 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
   constexpr int RPW = 8 / R0;                                                               \
   constexpr int lgR = 2, R = 4;                       /* chains per workgroup (compile-time: index arithmetic folds) */ \
   const int n = a.n;                                                                        \
+  /* Mh = 64 r0 is the smallest power of two >= n (r0 > 1): half of a lane's elements, j < 32 r0, need no j < n test */ \
+  if (R0 > 1) __builtin_assume(n > 32 * R0 && n <= 64 * R0);                                \
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63; /* wave: a scalar */ \
   const int half = wave & 1, unit = wave >> 1;        /* two waves per ring set */          \
   const D5Lane q{lane & 7, lane >> 3};                                                      \
