@@ -144,6 +144,75 @@ def test_sht_four_ops_literal_and_round_trip_large_L(L, spin):
     assert float(((lhs - rhs).abs() / lhs.abs()).max()) < 1e-11
 
 
+def test_wavelet_transform_literal_L512():
+    """The wavelet plan of BASELINE configs[4] (L=512, B=2, J_min=2: nine blocks, 1 221 796 coefficients) against the
+    DEFINITION of the four transforms (oracle.s2let.WaveletTransform = pxmcmc/transforms.py:101-154 through the
+    published pys2let formulae), restricted to inputs whose transforms are known in closed form.  A block that holds
+    one harmonic sampled on its own MW grid, X_j = Y_lm (band-limit bl_j > l), has forward transform delta_lm exactly,
+    so synthesis(X) = c_j kappa_j(l) Y_lm on the L grid; conversely analysis(Y_lm) = c^a_j kappa_j(l) Y_lm on every
+    block's grid; synthesis_adjoint is pinned through the literal inner products <synthesis(e_k), g> and
+    analysis_adjoint through <analysis(f), X> = <f, analysis_adjoint(X)> on dense random arrays.  Harmonics by the eigen route (no recursion in l, no tables), kernels kappa from
+    the oracle's tiling.  The fast oracle itself needs minutes and GBs of long-double tables at this size."""
+    import torch
+
+    from oracle import s2let, ssht, wigner
+    from pxmcmc_amd import ops
+
+    L, B, J_min = 512, 2, 2
+    bls = s2let.bandlimits(B, L, J_min)
+    k0, kap = s2let.tiling_axisym(B, L, J_min)
+    rows = [k0] + [kap[j] for j in range(J_min, kap.shape[0])]
+    c_syn = [1.0] + [s2let.C_SYNTHESIS] * (len(bls) - 1)
+    c_ana = [1.0] + [s2let.C_ANALYSIS] * (len(bls) - 1)
+    offs = np.concatenate([[0], np.cumsum([bl * (2 * bl - 1) for bl in bls])])
+    plan = ops.WavPlan(L, float(B), J_min, max_chains=1)
+    assert plan.ncoefs == offs[-1] == 1221796
+    thL, phL = ssht.sample_positions(L)
+    rng = np.random.default_rng(512)
+    # (block, l, m): the scaling function, small / middle scales and both top scales, inside each kernel's support
+    cases = [(0, 1, 1), (1, 5, -3), (4, 40, 17), (6, 200, -150), (7, 300, 299), (7, 400, 0), (8, 500, -499), (8, 511, 511)]
+    X = np.zeros(offs[-1], dtype=complex)
+    want_syn = np.zeros(L * (2 * L - 1), dtype=complex)
+    for i, el, m in cases:
+        bl = bls[i]
+        assert el < bl and rows[i][el] != 0.0, (i, el)
+        a = complex(rng.normal(), rng.normal())
+        th, ph = ssht.sample_positions(bl)
+        X[offs[i] : offs[i + 1]] += a * wigner.spin_harmonic_literal(el, m, 0, th, ph).ravel()
+        y = wigner.spin_harmonic_literal(el, m, 0, thL, phL).ravel()
+        want_syn += a * c_syn[i] * rows[i][el] * y
+    Xd = ops.as_device(X[None], torch.complex128)
+    got = plan.synthesis(Xd)[0].cpu().numpy()
+    assert np.abs(got - want_syn).max() < 1e-11 * np.abs(want_syn).max(), np.abs(got - want_syn).max()
+    # analysis of one harmonic: every block whose band holds it carries c^a kappa_j(l) Y_lm on its own grid
+    el, m = 300, -123
+    f = wigner.spin_harmonic_literal(el, m, 0, thL, phL).ravel()
+    W = plan.analysis(ops.as_device(f[None], torch.complex128))[0].cpu().numpy()
+    for i, bl in enumerate(bls):
+        blk = W[offs[i] : offs[i + 1]]
+        if el < bl and rows[i][el] != 0.0:
+            th, ph = ssht.sample_positions(bl)
+            ref = c_ana[i] * rows[i][el] * wigner.spin_harmonic_literal(el, m, 0, th, ph).ravel()
+            assert np.abs(blk - ref).max() < 1e-11 * max(np.abs(ref).max(), 1e-3), i
+        else:
+            assert np.abs(blk).max() < 1e-11, i
+    # analysis_adjoint against the analysis just checked: <A f, X> == <f, A^H X> on dense random arrays
+    fr = rng.normal(size=L * (2 * L - 1)) + 1j * rng.normal(size=L * (2 * L - 1))
+    Xr = rng.normal(size=offs[-1]) + 1j * rng.normal(size=offs[-1])
+    lhs = np.vdot(plan.analysis(ops.as_device(fr[None], torch.complex128))[0].cpu().numpy(), Xr)
+    rhs = np.vdot(fr, plan.analysis_adjoint(ops.as_device(Xr[None], torch.complex128))[0].cpu().numpy())
+    assert abs(lhs - rhs) < 1e-11 * abs(lhs)
+    # synthesis_adjoint: <S e_k, g> = (S^H g)_k for coefficient indices spread over every block
+    g = rng.normal(size=L * (2 * L - 1)) + 1j * rng.normal(size=L * (2 * L - 1))
+    Sg = plan.synthesis_adjoint(ops.as_device(g[None], torch.complex128))[0].cpu().numpy()
+    for i in range(len(bls)):
+        k = int(offs[i] + rng.integers(0, offs[i + 1] - offs[i]))
+        e = np.zeros(offs[-1], dtype=complex)
+        e[k] = 1.0
+        col = plan.synthesis(ops.as_device(e[None], torch.complex128))[0].cpu().numpy()
+        assert abs(np.vdot(col, g) - Sg[k]) < 1e-10 * max(abs(Sg[k]), np.linalg.norm(col) * np.linalg.norm(g) * 1e-3), i
+
+
 # ---- (ii) the fused MYULA iteration of the benchmark ---------------------------------------------------------
 def _plan_steps(path, plan, X0, data_c, invcov, T_dev, delta, lmda, noises, pairs):
     """K MYULA iterations through the very C-ABI calls the stepping engine makes (pxmcmc_amd/mcmc.py
