@@ -178,3 +178,46 @@ def test_bench_gpus2_self_launch_rehearsal():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 6 and out["warmup"] == 12
     assert out["config"]["global_chains"] == 32 and out["value"] > 0 and out["scaling"] == "weak"
     assert "cpu_baseline" not in out  # the CPU legs run at N = 1 only
+
+
+RCCL_WORKER = textwrap.dedent(
+    """
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["PXM_ROOT"])
+    import torch
+    import torch.distributed as dist
+    from pxmcmc_amd import distributed as D
+
+    torch.cuda.set_device(0)
+    # world size 1 (the test box has one GPU), but the REAL backend: RCCL initialises its communicator on cuda:0 and every
+    # collective of the benchmark's multi-GPU path (barrier, MAX / SUM all-reduce, all-gather) runs through it
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    D.barrier()
+    assert D.max_over_ranks(1.5) == 1.5
+    assert D.count_ranks() == 1
+    g = D.gather_summaries(np.arange(12.0).reshape(3, 4)).numpy()
+    assert g.shape == (3, 4) and np.array_equal(g, np.arange(12.0).reshape(3, 4))
+    D.barrier()
+    dist.destroy_process_group()
+    print("RCCL-OK", flush=True)
+    """
+)
+
+
+@pytest.mark.gpu
+def test_rccl_backend_single_rank_collectives(tmp_path):
+    """`pxmcmc_amd.distributed` on the backend the 8-GPU benchmark uses (`nccl` = RCCL), world size 1: communicator
+    initialisation with a device id, barrier, the max-over-ranks and rank-count all-reduces on device tensors and the
+    end-of-run all-gather.  (More than one rank per GPU is refused by RCCL; the two-rank tests above use gloo.)"""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, PXM_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    assert "RCCL-OK" in res.stdout
