@@ -297,7 +297,7 @@ def main():
     ap.add_argument("--ramp", type=int, default=400, help="untimed iterations before the warm-up (clock ramp; declared in the JSON)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=48)
-    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = min(cores, 16))")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = min(usable cores, 32))")
     ap.add_argument("--no-real-pairs", action="store_true", help="one complex128 slot per chain (reference layout)")
     ap.add_argument("--no-layout-compare", action="store_true", help="skip the reference-layout side measurement")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/pmc_summary.json instead of two rocprofv3 --pmc child passes")
