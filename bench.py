@@ -372,11 +372,17 @@ def main():
     # top-level "warmup" is the TOTAL untimed count (ramp + W); config.warmup_requested / clock_ramp_steps split it.
     untimed = args.ramp + args.warmup
     sampler._engine_advance(untimed)
+    # Timed region: start barrier (device idle + ranks aligned), then each rank times ITS OWN K steps up to its own
+    # device synchronise -- no torch.distributed call lies between t0 and dt (nothing crosses ranks on the data path, so a
+    # collective inside a 3-ms clock would only measure the collective).  The stop-side barrier follows, outside the
+    # clock; the reported time is the MAX over ranks of the per-rank times.
     barrier()
     t0 = time.perf_counter()
     sampler._engine_advance(args.steps)
+    torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0
     barrier()
-    dt = time.perf_counter() - t0
+    dt = dt_rank
     # roofline leg: the same steps once more through the same engine, launched eagerly (no graph replay) so that
     # every k_sht_gemm launch can be bracketed by HIP events on its stream (events cannot be read back from
     # inside a graph replay)
@@ -413,7 +419,15 @@ def main():
     if not os.environ.get("PXM_BENCH_ABLATION"):  # (timing-only ablation builds of the library compute garbage)
         assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
 
-    dt = D.max_over_ranks(dt)
+    dt = D.max_over_ranks(dt_rank)
+    per_rank_ms = [float(v) * 1e3 / args.steps for v in D.gather_summaries(np.array([dt_rank])).numpy().ravel()]
+    # cost of one empty start/stop barrier of this process group (synchronise + dist.barrier + synchronise), after the
+    # run: what the clock WOULD have contained had the stop barrier been inside it
+    barrier()
+    tb = time.perf_counter()
+    for _ in range(5):
+        barrier()
+    barrier_us = D.max_over_ranks((time.perf_counter() - tb) / 5) * 1e6
     ranks_seen = D.count_ranks()  # all-reduced over the process group (RCCL): the record shows N ranks took part
     used_graph = eng["graph"] is not None
 
@@ -472,6 +486,10 @@ def main():
             "steps": args.steps,
             "warmup": untimed,
             "ms_per_step": dt / args.steps * 1e3,
+            "per_rank_ms_per_step": per_rank_ms,
+            "barrier_us": barrier_us,
+            "timing": "per rank: start barrier, t0, K steps, own device synchronise, stop clock (no collective inside); "
+                      "ms_per_step = max over ranks; barrier_us = one empty barrier of the group, measured after the run",
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

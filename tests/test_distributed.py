@@ -159,6 +159,22 @@ def test_bench_self_launch_command_is_a_child_torchrun(monkeypatch):
     assert e.value.code == 5
 
 
+def test_bench_timed_region_holds_no_collective():
+    """bench.py's clock: `t0` right after the start barrier, `dt_rank` right after the rank's own device synchronise --
+    no torch.distributed call (barrier, all-reduce, gather) between the two (the chains never cross ranks,
+    experiments/earthtopography/main.py:31-36,169: one process per chain)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    i0 = src.index("t0 = time.perf_counter()\n    sampler._engine_advance(args.steps)")
+    i1 = src.index("dt_rank = time.perf_counter() - t0")
+    region = [ln.split("#")[0] for ln in src[i0:i1].splitlines()]
+    code = "\n".join(region)
+    for banned in ("barrier(", "dist.", "D.", "all_reduce", "max_over_ranks"):
+        assert banned not in code, (banned, code)
+    assert "torch.cuda.synchronize()" in code
+    before = src[:i0].rstrip().splitlines()[-1].strip()
+    assert before == "barrier()", before  # the start barrier is the last statement before the clock starts
+
+
 @pytest.mark.gpu
 def test_bench_gpus2_self_launch_rehearsal():
     """The driver's N > 1 command issued plainly: `python bench.py --gpus 2` (no torchrun in front).  On the test
@@ -178,6 +194,13 @@ def test_bench_gpus2_self_launch_rehearsal():
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 6 and out["warmup"] == 12
     assert out["config"]["global_chains"] == 32 and out["value"] > 0 and out["scaling"] == "weak"
     assert "cpu_baseline" not in out  # the CPU legs run at N = 1 only
+    # the clock of a rank stops at its own device synchronise (no collective inside): per-rank times are reported, the
+    # headline is their maximum, and the cost of one barrier of the group is measured separately
+    per_rank = out["per_rank_ms_per_step"]
+    assert len(per_rank) == 2 and all(t > 0 for t in per_rank)
+    assert abs(max(per_rank) - out["ms_per_step"]) <= 1e-9 * out["ms_per_step"]
+    assert out["barrier_us"] > 0
+    assert abs(out["value"] - 32 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
 
 
 RCCL_WORKER = textwrap.dedent(
