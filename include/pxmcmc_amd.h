@@ -38,15 +38,22 @@ typedef void* pxm_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------ */
 int pxm_version(void);
-/* precision of the Box-Muller step of the Philox noise stream this library was built with: 32 (default: f32
- * transcendental units, deviates ~1e-6 relative) or 64 (-DPXM_NOISE_F64 build; pxmcmc/mcmc.py:193 draws fp64) */
+/* Precision of the Box-Muller step of the Philox noise stream (pxmcmc/mcmc.py:193-195 draws fp64 randn).  Every
+ * entry point that can draw noise takes the flag PXM_NOISE_F64, OR-ed into its `mode` (pxm_wav_*_step), `noise_complex`
+ * (pxm_myula_step*, pxm_chain_step*, pxm_pxmala_propose) or `dtype` (pxm_randn) argument:
+ *   absent   Box-Muller on the f32 transcendental units (v_log_f32 / v_sin_f32 / v_cos_f32 with the exact fp64 exponent:
+ *            deviates ~1e-6 relative, tail to 8.5 sigma) -- the default, pxm_noise_bits() == 32;
+ *   present  log / sqrt / sincos evaluated in double precision (branch-free polynomials, csrc/philox.h): deviates equal
+ *            numpy's float64 evaluation of the same formulae to ~1e-15.
+ * Both read the same Philox4x32-10 counter stream and the same uniforms: the two streams agree to ~1e-6. */
+#define PXM_NOISE_F64 16
 int pxm_noise_bits(void);
 /* Host-only (no GPU) check that every global address a launch of the plans' GEMM task lists and DFT groups can form
  * -- including the clamped / aliased loads whose values are discarded -- lies inside its buffer.  Builds the plans
  * named by `what` (1: SHT plan (L, spin); 2: wavelet plan (L, B, J_min) + Gram lists; 4: + weak-lensing lists) in
  * dry-run mode and returns the number of address ranges verified, < 0 on a violation (pxm_last_error names the task).
- * The same check runs at every real plan creation.  Not to be called while another thread creates plans (the dry-run
- * switch is process-wide) nor during a stream capture. */
+ * The same check runs at every real plan creation.  The dry-run switch is per thread (plans created concurrently on
+ * other threads are real); not to be called during a stream capture. */
 int64_t pxm_host_check_address_ranges(int L, double B, int J_min, int spin, int max_chains, int what);
 const char* pxm_last_error(void);
 /* number of visible HIP devices (0 when none; never fails) */
@@ -115,11 +122,26 @@ int64_t pxm_wav_table_bytes(pxm_wav_plan_t plan, int op /*0 synthesis,1 synthesi
 int pxm_wav_set_iter_counter(pxm_wav_plan_t plan, uint64_t* counter_dev);
 int pxm_wav_release_iter_counter(pxm_wav_plan_t plan, const uint64_t* counter_dev);
 int pxm_wav_iter_counter_add(pxm_wav_plan_t plan, uint64_t inc, pxm_stream_t stream);
-/* With PXM_FLOW=1 (read when a plan's Gram lists are built) the ring-space step launches its Gram and forward-adjoint
- * GEMM tasks in one grid with per-order counters between them.  A wait that is never satisfied raises a flag instead
- * of hanging the GPU:
- * 0 = every wait of this plan's launches so far was satisfied, 1 = one timed out (results invalid).  Synchronises. */
+/* Device status of a plan.  Two kernels of this library wait on each other with BOUNDED spins instead of barriers: the
+ * wave pairs of the fused phi-DFT kernels (csrc/dft5.hip, d5_pair_sync: an LDS counter per pair) and, with PXM_FLOW=1
+ * (experimental; read when a plan's Gram lists are built), the forward-adjoint tasks of the dataflow GEMM launch (per-
+ * order counters).  A wait that expires does not hang the GPU -- the kernel runs on with data its partner has not
+ * written -- and ORs a bit into the plan's status word; the results of that launch are invalid.  The reference fails
+ * loudly on bad state (pxmcmc/mcmc.py:104-109); so does the sampler here: it reads the word wherever it already
+ * synchronises (saved samples, progress prints, end of run) and raises.
+ *   pxm_wav_status / pxm_sht_status : bit mask since the last clear, 0 = every wait was satisfied; `clear` != 0 resets
+ *                                     it after reading.  Synchronises the stream.  < 0: error.
+ *   pxm_wav_flow_status             : the PXM_STATUS_FLOW_WAIT bit as 0 / 1 (round-3 interface).
+ *   pxm_wav_flow_enabled            : 1 when this plan's ring-space step takes the dataflow launch (known after
+ *                                     pxm_wav_ring_set_data), 0 when it runs the two ordinary launches.
+ * PXM_DEBUG_PAIR_SYNC_LIMIT=<n> (read at plan creation) sets the bound of the pair wait; 0 forces every wait to
+ * expire -- the test of this report path. */
+#define PXM_STATUS_FLOW_WAIT 1
+#define PXM_STATUS_PAIR_SYNC 2
+int pxm_wav_status(pxm_wav_plan_t plan, int clear, pxm_stream_t stream);
+int pxm_sht_status(pxm_sht_plan_t plan, int clear, pxm_stream_t stream);
 int pxm_wav_flow_status(pxm_wav_plan_t plan, pxm_stream_t stream);
+int pxm_wav_flow_enabled(pxm_wav_plan_t plan);
 
 /* Live kernel timing of one plan (bench.py roofline leg).  pxm_wav_profile_enable(plan, n) with n > 0 creates
  * n event pairs per kernel class; while enabled every SHT ring-GEMM launch and every grouped phi-DFT launch of
@@ -152,7 +174,8 @@ int64_t pxm_wav_workspace_nonfinite(pxm_wav_plan_t plan, pxm_stream_t stream);
  *   PXM_MODE_REAL_PAIRS 2  real data and real state: slot c carries the two REAL chains 2c (real part) and
  *                          2c+1 (imaginary part) through the complex-linear transforms; soft threshold and
  *                          noise are applied per component (injected noise: float64 [2C][N]; Philox keys
- *                          chain0 + 2c and chain0 + 2c + 1); data must then be passed as d + i d. */
+ *                          chain0 + 2c and chain0 + 2c + 1); data must then be passed as d + i d.
+ * | PXM_NOISE_F64: the Philox stream's Box-Muller step in double precision (see pxm_noise_bits above). */
 #define PXM_MODE_REAL_NOISE 0
 #define PXM_MODE_CPLX_NOISE 1
 #define PXM_MODE_REAL_PAIRS 2
@@ -247,6 +270,10 @@ int pxm_chain_step_it(const void* X, const void* proxf, const void* gradg, const
 /* N(0,1) draws of the Philox4x32-10 stream keyed (seed, chain0+c, iter): out [C][n] (f64 or c128) */
 int pxm_randn(void* out, int64_t n, int C, int dtype, uint64_t seed, uint64_t chain0, uint64_t iter,
               pxm_stream_t stream);
+/* The Box-Muller step of that stream on GIVEN uniforms u1, u2 in (0, 1] (device arrays [n]): z0 = r cos(2 pi u2),
+ * z1 = r sin(2 pi u2), r = sqrt(-2 ln u1); f64 != 0 selects the double-precision evaluation.  Test aid: the edge cases
+ * (u1 rounding to 1, the smallest u1, quadrant boundaries of u2) have probability ~2^-53 under Philox. */
+int pxm_box_muller(const double* u1, const double* u2, double* z0, double* z1, int64_t n, int f64, pxm_stream_t stream);
 /* The reductions below are deterministic two-stage sums; `scratch` is a caller-owned device buffer of
  * pxm_reduce_scratch_doubles(C) doubles (no library-owned buffer is shared between calls or streams). */
 int64_t pxm_reduce_scratch_doubles(int C);

@@ -319,23 +319,28 @@ def myula_run(fwd, prior, lmda, delta, mu, nsamples, nburn, ngap, X0, noise, cpl
     return out
 
 
-def pxmala_run(fwd, prior, lmda, delta, mu, nsamples, nburn, ngap, X0, noise, unif, tune=True):
-    """pxmcmc/mcmc.py:218-275 with injected normal ``noise(i)`` and uniform ``unif(i)`` draws."""
+def pxmala_run(fwd, prior, lmda, delta, mu, nsamples, nburn, ngap, X0, noise, unif, tune=True, max_iter=None):
+    """pxmcmc/mcmc.py:218-275 with injected normal ``noise(i)`` and uniform ``unif(i)`` draws.  ``max_iter`` (test
+    aid, not in the reference) stops after that many iterations; ``lt_cp`` / ``lt_pc`` record both
+    calc_logtransition values of every iteration (:240-241)."""
     X = np.array(X0)
     preds = fwd.forward(X)
     gradg = fwd.calc_gradg(preds)
     px = prior.proxf(X)
     lpc, l2c, prc = logpi(X, preds, fwd.data, fwd.invcov, prior.prior, mu)
     acc, deltas = [], [delta]
+    lt_cp, lt_pc = [], []
     out = dict(chain=[], logPi=[], L2s=[], priors=[], preds=[])
     i = j = 0
-    while j < nsamples:
+    while j < nsamples and (max_iter is None or i < max_iter):
         Xp = chain_step(X, px, gradg, delta, lmda, noise(i))
         pp = fwd.forward(Xp)
         gp = fwd.calc_gradg(pp)
         pxp = prior.proxf(Xp)
         t_cp = calc_logtransition(X, Xp, px, gradg, delta, lmda)
         t_pc = calc_logtransition(Xp, X, pxp, gp, delta, lmda)
+        lt_cp.append(t_cp)
+        lt_pc.append(t_pc)
         lpp, l2p, prp = logpi(Xp, pp, fwd.data, fwd.invcov, prior.prior, mu)
         logalpha = t_pc + lpp - t_cp - lpc
         accept = np.log(unif(i)) < logalpha
@@ -355,5 +360,6 @@ def pxmala_run(fwd, prior, lmda, delta, mu, nsamples, nburn, ngap, X0, noise, un
         i += 1
     out = {k: np.array(v) for k, v in out.items()}
     out["acceptance_trace"], out["deltas_trace"] = np.array(acc), np.array(deltas)
+    out["lt_cp"], out["lt_pc"] = np.array(lt_cp), np.array(lt_pc)
     out["X"], out["niter"] = X, i
     return out

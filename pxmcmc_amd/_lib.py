@@ -34,6 +34,9 @@ SIGNATURES = {
     "pxm_wav_release_iter_counter": (c_int, [c_vp, c_vp]),
     "pxm_wav_iter_counter_add": (c_int, [c_vp, c_u64, c_vp]),
     "pxm_wav_flow_status": (c_int, [c_vp, c_vp]),
+    "pxm_wav_flow_enabled": (c_int, [c_vp]),
+    "pxm_wav_status": (c_int, [c_vp, c_int, c_vp]),
+    "pxm_sht_status": (c_int, [c_vp, c_int, c_vp]),
     "pxm_wav_profile_enable": (c_int, [c_vp, c_int]),
     "pxm_wav_profile_read": (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "pxm_wav_profile_read_launches": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
@@ -98,6 +101,7 @@ SIGNATURES = {
         [c_vp, c_vp, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_int, c_u64, c_u64, c_u64, c_vp, c_vp, c_i64, c_int, c_int, c_vp],
     ),
     "pxm_randn": (c_int, [c_vp, c_i64, c_int, c_int, c_u64, c_u64, c_u64, c_vp]),
+    "pxm_box_muller": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp]),
     "pxm_reduce_l1": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_reduce_l2": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
     "pxm_reduce_vdot": (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]),
@@ -126,6 +130,10 @@ SIGNATURES = {
 
 class PxmError(RuntimeError):
     pass
+
+
+NOISE_F64 = 16  # PXM_NOISE_F64: OR-ed into the mode / noise_complex / dtype argument of the noise-drawing entry points
+STATUS_FLOW_WAIT, STATUS_PAIR_SYNC = 1, 2  # bits of pxm_wav_status / pxm_sht_status
 
 
 def _load():

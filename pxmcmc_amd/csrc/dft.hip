@@ -163,6 +163,7 @@ int make_dft_plan(int L, DftPlan* p) {
     if (rc) return rc;
     dft5_geometry(b.n, &p->R5, &p->TR5, &p->lds5);
     p->use5 = true;
+    if (const char* e = getenv("PXM_DEBUG_PAIR_SYNC_LIMIT")) p->spin_limit = (unsigned)std::max(0, atoi(e));
   }
   if (b.n > 512 && b.n <= 1023 && !getenv("PXM_DFT_NO_W")) {
     rc = dft6_make_tables(b.n, &p->t6);  // 256 < L <= 512: four waves per ring, 8 points per lane

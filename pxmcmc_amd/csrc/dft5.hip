@@ -75,6 +75,8 @@ struct Dft5Args {
   const double2* wt;    // [8][8]  W_(8 r0)^(a b)
   const double2* bE;    // [r0][64] FFT_M(filter)/M at the even bins, in the order pass 3 leaves them
   const double2* bO;    // [r0][64] the odd bins
+  unsigned* err;        // status word of the owning plan (bit PXM_STATUS_PAIR_SYNC: a pair wait expired) or null
+  unsigned spin_limit;  // bound of the pair wait (1 << 18; PXM_DEBUG_PAIR_SYNC_LIMIT at plan creation forces an expiry)
 };
 
 // one scale of a grouped launch
@@ -107,19 +109,28 @@ __device__ __forceinline__ void d5_barrier() {
 // in lock-step -- all eight waves hit the LDS in the same phase and the vector ALUs in the next -- although only the
 // pairs exchange anything between the staging barriers; decoupled, the pairs drift apart and one pair's transposes
 // overlap another's butterflies.  LDS operations of a wave are performed in order, so the ds_add behind the wave's
-// ds_writes publishes them; the spin is bounded (a lost partner would otherwise hang the GPU: the kernel then runs
-// on with wrong data instead, which the parity tests catch).  -DPXM_D5_NO_PAIR_SYNC: workgroup barriers as before.
-__device__ __forceinline__ void d5_pair_sync(unsigned* cnt, unsigned target, int lane) {
+// ds_writes publishes them.  The spin is bounded (a lost partner would otherwise hang the GPU); a wait that EXPIRES
+// sets bit PXM_STATUS_PAIR_SYNC of the owning plan's status word -- the kernel runs on with data its partner has not
+// written, and the host finds the bit wherever it already synchronises (pxm_wav_status / pxm_sht_status: the sampler
+// raises at its next save point instead of returning a silently corrupted chain).  -DPXM_D5_NO_PAIR_SYNC: workgroup
+// barriers as before.
+struct D5Sync {
+  unsigned* err;
+  unsigned limit;
+};
+__device__ __forceinline__ void d5_pair_sync(unsigned* cnt, unsigned target, int lane, const D5Sync& sy) {
 #ifdef PXM_D5_NO_PAIR_SYNC
-  (void)cnt; (void)target; (void)lane;
+  (void)cnt; (void)target; (void)lane; (void)sy;
   d5_barrier();
 #else
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   unsigned spins = 0;
-  while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < (int)target &&
-         ++spins < (1u << 18))
+  bool ready;
+  while (!(ready = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= (int)target) &&
+         ++spins < sy.limit)
     __builtin_amdgcn_s_sleep(1);
+  if (!ready && sy.err && lane == 0) __hip_atomic_fetch_or(sy.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("" ::: "memory");
 #endif
 }
@@ -305,20 +316,20 @@ __device__ __forceinline__ double2 d5_sel(int half, double2 a, double2 b) { retu
 // SLOT selects one of two disjoint exchange regions of the planes (two exchanges may be in flight).
 template <int SLOT>
 __device__ __forceinline__ void d5_exchange_sum(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half,
-                                                unsigned* pcnt, unsigned& epoch) {
+                                                unsigned* pcnt, unsigned& epoch, const D5Sync& sy) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) plane[256 * SLOT + 64 * u + lane] = d5_sel(half, x[u], x[4 + u]);
-  d5_pair_sync(pcnt, epoch += 2, lane);
+  d5_pair_sync(pcnt, epoch += 2, lane, sy);
 #pragma unroll
   for (int u = 0; u < 4; ++u) x[u] = cadd(d5_sel(half, x[4 + u], x[u]), pplane[256 * SLOT + 64 * u + lane]);
 }
 // own elements x[0..4) -> partner; x <- all 8 elements of the ring in natural order (both waves then hold them)
 template <int SLOT>
 __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane, double2* pplane, int lane, int half,
-                                                 unsigned* pcnt, unsigned& epoch) {
+                                                 unsigned* pcnt, unsigned& epoch, const D5Sync& sy) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) plane[256 * SLOT + 64 * u + lane] = x[u];
-  d5_pair_sync(pcnt, epoch += 2, lane);
+  d5_pair_sync(pcnt, epoch += 2, lane, sy);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const double2 o = pplane[256 * SLOT + 64 * u + lane], own = x[u];
@@ -359,6 +370,7 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
   /* (row a = 0 of the wt copy, tw[448 .. 455], is never read: it holds the pair counters of d5_pair_sync) */ \
   unsigned* pcnt = reinterpret_cast<unsigned*>(lds5 + 2 * R * D5_PLANE + 448) + unit;       \
   unsigned epoch = 0;                                                                       \
+  const D5Sync sy{a.err, a.spin_limit};                                                     \
   for (int i = threadIdx.x; i < D5_TW; i += 512)                                     \
     lds5[2 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : (i < 456 ? double2{0.0, 0.0} : a.wt[i - 448]);
 #define PXM_D5_SLOT(RING, K, CH) ((((RING)*n + (K)) << lgR) + (((CH) + ((K) >> rsh)) & (R - 1)))
@@ -389,7 +401,7 @@ __device__ __forceinline__ void d5_exchange_fill(double2 (&x)[8], double2* plane
 // the transform of x (all 8 elements in every wave of the ring) -> the wave's own elements of the result in x[0 .. P1)
 #define PXM_D5_TRANSFORM(SLOT)                                            \
   d5_dft_half<R0>(x, plane, lane, q, jb, half, a, tw);                    \
-  d5_exchange_sum<SLOT>(x, plane, pplane, lane, half, pcnt, epoch);
+  d5_exchange_sum<SLOT>(x, plane, pplane, lane, half, pcnt, epoch, sy);
 // own elements of x -> stage (after every plane of the workgroup is dead)
 #define PXM_D5_TO_STAGE                                                   \
   d5_barrier();                                                        \
@@ -449,7 +461,9 @@ __device__ unsigned long long* g_dft_trace = nullptr;
 #else
 #define PXM_D5_STAMP(K)
 #endif
-template <int R0, bool RING_OUT>
+// N64: the Philox stream's Box-Muller step in double precision (PxOut::noise64; a kernel instantiation of its own: the
+// fp64 evaluation holds ~40 registers and the update epilogue sits at the 128-VGPR budget of four waves per SIMD)
+template <int R0, bool RING_OUT, bool N64>
 __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restrict__ G, int ncol, const PxOut& out, int C,
                                               int bx, int by, double2* lds5) {
   // chain groups without a live chain do nothing (see run_tasks / GemmAffine::ncol_live: nothing iterates on them)
@@ -529,7 +543,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         wph[u] = double2{0.0, 0.0};
-        if (!out.noise) wph[u] = px_noise_philox(out, ch_s, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
+        if (!out.noise) wph[u] = px_noise_philox_t<N64>(out, ch_s, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
@@ -561,7 +575,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         wph[u] = double2{0.0, 0.0};
-        if (!out.noise) wph[u] = px_noise_philox(out, ch_s, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
+        if (!out.noise) wph[u] = px_noise_philox_t<N64>(out, ch_s, e0 + (int64_t)(8 * R0) * (g0 + u), it_eff);
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
@@ -578,7 +592,7 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
 #if PXM_D5_PHILOX_FIRST
         if (!out.noise) w = wph[u];
 #elif !(PXM_D5_ABLATE & 1)
-        if (!out.noise) w = px_noise_philox(out, ch, e0 + off, it_eff);
+        if (!out.noise) w = px_noise_philox_t<N64>(out, ch, e0 + off, it_eff);
 #endif
         x[p] = px_update(out, xs[u], Ts[u], y, w);
         reinterpret_cast<double2*>(out.f)[ce0 + off] = x[p];
@@ -624,8 +638,8 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
   if (!RING_OUT) return;
   PXM_D5_STAMP(2)  // prox + update + noise done
   // ---- forward transform of the updated ring
-  d5_exchange_fill<1>(x, plane, pplane, lane, half, pcnt, epoch);  // both waves of the ring set need all 8 elements
-  d5_pair_sync(pcnt, epoch += 2, lane);            // ... and every exchange read is done before the planes are reused
+  d5_exchange_fill<1>(x, plane, pplane, lane, half, pcnt, epoch, sy);  // both waves of the ring set need all 8 elements
+  d5_pair_sync(pcnt, epoch += 2, lane, sy);        // ... and every exchange read is done before the planes are reused
   PXM_D5_TRANSFORM(0)
   PXM_D5_STAMP(3)  // forward transform done
   PXM_D5_TO_STAGE
@@ -649,11 +663,11 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_px2ring5(Dft5Args a, PxIn 
   px2ring_body5<R0>(a, in, G, ncol, C, blockIdx.x, blockIdx.y, lds5);
 }
 
-template <int R0, bool RING_OUT>
+template <int R0, bool RING_OUT, bool N64>
 __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px5(Dft5Args a, double* __restrict__ G, int ncol,
                                                                                  PxOut out, int C) {
   extern __shared__ double2 lds5[];
-  ring2px_body5<R0, RING_OUT>(a, G, ncol, out, C, blockIdx.x, blockIdx.y, lds5);
+  ring2px_body5<R0, RING_OUT, N64>(a, G, ncol, out, C, blockIdx.x, blockIdx.y, lds5);
 }
 
 // block id -> (scale entry, bx, by).  XCD-aware order inside a scale: the chain groups (by) of one ring set share
@@ -695,7 +709,7 @@ extern "C" int pxm_debug_set_dft_trace(unsigned long long* buf) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_dft_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
 }
 #endif
-template <bool RING_OUT>
+template <bool RING_OUT, bool N64>
 __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5Group* __restrict__ ents, int nent,
                                                                                        double* __restrict__ ws, int ncol, PxOut out,
                                                                                        int C, unsigned* __restrict__ zero_words,
@@ -710,10 +724,10 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5G
   PXM_D5_GROUP_DECODE
   out.ring0 = g.ring0;
   switch (g.r0) {
-    case 8: ring2px_body5<8, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
-    case 4: ring2px_body5<4, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
-    case 2: ring2px_body5<2, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
-    default: ring2px_body5<1, RING_OUT>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 8: ring2px_body5<8, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 4: ring2px_body5<4, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
+    case 2: ring2px_body5<2, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
+    default: ring2px_body5<1, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
   }
 #ifdef PXM_D5_TRACE
   if (threadIdx.x == 0 && g_dft_trace) {
@@ -897,6 +911,7 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
   }
 }
 
+template <bool N64>
 __global__ __launch_bounds__(512, 4) void k_ring2px6(Dft6Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
   extern __shared__ double2 lds5[];
   const int bx = blockIdx.x, by = blockIdx.y;
@@ -970,7 +985,7 @@ __global__ __launch_bounds__(512, 4) void k_ring2px6(Dft6Args a, const double* _
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (!ok[u]) continue;
-      const double2 wv = out.noise ? wn[u] : px_noise_philox(out, ch, e0 + eo[u], it_eff);
+      const double2 wv = out.noise ? wn[u] : px_noise_philox_t<N64>(out, ch, e0 + eo[u], it_eff);
       reinterpret_cast<double2*>(out.f)[ce0 + eo[u]] = px_update(out, xs[u], Ts[u], yv[u], wv);
     }
   } else {
@@ -1074,7 +1089,8 @@ void dft5_geometry(int n, int* R, int* TR, size_t* lds) {
 static Dft5Args dft5_args(const DftPlan& p) {
   const Dft5Tables& t = p.t5;
   auto c = [](const double* x) { return reinterpret_cast<const double2*>(x); };
-  return Dft5Args{p.L, p.n, p.Rp, p.R5 == 4 ? 2 : (p.R5 == 2 ? 1 : 0), c(t.cE), c(t.cO), c(t.dO), c(t.tw1), c(t.wt), c(t.bE), c(t.bO)};
+  return Dft5Args{p.L, p.n, p.Rp, p.R5 == 4 ? 2 : (p.R5 == 2 ? 1 : 0), c(t.cE), c(t.cO), c(t.dO), c(t.tw1), c(t.wt), c(t.bE), c(t.bO),
+                  p.d_status, p.spin_limit};
 }
 
 template <int R0>
@@ -1082,8 +1098,10 @@ static int dft5_attr() {
   static bool done = false;
   if (!done) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring5<R0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
   return 0;
@@ -1104,10 +1122,14 @@ static int ring2px5_r(const DftPlan& p, const double* G, int ncol, const PxOut& 
   if (int rc = dft5_attr<R0>()) return rc;
   const int rings = p.TR5 * (8 / R0);
   dim3 grid((p.L + rings - 1) / rings, (C + p.R5 - 1) / p.R5), block(128 * p.R5);
+  // (the fp64-noise instantiations only where the launch draws Philox noise in double precision)
+  const bool n64 = out.X && !out.noise && out.noise64;
   if (ring_out) {
-    hipLaunchKernelGGL((k_ring2px5<R0, true>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
+    if (n64) hipLaunchKernelGGL((k_ring2px5<R0, true, true>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
+    else hipLaunchKernelGGL((k_ring2px5<R0, true, false>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
   } else {
-    hipLaunchKernelGGL((k_ring2px5<R0, false>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
+    if (n64) hipLaunchKernelGGL((k_ring2px5<R0, false, true>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
+    else hipLaunchKernelGGL((k_ring2px5<R0, false, false>), grid, block, p.lds5, st, dft5_args(p), const_cast<double*>(G), ncol, out, C);
   }
   PXM_HIP(hipGetLastError());
   return 0;
@@ -1208,8 +1230,10 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
   if (int rc = dev_upload(out->d, v.data(), v.size() * sizeof(Dft5Group))) return rc;
   static bool attr = false;
   if (!attr && !dry_run()) {
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px_group5<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px_group5<true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px_group5<true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px_group5<false, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px_group5<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring_group5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
@@ -1230,8 +1254,12 @@ int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& 
   const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
-  hipExtLaunchKernelGGL(k_ring2px_group5<true>, dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
-                        reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero);
+  if (out.X && !out.noise && out.noise64)
+    hipExtLaunchKernelGGL((k_ring2px_group5<true, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
+                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero);
+  else
+    hipExtLaunchKernelGGL((k_ring2px_group5<true, false>), dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
+                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -1246,8 +1274,12 @@ int dft5_group_px2ring(const DftGroupList& g, double* ws, int ncol, const PxIn& 
 
 int dft5_group_ring2px(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
   PXM_REQUIRE(out.gidx || g.ring_end <= out.chain_stride, "dft5_group_ring2px: a scale's coefficient block ends past chain_stride");
-  hipLaunchKernelGGL(k_ring2px_group5<false>, dim3(g.blocks), dim3(g.threads), g.lds, st, reinterpret_cast<const Dft5Group*>(g.d),
-                     g.n, ws, ncol, out, C, (unsigned*)nullptr, 0);
+  if (out.X && !out.noise && out.noise64)
+    hipLaunchKernelGGL((k_ring2px_group5<false, true>), dim3(g.blocks), dim3(g.threads), g.lds, st,
+                       reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, (unsigned*)nullptr, 0);
+  else
+    hipLaunchKernelGGL((k_ring2px_group5<false, false>), dim3(g.blocks), dim3(g.threads), g.lds, st,
+                       reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, (unsigned*)nullptr, 0);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -1333,7 +1365,8 @@ static int dft6_attr() {
   static bool done = false;
   if (!done) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px6<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px6<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
   return 0;
@@ -1348,7 +1381,8 @@ int dft6_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, h
 int dft6_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st) {
   if (int rc = dft6_attr()) return rc;
   dim3 grid(p.L, (C + D6_R - 1) / D6_R), block(256 * D6_R);
-  hipLaunchKernelGGL(k_ring2px6, grid, block, dft6_lds(), st, dft6_args(p), G, ncol, out, C);
+  if (out.X && !out.noise && out.noise64) hipLaunchKernelGGL(k_ring2px6<true>, grid, block, dft6_lds(), st, dft6_args(p), G, ncol, out, C);
+  else hipLaunchKernelGGL(k_ring2px6<false>, grid, block, dft6_lds(), st, dft6_args(p), G, ncol, out, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }

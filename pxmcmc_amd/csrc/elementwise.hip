@@ -54,7 +54,13 @@ struct NoiseSrc {
   int noise_complex;
   uint64_t seed, chain0, iter;
   const uint64_t* iter_dev = nullptr;  // optional device-resident addend to iter (caller-owned counter: graph replay)
+  int f64 = 0;                         // Box-Muller step in double precision (flag PXM_NOISE_F64 of the entry point)
 };
+// noise_complex argument of the entry points = (0 | 1) | PXM_NOISE_F64
+static inline NoiseSrc make_noise_src(const void* noise, int noise_arg, uint64_t seed, uint64_t chain0, uint64_t iter,
+                                      const uint64_t* iter_dev = nullptr) {
+  return NoiseSrc{(const double*)noise, noise_arg & 1, seed, chain0, iter, iter_dev, (noise_arg & PXM_NOISE_F64) ? 1 : 0};
+}
 
 template <bool CPLX>
 __device__ inline double2 draw_noise(const NoiseSrc& ns, int c, int64_t n, int64_t i) {
@@ -64,10 +70,10 @@ __device__ inline double2 draw_noise(const NoiseSrc& ns, int c, int64_t n, int64
   }
   const uint64_t it = ns.iter + (ns.iter_dev ? *ns.iter_dev : 0);
   if (CPLX && ns.noise_complex) {
-    NormalPair q = philox_normal_pair(ns.seed, ns.chain0 + c, (uint64_t)i, it);
+    NormalPair q = philox_normal_pair(ns.seed, ns.chain0 + c, (uint64_t)i, it, ns.f64);
     return double2{q.z0, q.z1};
   }
-  return double2{philox_normal_real(ns.seed, ns.chain0 + c, (uint64_t)i, it), 0.0};
+  return double2{philox_normal_real(ns.seed, ns.chain0 + c, (uint64_t)i, it, ns.f64), 0.0};
 }
 
 // X_out = (1-d/l) X + (d/l) P - d g + sqrt(2d) w, with P = soft(X,T) (FUSED_PROX) or given
@@ -100,6 +106,16 @@ __global__ void k_randn(double* __restrict__ out, int64_t n, NoiseSrc ns) {
     const double2 w = draw_noise<CPLX>(ns, c, n, i);
     if (CPLX) reinterpret_cast<double2*>(out)[(int64_t)c * n + i] = w;
     else out[(int64_t)c * n + i] = w.x;
+  }
+}
+
+// the Box-Muller step of the noise stream on given uniforms (test aid: its edge cases cannot be reached through Philox)
+__global__ void k_box_muller(const double* __restrict__ u1, const double* __restrict__ u2, double* __restrict__ z0,
+                             double* __restrict__ z1, int64_t n, int f64) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const NormalPair q = f64 ? box_muller_f64(u1[i], u2[i]) : box_muller_fast(u1[i], u2[i]);
+    z0[i] = q.z0;
+    z1[i] = q.z1;
   }
 }
 
@@ -474,9 +490,10 @@ int pxm_myula_step_it(const void* X, const void* gradg, const double* T, double 
                       pxm_stream_t stream) {
   CHECK_ARGS("pxm_myula_step");
   PXM_REQUIRE(X && gradg && X_out, "pxm_myula_step: null buffer");
-  PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_myula_step: complex noise needs a complex state");
+  PXM_REQUIRE((noise_complex & ~(1 | PXM_NOISE_F64)) == 0, "pxm_myula_step: noise_complex must be 0 or 1 (| PXM_NOISE_F64)");
+  PXM_REQUIRE(dtype == 1 || !(noise_complex & 1), "pxm_myula_step: complex noise needs a complex state");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, iter_dev};
+  NoiseSrc ns = make_noise_src(noise, noise_complex, seed, chain0, iter, iter_dev);
   if (dtype)
     hipLaunchKernelGGL((k_chain_step<true, true>), g, b, 0, st, (const double*)X, (const double*)nullptr,
                        (const double*)gradg, T, T_scalar, delta_dev, delta, lmda, ns, (double*)X_out, n);
@@ -499,9 +516,10 @@ int pxm_chain_step_it(const void* X, const void* proxf, const void* gradg, const
                       const uint64_t* iter_dev, void* X_out, int64_t n, int C, int dtype, pxm_stream_t stream) {
   CHECK_ARGS("pxm_chain_step");
   PXM_REQUIRE(X && proxf && gradg && X_out, "pxm_chain_step: null buffer");
-  PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_chain_step: complex noise needs a complex state");
+  PXM_REQUIRE((noise_complex & ~(1 | PXM_NOISE_F64)) == 0, "pxm_chain_step: noise_complex must be 0 or 1 (| PXM_NOISE_F64)");
+  PXM_REQUIRE(dtype == 1 || !(noise_complex & 1), "pxm_chain_step: complex noise needs a complex state");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, iter_dev};
+  NoiseSrc ns = make_noise_src(noise, noise_complex, seed, chain0, iter, iter_dev);
   if (dtype)
     hipLaunchKernelGGL((k_chain_step<true, false>), g, b, 0, st, (const double*)X, (const double*)proxf,
                        (const double*)gradg, (const double*)nullptr, 0.0, delta_dev, delta, lmda, ns, (double*)X_out, n);
@@ -521,12 +539,23 @@ int pxm_chain_step(const void* X, const void* proxf, const void* gradg, const do
 
 int pxm_randn(void* out, int64_t n, int C, int dtype, uint64_t seed, uint64_t chain0, uint64_t iter,
               pxm_stream_t stream) {
+  const int f64flag = dtype & PXM_NOISE_F64;  // dtype = (0 | 1) | PXM_NOISE_F64
+  dtype &= ~PXM_NOISE_F64;
   CHECK_ARGS("pxm_randn");
   PXM_REQUIRE(out, "pxm_randn: null buffer");
   dim3 g = ew_grid(n, C), b(256);
-  NoiseSrc ns{nullptr, dtype, seed, chain0, iter};
-  if (dtype) hipLaunchKernelGGL(k_randn<true>, g, b, 0, st, (double*)out, n, ns);
+  NoiseSrc ns = make_noise_src(nullptr, dtype | f64flag, seed, chain0, iter);
+  if (dtype & 1) hipLaunchKernelGGL(k_randn<true>, g, b, 0, st, (double*)out, n, ns);
   else hipLaunchKernelGGL(k_randn<false>, g, b, 0, st, (double*)out, n, ns);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_box_muller(const double* u1, const double* u2, double* z0, double* z1, int64_t n, int f64, pxm_stream_t stream) {
+  PXM_REQUIRE(u1 && u2 && z0 && z1 && n >= 0, "pxm_box_muller: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_box_muller, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     u1, u2, z0, z1, n, f64);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -609,11 +638,12 @@ int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, cons
   PXM_REQUIRE(n >= 1 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_pxmala_propose: bad n / C / dtype");
   PXM_REQUIRE(X && proxf && gradg && delta_dev && X_prop && proxf_prop && logtrans_out && prior_out && scratch,
               "pxm_pxmala_propose: null buffer");
-  PXM_REQUIRE(dtype == 1 || !noise_complex, "pxm_pxmala_propose: complex noise needs a complex state");
+  PXM_REQUIRE((noise_complex & ~(1 | PXM_NOISE_F64)) == 0, "pxm_pxmala_propose: noise_complex must be 0 or 1 (| PXM_NOISE_F64)");
+  PXM_REQUIRE(dtype == 1 || !(noise_complex & 1), "pxm_pxmala_propose: complex noise needs a complex state");
   hipStream_t st = (hipStream_t)stream;
   const int RS = red_slices(n);
   dim3 g(RS, C), b(256);
-  NoiseSrc ns{(const double*)noise, noise_complex, seed, chain0, iter, iter_dev};
+  NoiseSrc ns = make_noise_src(noise, noise_complex, seed, chain0, iter, iter_dev);
   if (dtype)
     hipLaunchKernelGGL(k_pxmala_propose<true>, g, b, 0, st, (const double*)X, (const double*)proxf, (const double*)gradg, T,
                        T_scalar, prior_weights, delta_dev, lmda, ns, (double*)X_prop, (double*)proxf_prop, scratch, n);

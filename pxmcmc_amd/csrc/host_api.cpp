@@ -65,7 +65,10 @@ struct Region {
 };
 std::mutex g_reg_mu;
 std::map<uintptr_t, Region> g_regions;  // by start address
-bool g_dry = false;
+// Dry-run mode is PER THREAD: pxm_host_check_address_ranges runs the real plan builders on the calling thread with fake
+// addresses; a plan created meanwhile on another thread must still get real device memory (a process-wide flag handed
+// it 0x7000... addresses with uploads skipped, and its first launch would have faulted the GPU).
+thread_local bool g_dry = false;
 uintptr_t g_fake_next = (uintptr_t)0x700000000000ull;  // far from anything the process maps
 std::atomic<int64_t> g_ranges{0};
 }  // namespace
@@ -169,15 +172,9 @@ int drain_deferred() {
 
 extern "C" {
 
-int pxm_version(void) { return 300; }  // 3.0: + pxm_noise_bits, pxm_wav_release_iter_counter; profile_read_launches takes a workgroup array
+int pxm_version(void) { return 400; }  // 4.0: PXM_NOISE_F64 launch flag, pxm_wav_status / pxm_sht_status / pxm_wav_flow_enabled
 
-int pxm_noise_bits(void) {
-#ifdef PXM_NOISE_F64  // (EXTRA=-DPXM_NOISE_F64: every translation unit of the build sees it, csrc/philox.h)
-  return 64;
-#else
-  return 32;
-#endif
-}
+int pxm_noise_bits(void) { return 32; }  // the DEFAULT of the stepping entry points; PXM_NOISE_F64 selects 64 per call
 
 int pxm_capture_begin(void) {
   std::lock_guard<std::mutex> lock(pxm::g_grave_mu);

@@ -16,7 +16,7 @@ __host__ __device__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32
   for (int r = 0; r < 10; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
     const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(__gfx950__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
     // three-input xor in one VALU operation (v_bitop3_b32, truth table 0x96): two instead of four per round
     const uint32_t n0 = __builtin_amdgcn_bitop3_b32((uint32_t)(p1 >> 32), c[1], k0, 0x96);
     const uint32_t n2 = __builtin_amdgcn_bitop3_b32((uint32_t)(p0 >> 32), c[3], k1, 0x96);
@@ -49,14 +49,18 @@ __device__ inline NormalPair box_muller_fast(double u1, double u2) {
   return NormalPair{(double)(r * __builtin_amdgcn_cosf(turns)), (double)(r * __builtin_amdgcn_sinf(turns))};
 }
 
-// The same transform in double precision (build switch -DPXM_NOISE_F64; pxm_noise_bits() reports which one a
-// library was built with, BASELINE.md gives the step time both ways): branch-free, no tables, ~75 fp64 instructions
-// per pair against ~20 for the f32 units (the math library's log + sincospi + sqrt cost five times that in the fused
-// DFT kernel).  Deviates agree with numpy's float64 evaluation of the same formulae to ~1e-15 (oracle/philox.py).
+// The same transform in double precision (launch-time switch PXM_NOISE_F64 of the stepping entry points, include/
+// pxmcmc_amd.h; BASELINE.md gives the step time both ways): branch-free, no tables, ~70 fp64 instructions per pair
+// against ~20 for the f32 units (the math library's log + sincospi + sqrt cost five times that in the fused DFT
+// kernel).  Deviates agree with numpy's float64 evaluation of the same formulae to ~1e-15 (oracle/philox.py).
 //   ln u1 = e ln 2 + 2 atanh(s), u1 = m 2^e with m in [sqrt(1/2), sqrt(2)), s = (m - 1) / (m + 1), |s| <= 0.172:
-//           ten terms of the odd series; the division by Newton iterations on v_rcp_f64 (the divisor lies in
-//           [1.7, 2.42): no scaling, no special cases);
-//   sqrt    by v_rsq_f64 + two coupled Newton steps (the argument -2 ln u1 lies in [1e-16, 75]);
+//           ten terms of the odd series; the division by ONE Newton iteration on v_rcp_f64 (the divisor lies in
+//           [1.7, 2.42): no scaling, no special cases) and a residual correction of the quotient;
+//   sqrt    by v_rsq_f64, one coupled Newton (Goldschmidt) step and one residual correction with the unrefined
+//           half-reciprocal (error = product of the two: far below an ulp).  u1 = (a + 1/2) 2^-53 rounds to exactly 1
+//           for a = 2^53 - 1: the argument -2 ln u1 is then -0.0, and rsq(-0.0) = -inf would turn the deviate into a
+//           NaN that poisons its chain for good (probability 2^-53 per pair) -- the argument is clamped to 1e-300
+//           (radius 1e-150: zero for every purpose; the f32 path and the oracle give 0 there);
 //   angle   2 pi u2 = k pi / 2 + a, k = rint(4 u2), |a| <= pi / 4: Taylor polynomials of sin / cos (nine terms each),
 //           quadrant by swapping and sign flips.
 __device__ inline NormalPair box_muller_f64(double u1, double u2) {
@@ -67,7 +71,6 @@ __device__ inline NormalPair box_muller_f64(double u1, double u2) {
   ex = lo ? ex - 1 : ex;
   const double num = m - 1.0, den = m + 1.0;
   double rc = __builtin_amdgcn_rcp(den);
-  rc = fma(fma(-den, rc, 1.0), rc, rc);
   rc = fma(fma(-den, rc, 1.0), rc, rc);
   double s = num * rc;
   s = fma(fma(-den, s, num), rc, s);
@@ -84,13 +87,13 @@ __device__ inline NormalPair box_muller_f64(double u1, double u2) {
   p = fma(p, z, 1.0);
   // -2 ln u1 = -2 e ln 2 - 4 s p  (ln 2 split so that e * hi is exact for |e| <= 54)
   const double e = (double)ex;
-  const double x = fma(e, -2.0 * 0.693147180369123816490, fma(-4.0 * s, p, e * (-2.0 * 1.90821492927058770002e-10)));
+  double x = fma(e, -2.0 * 0.693147180369123816490, fma(-4.0 * s, p, e * (-2.0 * 1.90821492927058770002e-10)));
+  x = fmax(x, 1e-300);  // u1 == 1.0: x = -0.0 (see above)
   double h = __builtin_amdgcn_rsq(x);
   double g = x * h;
   h *= 0.5;
-  double r = fma(-h, g, 0.5);
+  const double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
-  h = fma(h, r, h);
   g = fma(fma(-g, g, x), h, g);  // sqrt(x)
   const double t = 4.0 * u2;
   const double k = __builtin_rint(t);
@@ -112,14 +115,12 @@ __device__ inline NormalPair box_muller_f64(double u1, double u2) {
   return NormalPair{g * C, g * S};
 }
 
-#ifdef PXM_NOISE_F64
-#define PXM_NOISE_BITS 64
-#else
-#define PXM_NOISE_BITS 32
-#endif
-
+// The two Box-Muller evaluations above are selected per LAUNCH (flag PXM_NOISE_F64 of the stepping entry points): F64
+// as a template parameter where a kernel is instantiated per precision (the fused DFT epilogue: register budget), or the
+// run-time forms below behind a uniform branch (elementwise kernels).
 // two independent N(0,1) draws for counter (index, iter) under key (seed, chain)
-__device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter) {
+template <bool F64>
+__device__ inline NormalPair philox_normal_pair_t(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter) {
   const uint64_t key = seed + chain * 0x9E3779B97F4A7C15ull;
   uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)iter, (uint32_t)(iter >> 32)};
   philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
@@ -127,11 +128,11 @@ __device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, u
   const uint64_t b = (((uint64_t)c[3] << 32) | c[2]) >> 11;
   const double u1 = ((double)a + 0.5) * 0x1.0p-53;
   const double u2 = ((double)b + 0.5) * 0x1.0p-53;
-#ifdef PXM_NOISE_F64
-  return box_muller_f64(u1, u2);
-#else
+  if (F64) return box_muller_f64(u1, u2);
   return box_muller_fast(u1, u2);
-#endif
+}
+__device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter, bool f64 = false) {
+  return f64 ? philox_normal_pair_t<true>(seed, chain, index, iter) : philox_normal_pair_t<false>(seed, chain, index, iter);
 }
 
 // Real stream: chains come in pairs -- chain ch takes draw (ch & 1) of the Philox pair keyed by
@@ -139,11 +140,16 @@ __device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, u
 // a kernel that advances chains 2k and 2k+1 together (two real chains per complex slot, update.h) pays
 // one Philox + Box-Muller evaluation per two deviates.  Complex stream: element e of chain ch takes
 // the whole pair keyed (seed, ch).
-__device__ inline NormalPair philox_normal_chainpair(uint64_t seed, uint64_t pair, uint64_t e, uint64_t iter) {
-  return philox_normal_pair(seed + 0xD1B54A32D192ED03ull, pair, e, iter);
+constexpr uint64_t PXM_PAIR_TWEAK = 0xD1B54A32D192ED03ull;
+template <bool F64>
+__device__ inline NormalPair philox_normal_chainpair_t(uint64_t seed, uint64_t pair, uint64_t e, uint64_t iter) {
+  return philox_normal_pair_t<F64>(seed + PXM_PAIR_TWEAK, pair, e, iter);
 }
-__device__ inline double philox_normal_real(uint64_t seed, uint64_t chain, uint64_t e, uint64_t iter) {
-  const NormalPair p = philox_normal_chainpair(seed, chain >> 1, e, iter);
+__device__ inline NormalPair philox_normal_chainpair(uint64_t seed, uint64_t pair, uint64_t e, uint64_t iter, bool f64 = false) {
+  return philox_normal_pair(seed + PXM_PAIR_TWEAK, pair, e, iter, f64);
+}
+__device__ inline double philox_normal_real(uint64_t seed, uint64_t chain, uint64_t e, uint64_t iter, bool f64 = false) {
+  const NormalPair p = philox_normal_chainpair(seed, chain >> 1, e, iter, f64);
   return (chain & 1) ? p.z1 : p.z0;
 }
 

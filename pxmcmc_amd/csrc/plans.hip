@@ -188,7 +188,25 @@ struct pxm_sht_plan_s {
   double* ws = nullptr;  // [G | H | scratch]
   int64_t offG = 0, offH = 0, offS = 0;
   TaskList tl[4];
+  unsigned* d_status = nullptr;  // device status word of this plan (pxm_sht_status)
 };
+
+namespace pxm {
+// Device status word of a plan: kernels OR a bit in when a bounded wait expires (dft5.hip d5_pair_sync, sht_gemm.hip
+// k_sht_gemm_flow) instead of hanging the GPU; the host reads it wherever it synchronises anyway.
+static int status_alloc(unsigned** d) {
+  if (int rc = dev_alloc(d, 4 * sizeof(unsigned), "plan status word")) return rc;
+  return dev_zero(*d, 4 * sizeof(unsigned));
+}
+static int status_read(unsigned* d, hipStream_t st, int clear) {
+  if (!d) return 0;
+  unsigned h = 0;
+  PXM_HIP(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+  PXM_HIP(hipStreamSynchronize(st));
+  if (clear && h) PXM_HIP(hipMemsetAsync(d, 0, sizeof(unsigned), st));
+  return (int)(h & 0x7fffffffu);
+}
+}  // namespace pxm
 
 extern "C" {
 
@@ -214,6 +232,8 @@ int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht
   retain_tables(p->T);
   rc = make_dft_plan(L, &p->dft);
   if (rc) return rc;
+  if ((rc = status_alloc(&p->d_status))) return rc;
+  p->dft.d_status = p->d_status;
   const int64_t sz = arr_size(L, p->ncol);
   p->offG = 0;
   p->offH = sz;
@@ -237,6 +257,7 @@ int pxm_sht_plan_destroy(pxm_sht_plan_t p) {
   if (!p) return 0;
   free_dft_plan(&p->dft);
   deferred_free(p->ws);
+  deferred_free(p->d_status);
   for (int k = 0; k < 4; ++k) free_tasks(&p->tl[k]);
   release_tables(p->T);
   delete p;
@@ -295,6 +316,11 @@ int pxm_sht_forward(pxm_sht_plan_t p, const void* f, void* flm, int C, pxm_strea
 int pxm_sht_inverse_adjoint(pxm_sht_plan_t p, const void* f, void* flm, int C, pxm_stream_t s) {
   int rc = sht_check(p, f, flm, C, "pxm_sht_inverse_adjoint");
   return rc ? rc : sht_ring_to_el(p, TAB_INV_ADJ, f, flm, C, (hipStream_t)s);
+}
+
+int pxm_sht_status(pxm_sht_plan_t p, int clear, pxm_stream_t stream) {
+  PXM_REQUIRE(p, "pxm_sht_status: null plan");
+  return status_read(p->d_status, (hipStream_t)stream, clear);
 }
 
 int64_t pxm_sht_table_bytes(pxm_sht_plan_t p, int op) {
@@ -427,8 +453,9 @@ struct pxm_wav_plan_s {
   bool use_flow = false;
   TaskList flow;
   std::vector<GemmTask> h_adj_fwdadj;  // host copy of the forward-adjoint tasks (the flow list is built with the Gram list)
-  unsigned* d_flow_flags = nullptr;    // [L] per-m counters + [1] time-out flag
+  unsigned* d_flow_flags = nullptr;    // [L] per-m counters (the time-out flag is bit 0 of d_status)
   double flow_bytes = 0, flow_mfma = 0;
+  unsigned* d_status = nullptr;  // device status word of THIS plan: bit 0 dataflow wait, bit 1 DFT pair wait (pxm_wav_status)
   uint64_t* iter_dev = nullptr;  // device-resident Philox iteration counter of THIS plan (pxm_wav_set_iter_counter)
   Profiler prof;                 // live kernel timing of THIS plan (pxm_wav_profile_*)
 };
@@ -469,6 +496,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   }
   p->ncoefs = off;
   int rc;
+  if ((rc = status_alloc(&p->d_status))) return rc;
   // tables: every scale needs the forward pair (synthesis: FWD, its adjoint: FWD_ADJ) and, for the
   // analysis setting, the inverse pair at its own bandlimit; L needs all four.
   p->T.resize(p->nsc);
@@ -479,12 +507,14 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
     wav_hold(p, p->T[s]);
     rc = make_dft_plan(p->bl[s], &p->dft[s]);
     if (rc) return rc;
+    p->dft[s].d_status = p->d_status;  // (before the DFT group is built: its entries carry a copy)
   }
   rc = get_tables(L, 0, 0xF, &p->TL);
   if (rc) return rc;
   wav_hold(p, p->TL);
   rc = make_dft_plan(L, &p->dftL);
   if (rc) return rc;
+  p->dftL.d_status = p->d_status;
   // workspace
   int64_t w = 0;
   p->offGL = w; w += arr_size(L, p->ncol);
@@ -656,6 +686,7 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   deferred_free(p->d_kc_ana);
   deferred_free(p->d_wlk);
   deferred_free(p->d_flow_flags);
+  deferred_free(p->d_status);
   // (side streams / events belong to the per-device pool)
   TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj, &p->adj_invadj_R, &p->gram, &p->adj_invadj_D,
                      &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj, &p->wl_inv, &p->wl_invadj, &p->flow};
@@ -742,14 +773,23 @@ int64_t pxm_wav_workspace_nonfinite(pxm_wav_plan_t p, pxm_stream_t stream) {
   return (int64_t)h;
 }
 
-// 0: every wait of the dataflow launches of this plan was satisfied; 1: one timed out (results invalid); synchronises
+// bit mask of the bounded waits of this plan's kernels that EXPIRED since the last clear (0 = none): bit 0 a wait of
+// the dataflow GEMM launch, bit 1 a wave-pair wait of the fused phi-DFT kernels.  Synchronises the stream.
+int pxm_wav_status(pxm_wav_plan_t p, int clear, pxm_stream_t stream) {
+  PXM_REQUIRE(p, "pxm_wav_status: null plan");
+  return status_read(p->d_status, (hipStream_t)stream, clear);
+}
+// 0 / 1: the dataflow bit of pxm_wav_status (kept for callers of the round-3 interface); synchronises
 int pxm_wav_flow_status(pxm_wav_plan_t p, pxm_stream_t stream) {
   PXM_REQUIRE(p, "pxm_wav_flow_status: null plan");
-  if (!p->d_flow_flags) return 0;
-  unsigned h = 0;
-  PXM_HIP(hipMemcpyAsync(&h, p->d_flow_flags + p->L, sizeof(h), hipMemcpyDeviceToHost, (hipStream_t)stream));
-  PXM_HIP(hipStreamSynchronize((hipStream_t)stream));
-  return h ? 1 : 0;
+  const int st = status_read(p->d_status, (hipStream_t)stream, 0);
+  return st < 0 ? st : (st & PXM_STATUS_FLOW_WAIT_BIT ? 1 : 0);
+}
+// 1 when this plan's ring-space step takes the dataflow launch (PXM_FLOW=1 and every condition of wav_make_gram_lists
+// held), 0 otherwise -- known once pxm_wav_ring_set_data has run
+int pxm_wav_flow_enabled(pxm_wav_plan_t p) {
+  PXM_REQUIRE(p, "pxm_wav_flow_enabled: null plan");
+  return p->use_flow ? 1 : 0;
 }
 
 int pxm_tables_trim(void) {
@@ -952,7 +992,7 @@ int pxm_wav_gradg_step(pxm_wav_plan_t p, const void* X, const void* preds, const
   if (rc) return rc;
   PXM_REQUIRE(preds && data && invcov, "pxm_wav_gradg_step: null argument");
   PXM_REQUIRE(X != X_out, "pxm_wav_gradg_step: X_out must not alias X");
-  PXM_REQUIRE(mode >= 0 && mode <= 2, "pxm_wav_gradg_step: mode must be 0, 1 or 2");
+  PXM_REQUIRE((mode & ~PXM_NOISE_F64) >= 0 && (mode & ~PXM_NOISE_F64) <= 2, "pxm_wav_gradg_step: mode must be 0, 1 or 2 (| PXM_NOISE_F64)");
   PxIn in;
   in.f = (const double*)preds;
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
@@ -967,7 +1007,8 @@ int pxm_wav_gradg_step(pxm_wav_plan_t p, const void* X, const void* preds, const
   out.delta = delta;
   out.lmda = lmda;
   out.noise = (const double*)noise;
-  out.mode = mode;
+  out.mode = mode & ~PXM_NOISE_F64;
+  out.noise64 = (mode & PXM_NOISE_F64) ? 1 : 0;
   out.seed = seed;
   out.chain0 = chain0;
   out.iter = iter;
@@ -1009,7 +1050,7 @@ int pxm_wav_image_step(pxm_wav_plan_t p, const void* X, const void* data, const 
   if (rc) return rc;
   PXM_REQUIRE(data && invcov && preds_out, "pxm_wav_image_step: null argument");
   PXM_REQUIRE(X != X_out, "pxm_wav_image_step: X_out must not alias X");
-  PXM_REQUIRE(mode >= 0 && mode <= 2, "pxm_wav_image_step: mode must be 0, 1 or 2");
+  PXM_REQUIRE((mode & ~PXM_NOISE_F64) >= 0 && (mode & ~PXM_NOISE_F64) <= 2, "pxm_wav_image_step: mode must be 0, 1 or 2 (| PXM_NOISE_F64)");
   hipStream_t st = (hipStream_t)stream;
   PxOut out;
   out.f = (double*)X_out;
@@ -1019,7 +1060,8 @@ int pxm_wav_image_step(pxm_wav_plan_t p, const void* X, const void* data, const 
   out.delta = delta;
   out.lmda = lmda;
   out.noise = (const double*)noise;
-  out.mode = mode;
+  out.mode = mode & ~PXM_NOISE_F64;
+  out.noise64 = (mode & PXM_NOISE_F64) ? 1 : 0;
   out.seed = seed;
   out.chain0 = chain0;
   out.iter = iter;
@@ -1116,8 +1158,8 @@ static int wav_make_gram_lists(pxm_wav_plan_t p) {
       fl.insert(fl.end(), av.begin(), av.end());
       // (upload_tasks re-sorts by work: the list keeps its two parts because the order is forced to "flow")
       if ((rc = upload_tasks(fl, true, &p->flow, p->bl, p->ncol, p->ws, "dataflow Gram + forward-adjoint", {}, true))) return rc;
-      if ((rc = dev_alloc(&p->d_flow_flags, (size_t)(p->L + 1) * sizeof(unsigned), "dataflow counters"))) return rc;
-      if ((rc = dev_zero(p->d_flow_flags, (size_t)(p->L + 1) * sizeof(unsigned)))) return rc;
+      if ((rc = dev_alloc(&p->d_flow_flags, (size_t)p->L * sizeof(unsigned), "dataflow counters"))) return rc;
+      if ((rc = dev_zero(p->d_flow_flags, (size_t)p->L * sizeof(unsigned)))) return rc;
       p->use_flow = true;
     }
   }
@@ -1171,7 +1213,7 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
   if (rc) return rc;
   PXM_REQUIRE(p->have_data_rings, "pxm_wav_ring_step: call pxm_wav_ring_set_data first");
   PXM_REQUIRE(X != X_out, "pxm_wav_ring_step: X_out must not alias X");
-  PXM_REQUIRE(mode >= 0 && mode <= 2, "pxm_wav_ring_step: mode must be 0, 1 or 2");
+  PXM_REQUIRE((mode & ~PXM_NOISE_F64) >= 0 && (mode & ~PXM_NOISE_F64) <= 2, "pxm_wav_ring_step: mode must be 0, 1 or 2 (| PXM_NOISE_F64)");
   hipStream_t st = (hipStream_t)stream;
   if (p->use_gram) {
     // H' = w ((2L-1) B^T B H - B^T DFT(data)): inverse transform, ring residual and inverse-adjoint in one GEMM
@@ -1188,7 +1230,7 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
       rc = launch_gemm_flow(p->flow.d, p->flow.n, 2, p->ws, p->ws, p->ncol, ct,
                             tasklist_bytes(p->gram, cg) + tasklist_bytes(p->adj_fwdadj, cg),
                             (p->gram.mfma_units + p->adj_fwdadj.mfma_units) * ct * 2048.0, st, aff, p->d_flow_flags,
-                            p->d_flow_flags + p->L, &p->prof);
+                            p->d_status, &p->prof);
       if (rc) return rc;
     } else {
       if ((rc = run_tasks(p->gram, p->ws, p->ws, p->ncol, C, st, aff, &p->prof))) return rc;
@@ -1213,7 +1255,8 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
   out.delta = delta;
   out.lmda = lmda;
   out.noise = (const double*)noise;
-  out.mode = mode;
+  out.mode = mode & ~PXM_NOISE_F64;
+  out.noise64 = (mode & PXM_NOISE_F64) ? 1 : 0;
   out.seed = seed;
   out.chain0 = chain0;
   out.iter = iter;

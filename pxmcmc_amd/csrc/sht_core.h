@@ -210,7 +210,13 @@ struct DftPlan {
   // four waves per ring (dft5.hip, k_*6): M = 2048 = 4 x 512 for 256 < L <= 512 (default there)
   bool use6 = false;
   Dft6Tables t6;
+  // status word of the OWNING plan (set by the owner after make_dft_plan; null: expiries go unrecorded) and the bound
+  // of the wave-pair wait of the dft5 kernels (PXM_DEBUG_PAIR_SYNC_LIMIT, read at plan creation: 0 forces an expiry)
+  unsigned* d_status = nullptr;
+  unsigned spin_limit = 1u << 18;
 };
+// bits of a plan's status word (pxm_wav_status / pxm_sht_status)
+enum { PXM_STATUS_FLOW_WAIT_BIT = 1, PXM_STATUS_PAIR_SYNC_BIT = 2 };
 
 int make_dft_plan(int L, DftPlan* p);
 void free_dft_plan(DftPlan* p);
@@ -239,6 +245,7 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
   double T_scalar = 0, delta = 0, lmda = 0;
   const double* noise = nullptr;  // injected noise or null -> Philox
   int mode = 0;  // update.h: 0 complex state + real noise, 1 + complex noise, 2 two real chains per slot
+  int noise64 = 0;  // Box-Muller step of the Philox stream in double precision (flag PXM_NOISE_F64 of the entry points)
   uint64_t seed = 0, chain0 = 0, iter = 0;
   const uint64_t* iter_dev = nullptr;  // optional device-resident addend to iter (graph replay)
   // residual mode of the fused rings -> image -> rings kernel (X == null): the image is written to f and the rings

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm_flow(const GemmTask* __res
       unsigned spins = 0;
       while ((int)__hip_atomic_load(flags + wait_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_target) {
         if (++spins > (1u << 22)) {  // (~1 s: the producers of a live launch arrive within tens of microseconds)
-          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_or(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // PXM_STATUS_FLOW_WAIT
           break;
         }
         __builtin_amdgcn_s_sleep(8);

@@ -150,11 +150,12 @@ __device__ __forceinline__ double2 px_noise_load(const PxOut& o, int c, int64_t 
 // Philox noise of (slot c, element e) at iteration it.  Two real chains per slot whose first chain id is
 // even are exactly one chain pair of the real stream (philox.h): one Philox + Box-Muller evaluation
 // yields both deviates.  Every other case runs a rolled loop of 1 or 2 trips over one Philox body (no
-// extra registers in the DFT epilogues).
-__device__ __forceinline__ double2 px_noise_philox(const PxOut& o, int c, int64_t e, uint64_t it) {
+// extra registers in the DFT epilogues).  F64: the Box-Muller step in double precision (PxOut::noise64).
+template <bool F64>
+__device__ __forceinline__ double2 px_noise_philox_t(const PxOut& o, int c, int64_t e, uint64_t it) {
   const bool pairs = o.mode == PXM_MODE_REAL_PAIRS, cplx = o.mode == PXM_MODE_CPLX_NOISE;
   if (pairs && !(o.chain0 & 1)) {
-    const NormalPair q = philox_normal_chainpair(o.seed, (o.chain0 >> 1) + c, (uint64_t)e, it);
+    const NormalPair q = philox_normal_chainpair_t<F64>(o.seed, (o.chain0 >> 1) + c, (uint64_t)e, it);
     return double2{q.z0, q.z1};
   }
   const int nk = pairs ? 2 : 1;
@@ -162,8 +163,8 @@ __device__ __forceinline__ double2 px_noise_philox(const PxOut& o, int c, int64_
 #pragma nounroll
   for (int k = 0; k < nk; ++k) {
     const uint64_t chain = o.chain0 + (pairs ? 2 * c + k : c);
-    const NormalPair q = cplx ? philox_normal_pair(o.seed, chain, (uint64_t)e, it)
-                              : philox_normal_chainpair(o.seed, chain >> 1, (uint64_t)e, it);
+    const NormalPair q = cplx ? philox_normal_pair_t<F64>(o.seed, chain, (uint64_t)e, it)
+                              : philox_normal_chainpair_t<F64>(o.seed, chain >> 1, (uint64_t)e, it);
     const double v = (cplx || !(chain & 1)) ? q.z0 : q.z1;
     if (k == 0) {
       w.x = v;
@@ -173,6 +174,10 @@ __device__ __forceinline__ double2 px_noise_philox(const PxOut& o, int c, int64_
     }
   }
   return w;
+}
+// run-time form (kernels that are not instantiated per noise precision): one uniform branch
+__device__ __forceinline__ double2 px_noise_philox(const PxOut& o, int c, int64_t e, uint64_t it) {
+  return o.noise64 ? px_noise_philox_t<true>(o, c, e, it) : px_noise_philox_t<false>(o, c, e, it);
 }
 
 // X' = (1 - d/l) X + (d/l) soft(X, T) - d g + sqrt(2 d) w

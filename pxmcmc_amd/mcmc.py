@@ -12,6 +12,10 @@ Extensions (all optional, defaults reproduce the reference's one-chain behaviour
 * ``chain_offset`` -- global index of this process's first chain (multi-GPU sharding);
 * ``use_graph``    -- replay the fused iteration from a captured HIP graph (default on);
 * ``ring_shortcut`` -- with a scalar ``sig_d`` apply the residual on the ring transforms (default on);
+* ``noise_bits``   -- 32 (default) or 64: arithmetic of the Box-Muller step of the device Philox stream.  32 runs it
+  on the f32 transcendental units (deviates ~1e-6 relative, exact fp64 exponent: tail to 8.5 sigma); 64 evaluates log /
+  sqrt / sincos in double precision as the reference's ``np.random.randn`` does (pxmcmc/mcmc.py:193), ~7 % slower at the
+  benchmark size.  Same Philox counters and uniforms either way: the two streams agree to ~1e-6;
 * ``real_pairs``   -- with REAL data, a real start point and ``params.complex == False`` the reference's
   complex128 state has a zero imaginary part (every operator of the path maps real fields to real
   fields); the fused wavelet path then carries two real chains per complex slot -- chain 2c in the real
@@ -87,7 +91,7 @@ class PxMCMC:
     """
 
     def __init__(self, forward, prior, mcmcparams=PxMCMCParams(), nchains=1, rng="philox", seed=0, chain_offset=0,
-                 use_graph=True, ring_shortcut=True, real_pairs=True):
+                 use_graph=True, ring_shortcut=True, real_pairs=True, noise_bits=32):
         self.forward = forward
         self.prior = prior
         for attr in mcmcparams.__dict__.keys():
@@ -101,6 +105,10 @@ class PxMCMC:
         self.use_graph = bool(use_graph)
         self.ring_shortcut = bool(ring_shortcut)
         self.real_pairs = bool(real_pairs)
+        if noise_bits not in (32, 64):
+            raise ValueError("noise_bits must be 32 or 64")
+        self.noise_bits = int(noise_bits)
+        self.noise64 = self.noise_bits == 64
         self._pairs = False
         self.nsamples = int(self.nsamples)
         for op in (getattr(forward, "transform", None), getattr(forward, "measurement", None)):
@@ -227,6 +235,25 @@ class PxMCMC:
         if hasattr(self, "chain"):
             put(self.chain, X_curr)
 
+    # ---- device status -----------------------------------------------------------------
+    def _device_plans(self):
+        """every transform plan this sampler's operators launch kernels on"""
+        plans = []
+        tr, ms = getattr(self.forward, "transform", None), getattr(self.forward, "measurement", None)
+        for owner, names in ((tr, ("_plan",)), (ms, ("_sht0", "_sht2")), (self, ("_pair_plan",))):
+            for n in names:
+                pl = getattr(owner, n, None) if owner is not None else None
+                if pl is not None and hasattr(pl, "raise_on_fault") and getattr(pl, "_h", None):
+                    plans.append(pl)
+        return plans
+
+    def _check_device_status(self):
+        """Fail loudly (PxmError) if a kernel reported an expired bounded wait since the last check -- called where the
+        sampler synchronises with the device anyway: saved samples, progress prints, end of run (the reference raises
+        on bad state, pxmcmc/mcmc.py:104-109; a silently corrupted chain is not an outcome)."""
+        for pl in self._device_plans():
+            pl.raise_on_fault()
+
     # ---- noise ---------------------------------------------------------------------------
     def _host_noise(self, shape_like):
         """the reference's draw order: randn(N) [+ 1j randn(N)] per chain (pxmcmc/mcmc.py:193-195)."""
@@ -277,10 +304,11 @@ class MYULA(PxMCMC):
             noise = self._host_noise_pairs(X) if self.rng == "numpy" else None
             return self._pair_plan.gradg_step(
                 X, preds, self._pair_data, self.forward.invcov.diag, self.prior.T_dev, delta, self.lmda, noise=noise,
-                seed=self.seed, chain0=self.chain_offset, it=i, pairs=True,
+                seed=self.seed, chain0=self.chain_offset, it=i, pairs=True, noise64=self.noise64,
             )
         noise = self._host_noise(X) if self.rng == "numpy" else None
-        kw = dict(noise=noise, noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=i)
+        kw = dict(noise=noise, noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=i,
+                  noise64=self.noise64)
         if self._fused_wav:
             f = self.forward
             return f.transform._plan.gradg_step(
@@ -374,7 +402,8 @@ class MYULA(PxMCMC):
         eng["side"] = "A"  # which buffer holds the current state
         args = (data, f.invcov.diag, self.prior.T_dev, float(self.delta), self.lmda)
         # params.complex: randn + 1j randn (pxmcmc/mcmc.py:193-195) -> PXM_MODE_CPLX_NOISE in the fused epilogues
-        kw = dict(noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=0, pairs=self._pairs)
+        kw = dict(noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=0, pairs=self._pairs,
+                  noise64=self.noise64)
         # Uniform inverse covariance (scalar sig_d): the image-space residual is applied on the rings and the
         # L-level iDFT/DFT pair between forward() and calc_gradg() drops out (pxm_wav_ring_step); preds is
         # then materialised only when it is observed.
@@ -417,7 +446,8 @@ class MYULA(PxMCMC):
         eng["cnt"] = _DevCounter(i0)
         eng["cnt0"] = lambda i: i
         eng["reset"] = lambda: None
-        kw = dict(noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=0, iter_dev=eng["cnt"].t)
+        kw = dict(noise_complex=bool(self.complex), seed=self.seed, chain0=self.chain_offset, it=0, iter_dev=eng["cnt"].t,
+                  noise64=self.noise64)
         delta, lmda = float(self.delta), self.lmda
 
         def one(src, dst):
@@ -503,6 +533,9 @@ class MYULA(PxMCMC):
         if eng["ring"] and not eng["P_valid"]:  # forward(X) of the carried rings, on demand
             eng["plan"].ring_preds(eng["P"].shape[0], out=eng["P"])
             eng["P_valid"] = True
+        # observation point: the host is about to read the state -- an expired device wait since the last one raises
+        if eng.get("plan") is not None:
+            eng["plan"].raise_on_fault()
         X = eng["XA"] if eng["side"] == "A" else eng["XB"]
         if eng["pairs"]:
             return self._unpack(X), self._unpack(eng["P"])
@@ -543,6 +576,7 @@ class MYULA(PxMCMC):
             if i >= self.nburn:
                 if self.ngap == 0 or (i - self.nburn) % self.ngap == 0:
                     Xs, Ps = (self._unpack(X_curr), self._unpack(curr_preds)) if self._pairs else (X_curr, curr_preds)
+                    self._check_device_status()
                     logPi, L2, prior = self._logpi_dev(Xs, Ps)
                     self._tracking(j, Xs, Ps, logPi, L2, prior)
                     j += 1
@@ -555,6 +589,7 @@ class MYULA(PxMCMC):
             i += 1
         if self._pairs:
             X_curr, curr_preds = self._unpack(X_curr), self._unpack(curr_preds)
+        self._check_device_status()
         self.X_curr, self.curr_preds, self.niter = X_curr, curr_preds, i
         print("\nDONE")
 
@@ -583,6 +618,8 @@ class MYULA(PxMCMC):
                 X_curr, curr_preds = self._engine_state()
                 if i >= nburn:
                     if ngap == 0 or (i - nburn) % ngap == 0:
+                        if self._eng.get("plan") is None:  # generic engine: the operators' own plans
+                            self._check_device_status()
                         logPi, L2, prior = self._logpi_dev(X_curr, curr_preds)
                         self._tracking(j, X_curr, curr_preds, logPi, L2, prior)
                         j += 1
@@ -593,6 +630,7 @@ class MYULA(PxMCMC):
                     print("Burning in...")
                 i += 1
             X_curr, curr_preds = self._engine_state()
+            self._check_device_status()
             self.X_curr, self.curr_preds, self.niter = X_curr.clone(), curr_preds.clone(), i
             self.used_graph = self._eng["graph"] is not None
             self.graph_error = self._eng.get("graph_error")
@@ -613,7 +651,7 @@ class MYULA(PxMCMC):
             self._it = getattr(self, "_it", 0) + 1
         out = ops.chain_step(
             x, proxf, gradg, self.delta, self.lmda, noise=noise, noise_complex=bool(self.complex),
-            seed=self.seed, chain0=self.chain_offset, it=getattr(self, "_it", 0),
+            seed=self.seed, chain0=self.chain_offset, it=getattr(self, "_it", 0), noise64=self.noise64,
         )
         return out if isinstance(X, torch.Tensor) else out.cpu().numpy()
 
@@ -627,9 +665,13 @@ class PxMALA(MYULA):
 
     _CHUNK = 1024
 
-    def __init__(self, forward, prox, mcmcparams=PxMCMCParams(), tune_delta=True, **kwargs):
+    def __init__(self, forward, prox, mcmcparams=PxMCMCParams(), tune_delta=True, track_transitions=False, **kwargs):
         super().__init__(forward, prox, mcmcparams, **kwargs)
         self.tune_delta = tune_delta
+        # extension: keep both calc_logtransition values of every iteration in ``transitions_trace`` (a list of
+        # (q(X'|X), q(X|X')) complex128 [C] pairs; the static buffers of a graph replay are read after each replay)
+        self.track_transitions = bool(track_transitions)
+        self.transitions_trace = []
 
     def _l2_dev(self, preds):
         """L2 = vdot(d, invcov @ d) of a [C, ndata] prediction batch -> complex128 [C] (pxmcmc/mcmc.py:78-79)"""
@@ -691,12 +733,13 @@ class PxMALA(MYULA):
             noise = self._host_noise(X_curr) if host_rng else None
             if stock:
                 ops.pxmala_propose(X_curr, proxf_curr, gradg_curr, T_dev, w_prior, delta_dev, self.lmda, X_prop, proxf_prop,
-                                   lt_cp, prior_p, noise=noise, noise_complex=bool(self.complex), iter_dev=counter, **kw)
+                                   lt_cp, prior_p, noise=noise, noise_complex=bool(self.complex), iter_dev=counter,
+                                   noise64=self.noise64, **kw)
                 Xp, pxp, ltc, prp = X_prop, proxf_prop, lt_cp, prior_p
             else:  # user-supplied prior / chain_step: the reference's own sequence of calls (mcmc.py:231-242)
                 if type(self).chain_step is MYULA.chain_step:
                     Xp = ops.chain_step(X_curr, proxf_curr, gradg_curr, delta_dev, self.lmda, noise=noise,
-                                        noise_complex=bool(self.complex), **kw)
+                                        noise_complex=bool(self.complex), noise64=self.noise64, **kw)
                 else:
                     Xp = ops.as_device(self.chain_step(X_curr, proxf_curr, gradg_curr), dt)
                 pxp = ops.as_device(self.prior.proxf(Xp), dt)
@@ -709,6 +752,7 @@ class PxMALA(MYULA):
             gp = ops.as_device(self.forward.calc_gradg(pp), dt)
             L2p = self._l2_dev(pp)
             ltp = ops.logtransition(Xp, X_curr, pxp, gp, delta_dev, self.lmda)
+            self._last_transitions = (ltc, ltp)  # q(X'|X), q(X|X') of this iteration (pxmcmc/mcmc.py:240-241)
             u = np.array([np.random.rand() for _ in range(C)]) if host_rng else None
             ops.pxmala_accept2(ltp, ltc, prp, L2p, self.mu, logpiXc, L2Xc, priorXc, accept, delta_dev, self.tune_delta,
                                self.lmda, u=u, iter_dev=counter, acc_trace=acc_buf, delta_trace=delta_buf, **kw)
@@ -749,6 +793,8 @@ class PxMALA(MYULA):
                 graph.replay()
             else:
                 iteration(i, None)
+            if self.track_transitions:  # observation only (synchronises): both calc_logtransition values per iteration
+                self.transitions_trace.append(tuple(t.cpu().numpy().copy() for t in self._last_transitions))
             k = i % self._CHUNK
             if k == self._CHUNK - 1:
                 acc_chunks.append(acc_buf.cpu().numpy().copy())
@@ -760,6 +806,7 @@ class PxMALA(MYULA):
                 acc_h = accept.cpu().numpy()  # the only per-iteration host sync, on save candidates only
                 chains = [c for c in range(C) if acc_h[c] and j[c] < self.nsamples]
                 if chains:
+                    self._check_device_status()
                     self._tracking(j[chains] if C > 1 else int(j[0]), X_curr, curr_preds, logpiXc, L2Xc, priorXc,
                                    chains=chains if C > 1 else None)
                     j[chains] += 1
@@ -784,6 +831,7 @@ class PxMALA(MYULA):
             self.deltas_trace = del_all
         self.delta = float(delta_dev[0].item())
         self.delta_dev = delta_dev
+        self._check_device_status()
         self.X_curr, self.curr_preds, self.niter = X_curr, curr_preds, i
         print("\nDONE")
 

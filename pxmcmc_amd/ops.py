@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import check, lib, require_gpu
+from ._lib import NOISE_F64, STATUS_FLOW_WAIT, STATUS_PAIR_SYNC, PxmError, check, lib, require_gpu
 
 _CPLX, _REAL = torch.complex128, torch.float64
 
@@ -97,6 +97,25 @@ def residual_grad(preds, data, invcov):
     return out[0] if squeeze else out
 
 
+def _nf(noise64):
+    """PXM_NOISE_F64 flag of the noise-drawing entry points: the Philox stream's Box-Muller step in double precision"""
+    return NOISE_F64 if noise64 else 0
+
+
+def raise_on_status(status, what):
+    """A plan's device status word (pxm_wav_status / pxm_sht_status) -> PxmError when a bounded wait expired"""
+    if status:
+        bits = []
+        if status & STATUS_PAIR_SYNC:
+            bits.append("a wave-pair wait of the fused phi-DFT kernels expired (csrc/dft5.hip, d5_pair_sync)")
+        if status & STATUS_FLOW_WAIT:
+            bits.append("a wait of the dataflow GEMM launch expired (PXM_FLOW=1)")
+        if status & ~(STATUS_PAIR_SYNC | STATUS_FLOW_WAIT):
+            bits.append(f"unknown status bits {status:#x}")
+        raise PxmError(f"{what}: device status {status:#x}: " + "; ".join(bits) + " -- the results of this plan since its last "
+                       "status check are invalid")
+
+
 def _delta_args(delta, C_, dev):
     if isinstance(delta, torch.Tensor):
         dd = delta.to(device=dev, dtype=_REAL).contiguous()
@@ -129,7 +148,8 @@ def _noise_args(noise, x, noise_complex):
     return w, int(w.is_complex())
 
 
-def myula_step(X, gradg, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None, out=None):
+def myula_step(X, gradg, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None, out=None,
+               noise64=False):
     """chain_step(X, soft(X, T), gradg) in one pass (pxmcmc/mcmc.py:185-201 + prior.py:49-50).
     iter_dev: int64 device counter added to ``it`` when the kernel runs (graph replay); out: result buffer."""
     x, squeeze = _batched(as_device(X))
@@ -142,7 +162,7 @@ def myula_step(X, gradg, T, delta, lmda, noise=None, noise_complex=False, seed=0
     out = torch.empty_like(x) if out is None else _out_like(out, x)
     check(
         lib.pxm_myula_step_it(
-            _p(x), _p(g), _p(Tv), Ts, _p(dd), ds, float(lmda), _p(w), wc, seed, chain0, it, _p(iter_dev), _p(out), x.shape[1],
+            _p(x), _p(g), _p(Tv), Ts, _p(dd), ds, float(lmda), _p(w), wc | _nf(noise64), seed, chain0, it, _p(iter_dev), _p(out), x.shape[1],
             x.shape[0], _dt(x), _stream()
         )
     )
@@ -156,7 +176,8 @@ def _out_like(out, x):
     return o
 
 
-def chain_step(X, proxf, gradg, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None, out=None):
+def chain_step(X, proxf, gradg, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None, out=None,
+               noise64=False):
     """MYULA.chain_step (pxmcmc/mcmc.py:185-201); iter_dev / out as in :func:`myula_step`."""
     x, squeeze = _batched(as_device(X))
     px, _ = _batched(as_device(proxf, x.dtype))
@@ -168,17 +189,28 @@ def chain_step(X, proxf, gradg, delta, lmda, noise=None, noise_complex=False, se
     out = torch.empty_like(x) if out is None else _out_like(out, x)
     check(
         lib.pxm_chain_step_it(
-            _p(x), _p(px), _p(g), _p(dd), ds, float(lmda), _p(w), wc, seed, chain0, it, _p(iter_dev), _p(out), x.shape[1],
+            _p(x), _p(px), _p(g), _p(dd), ds, float(lmda), _p(w), wc | _nf(noise64), seed, chain0, it, _p(iter_dev), _p(out), x.shape[1],
             x.shape[0], _dt(x), _stream()
         )
     )
     return out[0] if squeeze else out
 
 
-def randn(n, C_=1, complex_=False, seed=0, chain0=0, it=0):
+def randn(n, C_=1, complex_=False, seed=0, chain0=0, it=0, noise64=False):
+    """N(0,1) draws of the device Philox stream keyed (seed, chain0 + c, it); noise64: Box-Muller in double precision"""
     out = torch.empty((C_, n), dtype=_CPLX if complex_ else _REAL, device=device())
-    check(lib.pxm_randn(_p(out), n, C_, int(complex_), seed, chain0, it, _stream()))
+    check(lib.pxm_randn(_p(out), n, C_, int(complex_) | _nf(noise64), seed, chain0, it, _stream()))
     return out
+
+
+def box_muller(u1, u2, noise64=False):
+    """the Box-Muller step of the device noise stream on given uniforms (test aid, include/pxmcmc_amd.h) -> (z0, z1)"""
+    a, b = as_device(u1, _REAL).reshape(-1), as_device(u2, _REAL).reshape(-1)
+    if a.shape != b.shape:
+        raise ValueError("box_muller: u1 and u2 must have the same length")
+    z0, z1 = torch.empty_like(a), torch.empty_like(a)
+    check(lib.pxm_box_muller(_p(a), _p(b), _p(z0), _p(z1), a.numel(), int(bool(noise64)), _stream()))
+    return z0, z1
 
 
 def _red_scratch(C_, dev):
@@ -246,7 +278,7 @@ def pxmala_accept(terms, delta_dev, tune, lmda, it_index, u=None, seed=0, chain0
 
 
 def pxmala_propose(X, proxf, gradg, T, prior_weights, delta_dev, lmda, Xp, proxf_p, lt_out, prior_out, noise=None,
-                   noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None):
+                   noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None, noise64=False):
     """chain_step + soft + calc_logtransition(X, X') + prior(X') in one pass; writes into the given buffers
     (Xp, proxf_p [C, n]; lt_out complex128 [C]; prior_out float64 [C])."""
     x, _ = _batched(X)
@@ -256,7 +288,7 @@ def pxmala_propose(X, proxf, gradg, T, prior_weights, delta_dev, lmda, Xp, proxf
     scratch = torch.empty(4 * int(lib.pxm_reduce_scratch_doubles(x.shape[0])), dtype=_REAL, device=x.device)
     check(
         lib.pxm_pxmala_propose(
-            _p(x), _p(proxf), _p(gradg), _p(Tv), Ts, _p(wp), _p(delta_dev), float(lmda), _p(w), wc, seed, chain0, int(it),
+            _p(x), _p(proxf), _p(gradg), _p(Tv), Ts, _p(wp), _p(delta_dev), float(lmda), _p(w), wc | _nf(noise64), seed, chain0, int(it),
             _p(iter_dev), _p(Xp), _p(proxf_p), _p(lt_out), _p(prior_out), _p(scratch), x.shape[1], x.shape[0], _dt(x), _stream(),
         )
     )
@@ -382,6 +414,13 @@ class ShtPlan:
     def table_bytes(self, op):
         return int(lib.pxm_sht_table_bytes(self._h, op))
 
+    def status(self, clear=False):
+        """bit mask of the bounded device waits of this plan that expired (0 = none); synchronises"""
+        return int(check(lib.pxm_sht_status(self._h, int(bool(clear)), _stream())))
+
+    def raise_on_fault(self):
+        raise_on_status(self.status(clear=True), f"ShtPlan(L={self.L}, spin={self.spin})")
+
 
 class WavPlan:
     """Axisymmetric scale-discretised wavelet transforms (replaces the pys2let calls)."""
@@ -429,7 +468,7 @@ class WavPlan:
         return self._run(lib.pxm_wav_analysis_adjoint, X, self.ncoefs, self.npix)
 
     def gradg_step(self, X, preds, data, invcov, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, out=None,
-                   pairs=False):
+                   pairs=False, noise64=False):
         """Fused calc_gradg + proxf + chain_step (pxmcmc/mcmc.py:158-160) for the synthesis setting.
         ``pairs``: every complex slot of X carries two real chains (PXM_MODE_REAL_PAIRS)."""
         x, squeeze = _batched(as_device(X, _CPLX))
@@ -449,7 +488,7 @@ class WavPlan:
         check(
             lib.pxm_wav_gradg_step(
                 self._h, _p(x), _p(p), _p(d), _p(ic), int(ic.is_complex()), _p(Tv), Ts, float(delta), float(lmda),
-                _p(w), wc, seed, chain0, it, _p(out), x.shape[0], _stream(),
+                _p(w), wc | _nf(noise64), seed, chain0, it, _p(out), x.shape[0], _stream(),
             )
         )
         return out[0] if squeeze else out
@@ -470,7 +509,7 @@ class WavPlan:
         check(lib.pxm_wav_image_init(self._h, _p(p), _p(d), _p(ic), int(ic.is_complex()), p.shape[0], _stream()))
 
     def image_step(self, X, data, invcov, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0,
-                   out=None, preds_out=None, pairs=False):
+                   out=None, preds_out=None, pairs=False, noise64=False):
         """calc_gradg + proxf + chain_step + forward of the new state; the residual rings of the current state come
         from the previous ``image_step`` / ``image_init`` on this plan."""
         x, squeeze = _batched(as_device(X, _CPLX))
@@ -490,7 +529,7 @@ class WavPlan:
         check(
             lib.pxm_wav_image_step(
                 self._h, _p(x), _p(d), _p(ic), int(ic.is_complex()), _p(Tv), Ts, float(delta), float(lmda),
-                _p(w), wc, seed, chain0, it, _p(out), _p(preds_out), x.shape[0], _stream(),
+                _p(w), wc | _nf(noise64), seed, chain0, it, _p(out), _p(preds_out), x.shape[0], _stream(),
             )
         )
         return (out[0], preds_out[0]) if squeeze else (out, preds_out)
@@ -508,7 +547,8 @@ class WavPlan:
             raise AssertionError("ring_init: shape mismatch")
         check(lib.pxm_wav_ring_init(self._h, _p(x), x.shape[0], _stream()))
 
-    def ring_step(self, X, w, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, out=None, pairs=False):
+    def ring_step(self, X, w, T, delta, lmda, noise=None, noise_complex=False, seed=0, chain0=0, it=0, out=None, pairs=False,
+                  noise64=False):
         """calc_gradg + proxf + chain_step + forward for a uniform inverse covariance ``w``; the rings of the
         new state stay inside the plan (``ring_preds`` materialises forward(X) when it is observed)."""
         x, squeeze = _batched(as_device(X, _CPLX))
@@ -523,7 +563,7 @@ class WavPlan:
         w = complex(w)
         check(
             lib.pxm_wav_ring_step(
-                self._h, _p(x), w.real, w.imag, _p(Tv), Ts, float(delta), float(lmda), _p(wn), wc, seed, chain0, it,
+                self._h, _p(x), w.real, w.imag, _p(Tv), Ts, float(delta), float(lmda), _p(wn), wc | _nf(noise64), seed, chain0, it,
                 _p(out), x.shape[0], _stream(),
             )
         )
@@ -541,6 +581,18 @@ class WavPlan:
     def flow_status(self):
         """0: every wait of the dataflow GEMM launches of this plan was satisfied (include/pxmcmc_amd.h); synchronises"""
         return int(check(lib.pxm_wav_flow_status(self._h, _stream())))
+
+    def flow_enabled(self):
+        """True when the ring-space step of this plan takes the dataflow launch (PXM_FLOW=1; known after ring_set_data)"""
+        return bool(check(lib.pxm_wav_flow_enabled(self._h)))
+
+    def status(self, clear=False):
+        """bit mask of the bounded device waits of this plan that expired (0 = none; include/pxmcmc_amd.h); synchronises"""
+        return int(check(lib.pxm_wav_status(self._h, int(bool(clear)), _stream())))
+
+    def raise_on_fault(self):
+        """raise PxmError if a kernel of this plan reported an expired wait since the last check (clears the word)"""
+        raise_on_status(self.status(clear=True), f"WavPlan(L={self.L})")
 
     # ---- weak-lensing measurement fused with the synthesis (pxm_wav_wl_*) ----
     def wl_attach(self, pix2data, weight, ndata):
@@ -661,7 +713,8 @@ def tables_trim():
 
 
 def noise_bits():
-    """32 or 64: precision of the Box-Muller step of the device noise stream in the loaded library"""
+    """32: the DEFAULT precision of the Box-Muller step of the device noise stream; every noise-drawing call takes
+    ``noise64=True`` for the double-precision evaluation (PXM_NOISE_F64, include/pxmcmc_amd.h)"""
     return int(lib.pxm_noise_bits())
 
 

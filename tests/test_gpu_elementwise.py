@@ -146,8 +146,8 @@ def test_philox_stream_matches_oracle():
     n, seed, it = 4097, 12345, 77
     r = _np(ops.randn(n, C_=3, complex_=False, seed=seed, chain0=10, it=it))
     c = _np(ops.randn(n, C_=2, complex_=True, seed=seed, chain0=4, it=it))
-    # the Box-Muller step of the loaded library: f32 transcendental units (default build, mirrored in float32: the
-    # hardware units differ from numpy's by a few float ulps) or the fp64 evaluation (-DPXM_NOISE_F64: 1e-13)
+    # the DEFAULT Box-Muller step: f32 transcendental units, mirrored in float32 (the hardware units differ from numpy's
+    # by a few float ulps); the fp64 evaluation (flag PXM_NOISE_F64 of the call) is pinned at 1e-13 in test_gpu_round4.py
     bits = ops.noise_bits()
     atol = 2e-5 if bits == 32 else 1e-13
     for k in range(3):

@@ -494,3 +494,179 @@ def test_weaklensing_wavelet_operator_fused_matches_composition_and_oracle(L, ma
     go = oop.calc_gradg(fo)
     assert np.abs(f_fused[0] - fo).max() < 1e-10 * np.abs(fo).max()
     assert np.abs(g_fused[0] - go).max() < 1e-9 * np.abs(go).max()
+
+
+# ---- (vi) the kernels BASELINE configs[4] really runs: the fused wavelet + weak-lensing operator at L = 512 -----------
+def test_config5_fused_weaklensing_operator_closed_form_L512():
+    """ForwardOperator(SphericalWaveletTransform, WeakLensing) at L = 512, B = 2, J_min = 2 with a mask and galaxy counts
+    -- `pxm_wav_wl_forward` / `pxm_wav_wl_adjoint` (harmonic kernel as the operand scale of the spin-2 inverse GEMM, mask
+    gather / scatter + covariance weight + residual in the four-wave DFT functors) -- against the DEFINITION of the
+    composed operator (pxmcmc/forward.py:63-72, transforms.py:114-139, measurements.py:221-240) on inputs whose image is
+    known in closed form.  A coefficient block holding one harmonic on its own MW grid, X_j = a Y_lm, has synthesis
+    coefficients a c_j kappa_j(l) delta_lm (exact quadrature), so
+        forward(X) = mask . inv_cov . a c_j kappa_j(l) k_l  2Y_lm(theta, phi),   k_l = -sqrt((l+2)(l-1)/((l+1)l)), 0 for l < 2,
+    with 2Y_lm from the eigen route (oracle.wigner.spin_harmonic_literal: no recursion in l, no table shared with the
+    product).  calc_gradg = A^H (invcov .* (preds - data)) is pinned through literal inner products with the same closed
+    forms: <A X, r> == <X, A^H r> for each probe X, with A X from the formula (never from the GPU).  Two chains."""
+    from oracle import pxmcmc_np as ref
+    from oracle import s2let, ssht, wigner
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    L, B, J_min, C = 512, 2, 2, 2
+    rng = np.random.default_rng(5512)
+    bls = s2let.bandlimits(B, L, J_min)
+    k0, kap = s2let.tiling_axisym(B, L, J_min)
+    rows = [k0] + [kap[j] for j in range(J_min, kap.shape[0])]
+    c_syn = [1.0] + [s2let.C_SYNTHESIS] * (len(bls) - 1)
+    offs = np.concatenate([[0], np.cumsum([bl * (2 * bl - 1) for bl in bls])])
+    kl = ref.wl_harmonic_kernel(L)  # measurements.py:151-160 (pinned by golden G7); entries l < 2 are zeroed by the mapping
+    thL, phL = ssht.sample_positions(L)
+    theta = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+    mask = np.ones((L, 2 * L - 1), dtype=int)
+    mask[np.abs(90 - np.degrees(theta)) < 10] = 0
+    mask[:, 300:420] = 0
+    ngal = rng.integers(1, 40, size=mask.shape).astype(float)
+    wl = WeakLensing(L, mask=mask, ngal=ngal, max_chains=C)
+    owl = ref.WeakLensing(L, mask=mask, ngal=ngal)  # (only its mask / inv_cov bookkeeping is used: no oracle SHT at this size)
+    np.testing.assert_allclose(wl.inv_cov, owl.inv_cov, rtol=1e-15)
+    tr = SphericalWaveletTransform(L, B, J_min, max_chains=C)
+    assert tr.ncoefs == offs[-1] == 1221796
+    data = rng.normal(size=wl.ndata) + 1j * rng.normal(size=wl.ndata)
+    op = ForwardOperator(data, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+    assert op._wl_plan() is not None and op.invcov.diag.is_complex()  # complex-variance rule (forward.py:81-82)
+    # (block, l, m): scaling function incl. a degree the kernel annihilates (l = 1), small / middle / both top scales, l = 511
+    cases = [(0, 1, 1), (0, 3, -2), (1, 5, -3), (4, 40, 17), (6, 200, -150), (7, 300, 299), (7, 400, 0), (8, 500, -499),
+             (8, 511, 511), (8, 511, -2)]
+    mflat = owl.mask.ravel()
+
+    def closed_form(i, el, m, a):
+        """(X block contribution, forward image in data space)"""
+        bl = bls[i]
+        assert el < bl and rows[i][el] != 0.0, (i, el)
+        th, ph = ssht.sample_positions(bl)
+        xb = a * wigner.spin_harmonic_literal(el, m, 0, th, ph).ravel()
+        if el < 2:
+            return xb, np.zeros(wl.ndata, dtype=complex)
+        y2 = wigner.spin_harmonic_literal(el, m, 2, thL, phL).ravel()
+        return xb, (a * c_syn[i] * rows[i][el] * kl[el * el + el + m]) * y2[mflat] * owl.inv_cov
+
+    X = np.zeros((C, offs[-1]), dtype=complex)
+    want = np.zeros((C, wl.ndata), dtype=complex)
+    probes = []
+    for i, el, m in cases:
+        for c in range(C):
+            a = complex(rng.normal(), rng.normal())
+            xb, img = closed_form(i, el, m, a)
+            X[c, offs[i] : offs[i + 1]] += xb
+            want[c] += img
+            if c == 0:
+                probes.append((i, xb, img))
+    got = op.forward(X)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() < 1e-11 * scale, np.abs(got - want).max() / scale
+    # l = 1 alone must vanish exactly up to round-off of the other terms' scale
+    X1 = np.zeros(offs[-1], dtype=complex)
+    X1[offs[0] : offs[1]] = closed_form(0, 1, 1, 1.0)[0]
+    assert np.abs(op.forward(X1)).max() < 1e-12 * np.abs(X1).max() * np.abs(owl.inv_cov).max()
+    # calc_gradg: A^H r with r = invcov .* (preds - data); <A X_probe, r> from the closed form == <X_probe, gradg>
+    preds = rng.normal(size=(C, wl.ndata)) + 1j * rng.normal(size=(C, wl.ndata))
+    gradg = op.calc_gradg(preds)
+    icv = ref.invcov_diag(data, 1 / owl.inv_cov)  # forward.py:74-88 restated (pinned by golden G3)
+    np.testing.assert_allclose(op.invcov.diagonal(), icv, rtol=1e-14)
+    for c in range(C):
+        r = icv * (preds[c] - data)
+        rn = np.linalg.norm(r)
+        for i, xb, img in probes:
+            lhs = np.vdot(img, r)                                  # <A X, r>, A X literal
+            rhs = np.vdot(xb, gradg[c, offs[i] : offs[i + 1]])     # <X, A^H r>, A^H on the GPU
+            gb = gradg[c, offs[i] : offs[i + 1]]
+            tol = 1e-10 * max(abs(lhs), 1e-3 * np.linalg.norm(img) * rn) + 1e-12 * np.linalg.norm(xb) * np.linalg.norm(gb)
+            assert abs(lhs - rhs) < tol, (c, i, abs(lhs - rhs), abs(lhs))
+    # the unfused composition (separate pxm_wav_synthesis / pxm_sht_* / pxm_wl_* kernels) gives the same numbers
+    op.fuse_weaklensing = False
+    assert op._wl_plan() is None
+    comp = op.forward(X[0])
+    assert np.abs(comp - want[0]).max() < 1e-11 * scale
+    g_comp = op.calc_gradg(preds[0])
+    assert np.abs(g_comp - gradg[0]).max() < 1e-10 * np.abs(g_comp).max()
+
+
+def test_config5_pxmala_trajectory_matches_oracle_L272():
+    """A PxMALA trajectory on the KERNEL PATH of BASELINE configs[4] -- bandlimit above 256 (four-wave phi-DFT at M = 2048),
+    unpaired spin-2 ring tables, the fused wavelet + weak-lensing operator with a mask and galaxy counts, the one-pass
+    `pxm_pxmala_propose` / `pxm_pxmala_accept2` kernels, two chains -- against oracle.pxmcmc_np.pxmala_run
+    (pxmcmc/mcmc.py:218-289) on the same injected normals and uniforms, iteration by iteration: the acceptance trace, the
+    per-chain delta adaptation, BOTH calc_logtransition values of every iteration (the literal squared sum over
+    ~350 k complex terms, mcmc.py:281-289: where a reduction-order difference would flip an accept), the saved samples
+    and their logPi / L2 / prior.  delta_0 = 1e-9 gives accepts and rejects within the first iterations (probed with the
+    oracle).  L = 272 is the largest size the fast oracle finishes in a minute; L = 512 is covered in closed form above."""
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    L, B, J_min, C = 272, 2, 2, 2
+    lmda, delta0, mu = 5e-7, 1e-9, 1.0
+    rng = np.random.default_rng(272)
+    theta = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+    mask = np.ones((L, 2 * L - 1), dtype=int)
+    mask[np.abs(90 - np.degrees(theta)) < 10] = 0
+    mask[:, L // 3 : L // 2] = 0
+    ngal = rng.integers(1, 40, size=mask.shape).astype(float)
+    wl = WeakLensing(L, mask=mask, ngal=ngal, max_chains=C)
+    tr = SphericalWaveletTransform(L, B, J_min, max_chains=C)
+    N = tr.ncoefs
+    T = ref.SphericalWaveletTransform(L, B, J_min)
+    owl = ref.WeakLensing(L, mask=mask, ngal=ngal)
+    # data = forward(truth) + noise, made with the ORACLE operator (the GPU operator never sees its own output as data)
+    Xtrue = rng.normal(size=N) * 0.01
+    o0 = ref.ForwardOperator(np.zeros(owl.ndata, dtype=complex), 1 / owl.inv_cov, "synthesis", T, owl, N)
+    data = o0.forward(Xtrue.astype(complex)) + (rng.normal(size=owl.ndata) + 1j * rng.normal(size=owl.ndata))
+    op = ForwardOperator(data, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=N)
+    oop = ref.ForwardOperator(data, 1 / owl.inv_cov, "synthesis", T, owl, N)
+    reg = S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, lmda * mu, L=L, B=B, J_min=J_min)
+    oreg = ref.S2_Wavelets_L1("synthesis", None, None, lmda * mu, L, B, J_min)
+    X0 = rng.normal(size=(C, N)) * 1e-3
+    nburn, K = 3, 8
+    p = PxMCMCParams(lmda=lmda, delta=delta0, mu=mu, nsamples=1, nburn=nburn, ngap=1, verbosity=0,
+                     track=["logposterior", "L2", "prior", "chain"])
+    s = PxMALA(op, reg, p, tune_delta=True, nchains=C, rng="numpy", track_transitions=True)
+    assert op._wl_plan() is not None
+    np.random.seed(2720)
+    _quiet(s.run, start_point=X0)
+    niter = s.niter
+    assert nburn + 1 <= niter <= 200, niter  # (a run of hundreds of rejections would mean the set-up has drifted)
+    # the same draws in the sampler's order: per iteration randn(N) for chain 0, chain 1, then rand() for chain 0, chain 1
+    np.random.seed(2720)
+    nz, un = np.zeros((niter, C, N)), np.zeros((niter, C))
+    for i in range(niter):
+        for c in range(C):
+            nz[i, c] = np.random.randn(N)
+        for c in range(C):
+            un[i, c] = np.random.rand()
+    Kc = min(K, niter)
+    acc = np.asarray(s.acceptance_trace)
+    dl = np.asarray(s.deltas_trace)
+    assert acc.shape == (niter, C) and dl.shape == (niter + 1, C) and len(s.transitions_trace) == niter
+    seen = set()
+    for c in range(C):
+        out = ref.pxmala_run(oop, oreg, lmda, delta0, mu, 10 ** 6, nburn, 1, X0[c].astype(complex), lambda i: nz[i, c],
+                             lambda i: un[i, c], tune=True, max_iter=Kc)
+        assert list(acc[:Kc, c]) == list(out["acceptance_trace"]), (c, acc[:Kc, c], out["acceptance_trace"])
+        seen.update(int(a) for a in out["acceptance_trace"])
+        np.testing.assert_allclose(dl[: Kc + 1, c], out["deltas_trace"], rtol=1e-12)
+        for i in range(Kc):
+            lt_cp, lt_pc = s.transitions_trace[i][0][c], s.transitions_trace[i][1][c]
+            assert abs(lt_cp - out["lt_cp"][i]) <= 1e-9 * abs(out["lt_cp"][i]), (c, i, lt_cp, out["lt_cp"][i])
+            assert abs(lt_pc - out["lt_pc"][i]) <= 1e-9 * abs(out["lt_pc"][i]), (c, i, lt_pc, out["lt_pc"][i])
+        # the sample this chain saved: its first accepted iteration at i >= nburn, if that fell inside the oracle's K
+        if len(out["chain"]):
+            np.testing.assert_allclose(s.chain[c, 0], out["chain"][0], rtol=0, atol=1e-9 * np.abs(out["chain"][0]).max())
+            np.testing.assert_allclose(s.logPi[c, 0], np.real(out["logPi"][0]), rtol=1e-9)
+            np.testing.assert_allclose(s.L2s[c, 0], np.real(out["L2s"][0]), rtol=1e-9)
+            np.testing.assert_allclose(s.priors[c, 0], out["priors"][0], rtol=1e-10)
+    assert seen == {0, 1}, "the compared iterations should hold accepted AND rejected proposals"

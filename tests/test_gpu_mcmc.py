@@ -675,7 +675,8 @@ def test_dataflow_gemm_launch_equals_two_launches(L, C, monkeypatch):
             for k in range(K):
                 plan.ring_step(X, complex(4.0, 0.0), T, 1e-4, 2e-3, noise=ops.as_device(noise[k]), out=out, pairs=pairs)
                 X, out = out, X
-            assert plan.flow_status() == 0
+            assert plan.flow_status() == 0 and plan.status() == 0
+            assert plan.flow_enabled() == (flow == "1")  # (the comparison below is k_sht_gemm_flow against the two launches)
             res[(flow, pairs)] = (X.cpu().numpy(), plan.ring_preds(X.shape[0]).cpu().numpy())
     for pairs in (True, False):
         np.testing.assert_array_equal(res[("1", pairs)][0], res[("0", pairs)][0])
