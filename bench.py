@@ -54,12 +54,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 
 MFMA_SUSTAINED_TFLOPS = 47.1  # fp64 MFMA-only loop on this part (scripts/mfma_rate.hip; spec 78.6)
 
 
-def synthetic_field(plan_inverse, L, seed):
-    """random real band-limited field, C_l ~ (1+l)^-2, unit RMS."""
+def synthetic_field(plan_inverse, L, seed, slope=-1.0):
+    """random real band-limited field, amplitude (1+l)^slope (C_l ~ (1+l)^-2 at slope -1), unit RMS."""
     rng = np.random.default_rng(seed)
     flm = np.zeros(L * L, dtype=complex)
     for el in range(L):
-        amp = (1.0 + el) ** -1.0
+        amp = (1.0 + el) ** slope
         flm[el * el + el] = amp * rng.normal()
         m = np.arange(1, el + 1)
         v = amp * (rng.normal(size=el) + 1j * rng.normal(size=el)) / np.sqrt(2)
@@ -144,7 +144,8 @@ def self_launch(n, argv):
 NOISE_NOTES = {
     32: "philox4x32-10 counter stream, Box-Muller on the f32 transcendental units (v_log_f32 / v_sin_f32 / v_cos_f32, exact "
         "fp64 exponent: deviates ~1e-6 relative, tail to 8.5 sigma); the reference draws fp64 randn (pxmcmc/mcmc.py:193)",
-    64: "philox4x32-10 counter stream, Box-Muller in fp64 (log / sincospi / sqrt in double)",
+    64: "philox4x32-10 counter stream, Box-Muller in fp64 (branch-free log / sqrt / sincos polynomials in double, 1e-15 vs numpy: "
+        "flag PXM_NOISE_F64 of the stepping calls, MYULA(noise_bits=64))",
 }
 
 NOMINAL_S_NORM2 = 1.35e4  # ||S||^2 at L=256, B=2, J_min=2 (power iteration on the GPU at start-up: checked below)
@@ -219,12 +220,11 @@ def parity_leg(plan, data, T_dev, T, delta, n_iter=3, chains=(0, 9), C=CHAINS_PE
     return err
 
 
-def live_traffic(timeout_s=120):
-    """HBM bytes per k_sht_gemm launch of the timed steps, measured NOW: two child runs of this script under
+def pmc_passes(child_args, timeout_s=150):
+    """HBM bytes per k_sht_gemm launch class, measured NOW: two child runs of this script (``child_args``) under
     ``rocprofv3 --pmc`` (FETCH_SIZE, then WRITE_SIZE: separate passes, MI355X_MICROARCH.md section HBM), started before
     this process touches the GPU.  KiB units; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads
-    (doubled here), WRITE_SIZE is taken as is.  Returns (bytes per launch, description, per-launch-class list) or
-    (None, reason, None)."""
+    (doubled here), WRITE_SIZE is taken as is.  Returns ({(kernel, workgroups): {...}}, seconds) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -234,13 +234,12 @@ def live_traffic(timeout_s=120):
 
     rocprof = shutil.which("rocprofv3")
     if not rocprof:
-        return None, "rocprofv3 not on PATH", None
+        return None, "rocprofv3 not on PATH"
     vals = {}
     t0 = time.perf_counter()
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pxm_pmc_", dir="/tmp")
-        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "10", "--warmup", "2", "--ramp", "0", "--no-cpu-baseline", "--no-layout-compare", "--no-live-traffic"]
+        cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + child_args
         # own session: on a timeout the whole group (rocprofv3 AND the profiled python) is killed and waited for
         # before this process goes near the GPU
         proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
@@ -253,40 +252,251 @@ def live_traffic(timeout_s=120):
             proc.wait()
             time.sleep(1.0)
             shutil.rmtree(d, ignore_errors=True)
-            return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s", None
+            return None, f"rocprofv3 --pmc {counter} pass exceeded {timeout_s} s"
         files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
         per = {}
         if rc == 0 and files:
             with open(files[0]) as fh:
                 for row in csv.DictReader(fh):
-                    # every ring-GEMM launch, keyed by launch class = (kernel variant, workgroups): the child's steps
-                    # launch the same three classes as the timed region (Gram, forward-adjoint group, forward group);
-                    # the set-up launches of other variants / grids are dropped when the classes are joined below
+                    # every ring-GEMM launch, keyed by launch class = (kernel variant, workgroups)
                     if row["Counter_Name"] == counter and row["Kernel_Name"].startswith("void pxm::k_sht_gemm<"):
                         wgs = int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1)
                         per.setdefault((row["Kernel_Name"].split("(")[0], wgs), []).append(float(row["Counter_Value"]))
         shutil.rmtree(d, ignore_errors=True)
         if not per:
-            return None, f"rocprofv3 --pmc {counter} pass gave no k_sht_gemm records (exit {rc})", None
+            return None, f"rocprofv3 --pmc {counter} pass gave no k_sht_gemm records (exit {rc})"
         vals[counter] = per
-    # classes of the stepping loop: the ones launched (almost) once per step of the 12-step child
-    steps_seen = 10
     classes = {}
     for key, rd_list in vals["FETCH_SIZE"].items():
         wr_list = vals["WRITE_SIZE"].get(key)
-        if wr_list is None or len(rd_list) < steps_seen:
+        if wr_list is None:
             continue
         rd = 2 * 1024 * sum(rd_list) / len(rd_list)
         wr = 1024 * sum(wr_list) / len(wr_list)
         classes[key] = {"kernel": key[0].replace("void pxm::", ""), "workgroups": key[1], "launches": len(rd_list),
                         "read_MB": rd / 1e6, "write_MB": wr / 1e6, "hbm_MB": (rd + wr) / 1e6}
+    return classes, time.perf_counter() - t0
+
+
+def live_traffic(timeout_s=120):
+    """PMC traffic of the timed iteration's k_sht_gemm launches: child passes of the headline step with --steps 10.
+    Returns (bytes per launch, description, per-launch-class list) or (None, reason, None)."""
+    classes, info = pmc_passes(["--steps", "10", "--warmup", "2", "--ramp", "0", "--no-cpu-baseline", "--no-layout-compare",
+                                "--no-live-traffic", "--no-config-legs"], timeout_s)
+    if classes is None:
+        return None, info, None
+    # classes of the stepping loop: the ones launched (almost) once per step of the 12-step child
+    classes = {k: c for k, c in classes.items() if c["launches"] >= 10}
     if not classes:
         return None, "rocprofv3 --pmc passes gave no per-step k_sht_gemm launch class", None
     n = sum(c["launches"] for c in classes.values())
     total = sum(c["hbm_MB"] * c["launches"] for c in classes.values()) * 1e6 / n
     return total, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command with --steps 10 "
                    f"({n} k_sht_gemm launches of {len(classes)} per-step launch classes, FETCH_SIZE x2 gfx950 correction, "
-                   f"{time.perf_counter() - t0:.0f} s)"), sorted(classes.values(), key=lambda c: c["workgroups"])
+                   f"{info:.0f} s)"), sorted(classes.values(), key=lambda c: c["workgroups"])
+
+
+# ---- side legs: BASELINE configs[1] (L=64 topography, 1 chain) and configs[4] (L=512 weak lensing, PxMALA, 1 chain) ----
+C2_L, C2_B, C2_JMIN = 64, 1.5, 2      # experiments/earthtopography/main.py:72-74
+C5_L, C5_B, C5_JMIN = 512, 2, 2       # experiments/weaklensing/main.py:85-87
+C5_DELTA0, C5_NGAL = 1e-6, 30.0       # SURVEY.md section 8d C5 (main.py:92: ngal = 30)
+
+
+def launch_classes(plan, cap):
+    """ring-GEMM launch classes of the launches bracketed since profile_enable: (workgroups, algorithmic bytes) -> avg us"""
+    l_ms, l_bytes, l_wgs = plan.profile_read_launches(cap)
+    out = []
+    for wgs, nbytes in sorted(set(zip(l_wgs.tolist(), np.round(l_bytes).tolist()))):
+        sel = (l_wgs == wgs) & (np.round(l_bytes) == nbytes)
+        us = float(l_ms[sel].mean() * 1e3)
+        out.append({"workgroups": int(wgs), "alg_MB": nbytes / 1e6, "launches": int(sel.sum()), "avg_us": us,
+                    "alg_GBs": nbytes / us / 1e3, "alg_frac": nbytes / us / 1e3 / HBM_PEAK_GBS})
+    return out
+
+
+def join_pmc(classes, pmc):
+    """PMC bytes of the child passes onto the event-timed launch classes (key: workgroup count) -> measured HBM rate"""
+    by_wgs = {}
+    for c in (pmc or {}).values():
+        by_wgs.setdefault(c["workgroups"], []).append(c)
+    for g in classes:
+        cs = by_wgs.get(g["workgroups"])
+        if cs:
+            n = sum(c["launches"] for c in cs)
+            mb = sum(c["hbm_MB"] * c["launches"] for c in cs) / n
+            g.update(pmc_MB=mb, pmc_over_alg=mb / g["alg_MB"], hbm_GBs=mb / g["avg_us"] * 1e3,
+                     hbm_frac=mb / g["avg_us"] * 1e3 / HBM_PEAK_GBS)
+    return classes
+
+
+def config2_problem():
+    """BASELINE configs[1]: L=64, B=1.5, J_min=2, one chain, complex data as the reference's alm2map_mw returns it
+    (experiments/earthtopography/main.py:82 => complex-variance rule, forward.py:81-82), C_l ~ (1+l)^-2."""
+    from pxmcmc_amd import ops
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    sht = ops.ShtPlan(C2_L, 0, max_chains=1)
+    truth, rng = synthetic_field(lambda flm: sht.inverse(flm).cpu().numpy(), C2_L, seed=1, slope=-2.0)
+    del sht
+    data = (truth + SIGMA * rng.normal(size=truth.size)).astype(complex)
+    op = SphericalWaveletTransformOperator(data, SIGMA, "synthesis", C2_L, C2_B, C2_JMIN, max_chains=1)
+    reg = S2_Wavelets_L1("synthesis", op.transform.inverse, op.transform.inverse_adjoint, LMDA * MU, L=C2_L, B=C2_B, J_min=C2_JMIN)
+    delta, _ = stable_delta(op.transform, SIGMA, LMDA)
+    params = PxMCMCParams(lmda=LMDA, delta=delta, mu=MU, nsamples=1, nburn=0, ngap=1, verbosity=0)
+    s = MYULA(op, reg, params, nchains=1, rng="philox", seed=1)
+    s._prepare()
+    with contextlib.redirect_stdout(io.StringIO()):
+        X, preds = s._initial_sample(np.zeros(op.nparams))
+    return s, X, preds
+
+
+def config2_leg(steps=400, warm=100, n_prof=50, pmc=None):
+    import torch
+
+    s, X, preds = config2_problem()
+    assert s._fused_wav and not s._pairs_ok(X)
+    eng = s._engine_start(X, preds, 0)
+    s._engine_advance(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    s._engine_advance(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    plan = eng["plan"]
+    graphs = eng["graph"], eng["graph_long"]
+    plan.profile_enable(3 * n_prof + 8)
+    eng["graph"] = eng["graph_long"] = None
+    s._engine_advance(n_prof)
+    eng["graph"], eng["graph_long"] = graphs
+    torch.cuda.synchronize()
+    classes = join_pmc(launch_classes(plan, 3 * n_prof + 8), pmc)
+    plan.profile_enable(0)
+    Xs, _ = s._engine_state()
+    finite = bool(torch.isfinite(Xs.real).all())
+    s._engine_stop()
+    return {"workload": f"MYULA, wavelet synthesis L={C2_L} B={C2_B} J_min={C2_JMIN} (N=28390, P=8128), identity measurement, 1 chain, "
+                        "complex data (reference-literal: complex-variance rule), ring-space + Gram step, HIP graph",
+            "iterations": steps, "ms_per_iteration": dt / steps * 1e3, "samples_per_s": steps / dt, "finite": finite,
+            "gemm_launch_classes": classes}
+
+
+def config5_mask(L):
+    """equatorial band |90 deg - theta| < 10 deg plus a great-circle band tilted by 60 deg (the
+    stand-in for utils.build_mask's galactic + ecliptic cuts, pxmcmc/utils.py:320-349)"""
+    theta = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+    phi = 2 * np.pi * np.arange(2 * L - 1) / (2 * L - 1)
+    st, ct = np.sin(theta)[:, None], np.cos(theta)[:, None]
+    x, y, z = st * np.cos(phi)[None, :], st * np.sin(phi)[None, :], ct * np.ones_like(phi)[None, :]
+    t = np.radians(60.0)
+    lat2 = np.degrees(np.arcsin(np.clip(np.cos(t) * z + np.sin(t) * y, -1, 1)))  # latitude about the tilted pole
+    mask = np.ones((L, 2 * L - 1), dtype=int)
+    mask[np.abs(90 - np.degrees(theta)) < 10, :] = 0
+    mask[np.abs(lat2) < 10] = 0
+    return mask
+
+
+def config5_problem():
+    """BASELINE configs[4] on one GPU: L=512 weak-lensing shear operator + wavelet synthesis, one chain"""
+    import torch
+
+    from pxmcmc_amd import ops
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    L = C5_L
+    rng = np.random.default_rng(3)
+    tr = SphericalWaveletTransform(L, C5_B, C5_JMIN, max_chains=1)
+    mask = config5_mask(L)
+    wl = WeakLensing(L, mask, ngal=np.full(mask.shape, C5_NGAL), max_chains=1)
+    # convergence: Gaussian flm with C_l ~ (1+l)^-1.5 exp(-(l/200)^2), klm[:4] = 0 (SURVEY C5), real field
+    flm = np.zeros(L * L, dtype=complex)
+    for el in range(2, L):
+        amp = np.sqrt((1.0 + el) ** -1.5 * np.exp(-((el / 200.0) ** 2)))
+        flm[el * el + el] = amp * rng.normal()
+        m = np.arange(1, el + 1)
+        v = amp * (rng.normal(size=el) + 1j * rng.normal(size=el)) / np.sqrt(2)
+        flm[el * el + el + m] = v
+        flm[el * el + el - m] = (-1.0) ** m * np.conj(v)
+    kappa = wl._sht0.inverse(flm)
+    kappa = kappa / kappa.abs().max() * 0.05
+    gamma = wl.forward(kappa)  # covariance-weighted shear: unit-variance noise in these units
+    data = gamma.cpu().numpy() + (rng.normal(size=wl.ndata) + 1j * rng.normal(size=wl.ndata)) / np.sqrt(2)
+    op = ForwardOperator(data, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+    lmda = C5_DELTA0 / 2
+    reg = S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, lmda * MU, L=L, B=C5_B, J_min=C5_JMIN)
+    del torch, ops
+    return op, reg, tr, wl, lmda
+
+
+def config5_operator_loop(op, nrep, seed=0):
+    """nrep x (forward, calc_gradg) of the fused wavelet + weak-lensing operator: the four ring GEMMs of a PxMALA iteration"""
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    Xd = torch.randn(1, op.nparams, dtype=torch.float64, generator=g).cuda() * 1e-3
+    for _ in range(nrep):
+        op.calc_gradg(op.forward(Xd))
+    torch.cuda.synchronize()
+
+
+def config5_leg(n_short=20, n_long=120, nrep=10, pmc=None):
+    import torch
+
+    from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams
+
+    t_setup = time.perf_counter()
+    op, reg, tr, wl, lmda = config5_problem()
+    plan = op._wl_plan()
+    assert plan is not None
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+    times, acc, used_graph, finite = {}, None, None, True
+    for n in (n_short, n_long):  # two runs of different length: the difference is free of set-up and graph capture
+        p = PxMCMCParams(nsamples=1, nburn=10 ** 9, ngap=1, delta=C5_DELTA0, lmda=lmda, mu=MU, verbosity=0, track=[])
+        s = PxMALA(op, reg, p, tune_delta=True, nchains=1, seed=3, max_iter=n)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with contextlib.redirect_stdout(io.StringIO()):
+            s.run(start_point=np.zeros(tr.ncoefs))
+        torch.cuda.synchronize()
+        times[n] = time.perf_counter() - t0
+        assert s.niter == n
+        acc, used_graph = float(np.mean(s.acceptance_trace)), bool(s.used_graph)
+        finite = finite and bool(torch.isfinite(s.X_curr.real).all())
+    ms_iter = (times[n_long] - times[n_short]) / (n_long - n_short) * 1e3
+    plan.profile_enable(4 * nrep + 8)
+    config5_operator_loop(op, nrep)
+    classes = join_pmc(launch_classes(plan, 4 * nrep + 8), pmc)
+    plan.profile_enable(0)
+    gemm_us = sum(c["avg_us"] * c["launches"] for c in classes) / nrep
+    return {"workload": f"PxMALA (tune_delta), wavelet synthesis L={C5_L} B={C5_B} J_min={C5_JMIN} (N=1221796) + weak-lensing shear "
+                        f"measurement with a mask ({wl.ndata} of {wl.npix} pixels kept) and ngal = {C5_NGAL:.0f}, 1 chain, fused operator, "
+                        "one-pass propose / accept kernels, HIP graph",
+            "iterations": n_long - n_short, "ms_per_iteration": ms_iter, "samples_per_s": 1e3 / ms_iter,
+            "acceptance": acc, "hip_graph": used_graph, "finite": finite, "setup_s": t_setup,
+            "ring_gemm_us_per_iteration": gemm_us, "gemm_launch_classes": classes,
+            "note": "four ring GEMMs per iteration (two spin-0 group launches on the 8 + 1 wavelet scales, two spin-2 launches on "
+                    "unpaired tables) stream ~4.2 GB of tables for 2 live MFMA columns: the bound is the table stream"}
+
+
+def pmc_child(which):
+    """body of the rocprofv3 --pmc child passes of the side legs: the same launches, a few of each, nothing printed"""
+    import torch
+
+    if "config2" in which:
+        s, X, preds = config2_problem()
+        s.use_graph = False
+        s._engine_start(X, preds, 0)
+        s._engine_advance(12)
+        torch.cuda.synchronize()
+        s._engine_stop()
+    if "config5" in which:
+        op, *_ = config5_problem()
+        config5_operator_loop(op, 6)
 
 
 def main():
@@ -301,7 +511,13 @@ def main():
     ap.add_argument("--no-real-pairs", action="store_true", help="one complex128 slot per chain (reference layout)")
     ap.add_argument("--no-layout-compare", action="store_true", help="skip the reference-layout side measurement")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/pmc_summary.json instead of two rocprofv3 --pmc child passes")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the side legs of BASELINE configs[1] (L=64) and configs[4] (L=512 weak lensing)")
+    ap.add_argument("--no-f64-noise-leg", action="store_true", help="skip the second timing with the fp64 Box-Muller (value_f64_noise)")
+    ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # internal: body of the side legs' rocprofv3 --pmc passes
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args.pmc_child)
+        return
 
     # --gpus N > 1 without a torchrun environment: this process has not imported torch nor touched the GPU -- it
     # starts the N ranks as a CHILD torchrun (never an exec), lets rank 0's JSON line through on the inherited
@@ -314,8 +530,13 @@ def main():
     single = int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus == 1
     cpu = cpu_legs(args) if single and not args.no_cpu_baseline else None
     live = (None, None, None)
+    legs_pmc, legs_pmc_note = None, "not collected"
     if single and not args.no_live_traffic and not args.no_cpu_baseline:
         live = live_traffic()
+        if not args.no_config_legs:
+            legs_pmc, info = pmc_passes(["--pmc-child", "config2,config5"], timeout_s=200)
+            legs_pmc_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of the side legs' launches in this run ({info:.0f} s), "
+                             "joined on the workgroup count") if legs_pmc is not None else f"child passes failed: {info}"
 
     import torch
     import torch.distributed as dist
@@ -449,6 +670,54 @@ def main():
         ref_layout_rate = C * args.steps / (time.perf_counter() - t1)
         s2._engine_stop()
 
+    # The same timed region with the STRICTLY fp64 noise stream (flag PXM_NOISE_F64: Box-Muller's log / sqrt / sincos in
+    # double precision, as the reference's np.random.randn, pxmcmc/mcmc.py:193): same library, same run, same counts.
+    f64_leg = None
+    if rank == 0 and world == 1 and not args.no_f64_noise_leg:
+        s3 = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain,
+                   real_pairs=not args.no_real_pairs, noise_bits=64)
+        s3._prepare()
+        with contextlib.redirect_stdout(io.StringIO()):
+            X3, P3 = s3._initial_sample(np.zeros(op.nparams))
+        if s3._pairs_ok(X3):
+            s3._pairs_start()
+        e3 = s3._engine_start(X3, P3, 0)
+        s3._engine_advance(untimed)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        s3._engine_advance(args.steps)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t1
+        p3 = e3["plan"]
+        p3.profile_enable(3 * n_prof + 8)
+        g3 = e3["graph"], e3["graph_long"]
+        e3["graph"] = e3["graph_long"] = None
+        s3._engine_advance(n_prof)
+        e3["graph"], e3["graph_long"] = g3
+        torch.cuda.synchronize()
+        _, (d3ms, d3n, _) = p3.profile_read()
+        p3.profile_enable(0)
+        X3, _ = s3._engine_state()
+        assert bool(torch.isfinite(X3.real).all())
+        s3._engine_stop()
+        f64_leg = {"value": C * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
+                   "dft_kernel_avg_launch_us": d3ms * 1e3 / max(d3n, 1), "noise": NOISE_NOTES[64],
+                   "what": "the timed region repeated with MYULA(noise_bits=64): same library, same run, same warm-up and step counts"}
+        del s3, e3, p3
+
+    config_legs = None
+    if rank == 0 and world == 1 and not args.no_config_legs:
+        sampler._engine_stop()
+        config_legs = {"pmc_source": legs_pmc_note}
+        for name, fn in (("configs[1]", config2_leg), ("configs[4]", config5_leg)):
+            t1 = time.perf_counter()
+            try:
+                config_legs[name] = fn(pmc=legs_pmc)
+            except Exception as exc:  # a side leg must never take the headline down with it
+                config_legs[name] = {"error": repr(exc)}
+            config_legs[name]["leg_wall_s"] = time.perf_counter() - t1
+            ops.tables_trim()
+
     if rank == 0:
         value = world * C * args.steps / dt
         gemm_avg_us = ms.value * 1e3 / max(nl.value, 1)
@@ -510,8 +779,13 @@ def main():
                 "graph_iterations_per_replay": 2 * sampler._GRAPH_PAIRS if used_graph else 0,
                 "warmup_requested": args.warmup,
                 "clock_ramp_steps": args.ramp,
-                "noise": NOISE_NOTES.get(ops.noise_bits(), "unknown"),
+                    "noise": NOISE_NOTES.get(ops.noise_bits(), "unknown"),
             },
+            # the strictly-fp64 headline: the same region with the fp64 Box-Muller (null when the leg was skipped)
+            "value_f64_noise": f64_leg["value"] if f64_leg else None,
+            "f64_noise": f64_leg,
+            # BASELINE configs[1] and configs[4] on this GPU, outside the headline's timed region
+            "configs": config_legs,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_sht_gemm (SHT ring-table GEMM, v_mfma_f64_16x16x4_f64)",

@@ -665,9 +665,13 @@ class PxMALA(MYULA):
 
     _CHUNK = 1024
 
-    def __init__(self, forward, prox, mcmcparams=PxMCMCParams(), tune_delta=True, track_transitions=False, **kwargs):
+    def __init__(self, forward, prox, mcmcparams=PxMCMCParams(), tune_delta=True, track_transitions=False, max_iter=None,
+                 **kwargs):
         super().__init__(forward, prox, mcmcparams, **kwargs)
         self.tune_delta = tune_delta
+        # extension: stop after this many iterations even if fewer than nsamples were saved (the reference's loop,
+        # pxmcmc/mcmc.py:230, only ends on accepted samples: a chain that stops accepting never returns)
+        self.max_iter = None if max_iter is None else int(max_iter)
         # extension: keep both calc_logtransition values of every iteration in ``transitions_trace`` (a list of
         # (q(X'|X), q(X|X')) complex128 [C] pairs; the static buffers of a graph replay are read after each replay)
         self.track_transitions = bool(track_transitions)
@@ -788,7 +792,7 @@ class PxMALA(MYULA):
 
         i = 0
         n_acc = 0
-        while j.min() < self.nsamples:
+        while j.min() < self.nsamples and (self.max_iter is None or i < self.max_iter):
             if graph is not None:
                 graph.replay()
             else:
