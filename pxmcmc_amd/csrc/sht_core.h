@@ -37,7 +37,7 @@ struct GemmTask {
   int64_t x_off[4];    // operand slab offsets (doubles)
   int64_t y_off[4];    // output slab offsets
   int64_t x2_off[4];   // optional second operand (same layout) added to the first while staging; 0 = none
-  int64_t hd_off[4];   // affine epilogue: per-row complex constant of each slab (columns 0,1 of an H-layout array)
+  int64_t hd_off[4];   // affine epilogue: per-row complex constant of each slab: (re, im) at hd_off + row * hd_stride
   int64_t ks_off[2];   // per group: optional per-k scale vector (indexed by absolute k) relative to the base; 0 = none
   int64_t rs_off[2];   // per group: optional per-output-row scale vector (absolute row); 0 = none
   int row_lo[2], row_hi[2];  // per group: only output rows in [row_lo, row_hi) are written
@@ -51,6 +51,8 @@ struct GemmTask {
   // increments when its rows are stored (-1 = none); ignored by the ordinary launches
   int variant, wait_idx, wait_target, signal_idx;
   int m_unit;          // the order this task belongs to: m (paired tables: m >= 0 serves +-m) or m + L - 1
+  int hd_stride;       // doubles between consecutive rows of the affine constants: 2 = the chain-less [m][row] complex
+                       // array of the Gram step (whole 64-B segments per wave), ncol = columns 0, 1 of an H-layout array
 };
 
 // affine epilogue of the Gram launch: out = w * (ns * acc - hd[row]) as a complex product per chain
@@ -96,7 +98,8 @@ struct GemmFuse {
   int64_t x2_base = -1;           // second operand array (same L / Rp as x), -1 = none
   const double* rscale = nullptr;  // per-output-row scale
   int row_lo = 0, row_hi = 1 << 30;
-  int64_t hd_base = -1;            // H-layout array holding the affine constants (chain 0), -1 = none
+  int64_t hd_base = -1;            // array holding the affine constants, -1 = none ...
+  int hd_stride = 0;               // ... and its row stride in doubles (0: H layout, ncol doubles per row, chain 0)
 };
 
 struct ShtTables {

@@ -284,7 +284,7 @@ __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks
     for (int sl = 0; sl < NSLAB; ++sl)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        hdv[r][sl][q] = (aff.on && t.hd_off[sl]) ? (X + t.hd_off[sl])[(int64_t)(rowb + 4 * q) * ncol + (cl & 1)] : 0.0;
+        hdv[r][sl][q] = (aff.on && t.hd_off[sl]) ? (X + t.hd_off[sl])[(int64_t)(rowb + 4 * q) * t.hd_stride + (cl & 1)] : 0.0;
 #pragma unroll
     for (int g = 0; g < NGRP; ++g)
 #pragma unroll
@@ -494,7 +494,8 @@ int check_gemm_task_ranges(const std::vector<GemmTask>& v, int nslab, int flags,
           return bad(ti, "operand scale vector", col0);
         // epilogue: rows row0 + 16 tile + kq + 4 q, tile <= n_rt - 1 (a tile the wave does not own: tile 0)
         const int64_t r_lo = t.row0, r_hi = t.row0 + 16 * t.n_rt - 1;
-        if (t.hd_off[slab] && !ok(t.hd_off[slab] + r_lo * ncol, t.hd_off[slab] + r_hi * ncol + 1))
+        // affine constants: (X + hd_off[slab])[(row) hd_stride + (cl & 1)]
+        if (t.hd_off[slab] && !ok(t.hd_off[slab] + r_lo * t.hd_stride, t.hd_off[slab] + r_hi * t.hd_stride + 1))
           return bad(ti, "affine data term", col0);
         if (t.rs_off[slab >> 1] && !ok(t.rs_off[slab >> 1] + r_lo, t.rs_off[slab >> 1] + r_hi))
           return bad(ti, "per-row output scale", col0);
@@ -598,9 +599,10 @@ static void fill_side(GemmTask& g, int grp, const ShtTables& T, int kind, int m,
     g.x2_off[s1] = (T.paired && m != 0) ? sd.fuse.x2_base + (int64_t)(-m + sd.x_L - 1) * sd.x_Rp * ncol : g.x2_off[s0];
   }
   g.hd_off[s0] = g.hd_off[s1] = 0;
+  g.hd_stride = sd.fuse.hd_stride > 0 ? sd.fuse.hd_stride : ncol;
   if (sd.fuse.hd_base >= 0) {
-    g.hd_off[s0] = sd.fuse.hd_base + (int64_t)(m + sd.y_L - 1) * sd.y_Rp * ncol;
-    g.hd_off[s1] = (T.paired && m != 0) ? sd.fuse.hd_base + (int64_t)(-m + sd.y_L - 1) * sd.y_Rp * ncol : g.hd_off[s0];
+    g.hd_off[s0] = sd.fuse.hd_base + (int64_t)(m + sd.y_L - 1) * sd.y_Rp * g.hd_stride;
+    g.hd_off[s1] = (T.paired && m != 0) ? sd.fuse.hd_base + (int64_t)(-m + sd.y_L - 1) * sd.y_Rp * g.hd_stride : g.hd_off[s0];
   }
   (void)kind;
 }

@@ -63,14 +63,16 @@ def test_box_muller_edge_cases_both_precisions():
     z0, z1 = [_np(z) for z in ops.box_muller(U1, U2, noise64=True)]
     assert np.isfinite(z0).all() and np.isfinite(z1).all()
     # numpy's cos / sin of 2 pi u2 carry the rounding of the product 2 pi u2 (up to 4e-16 in the angle at u2 ~ 1)
-    np.testing.assert_allclose(z0, want0, rtol=0, atol=2e-15 * np.maximum(rad, 1) + 1e-100)
-    np.testing.assert_allclose(z1, want1, rtol=0, atol=2e-15 * np.maximum(rad, 1) + 1e-100)
+    tol = 2e-15 * np.maximum(rad, 1) + 1e-100
+    assert (np.abs(z0 - want0) <= tol).all(), (np.abs(z0 - want0) / tol).max()
+    assert (np.abs(z1 - want1) <= tol).all(), (np.abs(z1 - want1) / tol).max()
     assert np.abs(z0[U1 == 1.0]).max() < 1e-100 and np.abs(z1[U1 == 1.0]).max() < 1e-100
     assert abs(np.hypot(z0, z1)[U1 == tiny].max() - np.sqrt(-2 * np.log(tiny))) < 1e-13  # 8.6 sigma reachable
     f0, f1 = [_np(z) for z in ops.box_muller(U1, U2, noise64=False)]
     assert np.isfinite(f0).all() and np.isfinite(f1).all()
-    np.testing.assert_allclose(f0, want0, rtol=0, atol=3e-6 * np.maximum(rad, 1))
-    np.testing.assert_allclose(f1, want1, rtol=0, atol=3e-6 * np.maximum(rad, 1))
+    tol = 3e-6 * np.maximum(rad, 1)
+    assert (np.abs(f0 - want0) <= tol).all(), (np.abs(f0 - want0) / tol).max()
+    assert (np.abs(f1 - want1) <= tol).all(), (np.abs(f1 - want1) / tol).max()
 
 
 def test_fp64_noise_moments_and_tails():
@@ -286,8 +288,9 @@ def test_pys2let_pyssht_shim_call_shapes_match_oracle():
         np.testing.assert_allclose(shim.forward_adjoint(fl, L, Spin=spin), ssht.forward_adjoint(fl, L, spin), rtol=0, atol=1e-11)
         assert shim.inverse(fl, L, Spin=spin).shape == (L, 2 * L - 1) and shim.forward(img, L, Spin=spin).shape == (L * L,)
     # the reference's property tests through the shim (tests/test_transforms.py:16-46): round trip and dot test
-    back = shim.synthesis_wav2px(*shim.analysis_px2wav(f, **params), **params)
-    np.testing.assert_allclose(back, f, rtol=0, atol=1e-11 * np.abs(f).max())
+    fb = ssht.inverse(flm, L, 0).ravel()  # (a band-limited image, as the reference's fixture: tests/conftest.py:34-44)
+    back = shim.synthesis_wav2px(*shim.analysis_px2wav(fb, **params), **params)
+    np.testing.assert_allclose(back, fb, rtol=0, atol=1e-11 * np.abs(fb).max())
     lhs = np.vdot(shim.synthesis_wav2px(wav, scal, **params), f)
     rhs = np.vdot(X, ref.flatten_mlm(*shim.synthesis_adjoint_px2wav(f, **params)))
     assert abs(lhs - rhs) < 1e-11 * abs(lhs)
