@@ -1,6 +1,6 @@
 """One-off functional + timing check of BASELINE config 5 sizes (L=512, weak lensing, PxMALA)."""
 import contextlib, io, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from pxmcmc_amd import ops
 from pxmcmc_amd.forward import ForwardOperator

@@ -1,5 +1,5 @@
 import os, sys, contextlib, io
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import pxmcmc_np as ref
 from pxmcmc_amd.forward import SphericalWaveletTransformOperator

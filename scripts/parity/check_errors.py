@@ -1,5 +1,5 @@
 import os, sys, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from pxmcmc_amd import ops
 from pxmcmc_amd._lib import lib, PxmError, check

@@ -1,5 +1,5 @@
 import contextlib, io, itertools, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pxmcmc_amd.forward import SphericalWaveletTransformOperator
 from pxmcmc_amd.mcmc import MYULA, PxMCMCParams

@@ -1,7 +1,7 @@
 """Fused wavelet MYULA paths (ring-space / Gram / grouped DFT / pairs, image-space) vs the unfused generic kernels over
 odd bandlimits, wavelet parameters and chain counts (development aid)."""
 import contextlib, io, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from pxmcmc_amd.forward import SphericalWaveletTransformOperator
 from pxmcmc_amd.mcmc import MYULA, PxMCMCParams

@@ -1,7 +1,7 @@
 """Randomised parity sweep: GPU MYULA / PxMALA on the reference's noise stream vs the oracle's literal loops, over
 settings x measurements x data types x priors at small L (development aid; a compact subset lives in tests/)."""
 import contextlib, io, itertools, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import scipy.sparse as sp
 from oracle import pxmcmc_np as ref

@@ -2,7 +2,7 @@
 iterations relative to the iteration's first kernel (which lanes overlap, where the gaps are).
 
     rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 bench.py --steps 40 --warmup 5 --ramp 0 ...
-    python scripts/step_timeline.py OUT [n_steps]
+    python scripts/profile/step_timeline.py OUT [n_steps]
 """
 import csv
 import glob

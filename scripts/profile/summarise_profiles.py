@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Turn raw rocprofv3 output (gpurun_out/<tag>/...) into the committed summaries under profiles/.
 
-  python scripts/summarise_profiles.py r01a r01
+  python scripts/profile/summarise_profiles.py r01a r01
 writes profiles/<name>_kernel_stats.csv (rocprofv3 --stats table, verbatim),
        profiles/<name>_summary.md       (per-kernel table + GEMM launch classes + HBM traffic),
        profiles/pmc_summary.json         (HBM bytes per k_sht_gemm launch, read by bench.py).
@@ -18,9 +18,9 @@ import shutil
 import sys
 
 tag, name = sys.argv[1], sys.argv[2]
-sq_tag = sys.argv[3] if len(sys.argv) > 3 else None   # gpurun_out/<sq_tag>/{a,b,c}: SQ counter passes (collect_pmc_sq.sh)
-c5_tag = sys.argv[4] if len(sys.argv) > 4 else None   # gpurun_out/<c5_tag>: kernel trace of scripts/time_config5.py
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sq_tag = sys.argv[3] if len(sys.argv) > 3 else None   # gpurun_out/<sq_tag>/{a,b,c}: SQ counter passes (collect.sh sq)
+c5_tag = sys.argv[4] if len(sys.argv) > 4 else None   # gpurun_out/<c5_tag>: kernel trace of scripts/timing/time_config5.py (collect.sh config5)
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
@@ -120,7 +120,7 @@ if c5_tag:
         shutil.copy(f[-1], os.path.join(dst, f"{name}_L512_kernel_stats.csv"))
         rows5 = list(csv.DictReader(open(f[-1])))
         log = [l.strip() for l in open(os.path.join(root, "gpurun_out", c5_tag + ".log")) if l.startswith("C=")]
-        o5 = [f"# rocprofv3 --kernel-trace --stats of scripts/time_config5.py (BASELINE config 5 sizes: L=512 weak lensing, PxMALA, 2 chains)\n",
+        o5 = [f"# rocprofv3 --kernel-trace --stats of scripts/timing/time_config5.py (BASELINE configs[4] sizes: L=512 weak lensing, PxMALA, eager launches)\n",
               *[f"    {l}" for l in log], "\n| kernel | calls | avg us | % |\n|---|---|---|---|"]
         for r in rows5[:24]:
             o5.append(f"| `{r['Name'][:72]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |")

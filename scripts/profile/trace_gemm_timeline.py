@@ -1,13 +1,13 @@
 """Per-workgroup timeline of the ring-GEMM launches of ONE headline iteration (development aid).
 
-Needs a trace build of the library:
-    make -C pxmcmc_amd/csrc BUILD=build_tr OUT=../lib_ab/libpxm_tr.so EXTRA=-DPXM_GEMM_TRACE
-    PXM_LIB_PATH=$PWD/pxmcmc_amd/lib_ab/libpxm_tr.so python scripts/trace_gemm_timeline.py
+Needs a trace build of the library, built OUTSIDE the tree on the GPU box (ablation / trace libraries are never shipped):
+    make -C pxmcmc_amd/csrc BUILD=/tmp/pxm_ab/build_tr OUT=/tmp/pxm_ab/libpxm_tr.so EXTRA="-DPXM_GEMM_TRACE -DPXM_D5_TRACE"
+    PXM_LIB_PATH=/tmp/pxm_ab/libpxm_tr.so python scripts/profile/trace_gemm_timeline.py     (TRACE=dft: the grouped DFT launch)
 Every workgroup of k_sht_gemm records (block id, grid, start, end [100 MHz wall clock], XCC / SE / CU, chunks, row tiles,
 Gram flag).  Printed per launch: span, per-workgroup duration against its chunk count, workgroups per CU, idle share.
 """
 import collections, contextlib, ctypes as C, io, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from pxmcmc_amd import ops

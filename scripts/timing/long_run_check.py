@@ -1,7 +1,7 @@
 """Long-run sanity check of the benchmark configuration: the data misfit must fall from its start value and
 settle, states stay finite, chains stay distinct (development aid)."""
 import contextlib, io, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from pxmcmc_amd import ops

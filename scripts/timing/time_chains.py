@@ -1,6 +1,6 @@
 """samples/s of the L=256 benchmark iteration against the number of chains batched on one GPU (development aid)."""
 import contextlib, io, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from pxmcmc_amd.forward import SphericalWaveletTransformOperator

@@ -1,6 +1,6 @@
 """BASELINE config 5 timing: L=512 weak-lensing shear operator + wavelet synthesis, PxMALA (development aid / BASELINE.md)."""
 import contextlib, io, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from pxmcmc_amd.forward import ForwardOperator
 from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams

@@ -5,7 +5,7 @@
   4. uncertainty.chain_to_images: saved samples -> images, L=64
 """
 import contextlib, io, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp, torch
 from pxmcmc_amd import ops
 from pxmcmc_amd.forward import PathIntegralOperator

@@ -1,4 +1,4 @@
-"""shared by scripts/time_next_rows.py and scripts/time_phasevel_one.py"""
+"""synthetic path matrices of scripts/timing/time_next_rows.py"""
 import numpy as np
 import scipy.sparse as sp
 

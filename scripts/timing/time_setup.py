@@ -1,7 +1,7 @@
 """Plan creation times (ring tables built on the host + device, one-off per bandlimit and spin): development aid.
 Measured on one MI355X box: L=64 0.2 s, L=256 0.9 s, L=512 4.6 s per plan."""
 import time, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from pxmcmc_amd import ops
 for L in (64, 256, 512):

@@ -1,5 +1,5 @@
 import contextlib, io, os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from pxmcmc_amd.forward import SphericalWaveletTransformOperator
 from pxmcmc_amd.mcmc import MYULA, PxMCMCParams

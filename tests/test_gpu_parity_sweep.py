@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 def test_parity_sweep_against_oracle():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "scripts"))
+    sys.path.insert(0, os.path.join(root, "scripts", "parity"))
     import fuzz_parity
 
     ntot, nfail = fuzz_parity.main(stride=3)
@@ -23,7 +23,7 @@ def test_fused_paths_equal_unfused_kernels_random_sizes():
     fused wavelet MYULA engine (ring-space + Gram + grouped DFT + real pairs, or image-space) equals the chain of
     separate calc_gradg / proxf / chain_step / forward kernels."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "scripts"))
+    sys.path.insert(0, os.path.join(root, "scripts", "parity"))
     import fuzz_fused
 
     ntot, nfail = fuzz_fused.main(ncase=25, seed=1)
@@ -38,4 +38,4 @@ def test_check_scripts(script):
     import runpy
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    runpy.run_path(os.path.join(root, "scripts", script), run_name="__main__")
+    runpy.run_path(os.path.join(root, "scripts", "parity", script), run_name="__main__")
