@@ -25,6 +25,8 @@ Extensions (all optional, defaults reproduce the reference's one-chain behaviour
 
 SKROCK (pxmcmc/mcmc.py:292-383) is out of scope.
 """
+import time
+
 import numpy as np
 import torch
 from scipy.stats import laplace
@@ -792,6 +794,8 @@ class PxMALA(MYULA):
 
         i = 0
         n_acc = 0
+        torch.cuda.synchronize()
+        t_loop = time.perf_counter()  # (loop_seconds: the iterations alone, without set-up and graph capture)
         while j.min() < self.nsamples and (self.max_iter is None or i < self.max_iter):
             if graph is not None:
                 graph.replay()
@@ -821,6 +825,8 @@ class PxMALA(MYULA):
                     int(j[0]) - 1, float(logpiXc[0].real), L2=float(L2Xc[0].real), prior=float(priorXc[0]), acceptanceRate=rate
                 )
             i += 1
+        torch.cuda.synchronize()
+        self.loop_seconds = time.perf_counter() - t_loop
         k = i % self._CHUNK
         if k:
             acc_chunks.append(acc_buf[:k].cpu().numpy().copy())

@@ -140,7 +140,7 @@ def test_error_paths_and_empty_inputs():
     import runpy
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    runpy.run_path(os.path.join(root, "scripts", "check_errors.py"), run_name="__main__")
+    runpy.run_path(os.path.join(root, "scripts", "parity", "check_errors.py"), run_name="__main__")
 
 
 def test_example_script_end_to_end(tmp_path):
