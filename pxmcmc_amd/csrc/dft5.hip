@@ -713,11 +713,8 @@ template <bool RING_OUT, bool N64>
 __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5Group* __restrict__ ents, int nent,
                                                                                        double* __restrict__ ws, int ncol, PxOut out,
                                                                                        int C, unsigned* __restrict__ zero_words,
-                                                                                       int n_zero, uint64_t* __restrict__ bump) {
+                                                                                       int n_zero) {
   extern __shared__ double2 lds5[];
-  // (the Philox iteration counter, when this step's noise was drawn by its Gram launch -- plans.hip: nothing in this
-  // kernel reads the counter then)
-  if (bump && blockIdx.x == 0 && threadIdx.x == 0) *bump += 1;
 #ifdef PXM_D5_TRACE
   const unsigned long long trace_t0 = wall_clock64();
 #endif
@@ -1250,19 +1247,19 @@ void dft_group_destroy(DftGroupList* g) {
 }
 
 int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st, Profiler* prof,
-                      unsigned* zero_words, int n_zero, uint64_t* bump) {
+                      unsigned* zero_words, int n_zero) {
   // algorithmic bytes: rings read + written (16 B per slot and coefficient, every padded slot), state read, new state
   // written (live slots), thresholds read once
   PXM_REQUIRE(g.ring_end <= out.chain_stride, "dft5_group_launch: a scale's coefficient block ends past chain_stride");
-  const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0) + (out.noise ? 16.0 * C : 0.0));
+  const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
   if (out.X && !out.noise && out.noise64)
     hipExtLaunchKernelGGL((k_ring2px_group5<true, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
-                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero, bump);
+                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero);
   else
     hipExtLaunchKernelGGL((k_ring2px_group5<true, false>), dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
-                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero, bump);
+                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -1279,10 +1276,10 @@ int dft5_group_ring2px(const DftGroupList& g, double* ws, int ncol, const PxOut&
   PXM_REQUIRE(out.gidx || g.ring_end <= out.chain_stride, "dft5_group_ring2px: a scale's coefficient block ends past chain_stride");
   if (out.X && !out.noise && out.noise64)
     hipLaunchKernelGGL((k_ring2px_group5<false, true>), dim3(g.blocks), dim3(g.threads), g.lds, st,
-                       reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, (unsigned*)nullptr, 0, (uint64_t*)nullptr);
+                       reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, (unsigned*)nullptr, 0);
   else
     hipLaunchKernelGGL((k_ring2px_group5<false, false>), dim3(g.blocks), dim3(g.threads), g.lds, st,
-                       reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, (unsigned*)nullptr, 0, (uint64_t*)nullptr);
+                       reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, (unsigned*)nullptr, 0);
   PXM_HIP(hipGetLastError());
   return 0;
 }

@@ -151,7 +151,7 @@ static double tasklist_bytes(const TaskList& tl, int cg) {
 
 // run a task list over all chain groups (16 chains = 32 columns per launch)
 static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, int C, hipStream_t st,
-                     const GemmAffine& aff = GemmAffine(), Profiler* prof = nullptr, const GemmNoise* nz = nullptr) {
+                     const GemmAffine& aff = GemmAffine(), Profiler* prof = nullptr) {
   note_stream(st);
   for (int col0 = 0; col0 < ncol; col0 += 32) {
     const int ct = (ncol - col0 >= 32) ? 2 : 1;
@@ -161,11 +161,7 @@ static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, i
     GemmAffine a = aff;
     if (col0) a.bump = nullptr;  // the iteration counter advances once per call, not once per column group
     a.ncol_live = 2 * C;
-    int rc;
-    if (nz && col0 == 0)  // the step's noise rides on the first launch of the Gram list (sht_gemm.hip: k_sht_gemm_noise)
-      rc = launch_gemm_noise(tl.d, tl.n, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, a, *nz, prof);
-    else
-      rc = launch_gemm(tl.d, tl.n, tl.nslab, tl.flags, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, a, prof);
+    int rc = launch_gemm(tl.d, tl.n, tl.nslab, tl.flags, X, Y, ncol, col0, ct, bytes, tl.mfma_units * ct * 2048.0, st, a, prof);
     if (rc) return rc;
   }
   return 0;
@@ -461,8 +457,6 @@ struct pxm_wav_plan_s {
   unsigned* d_flow_flags = nullptr;    // [L] per-m counters (the time-out flag is bit 0 of d_status)
   double flow_bytes = 0, flow_mfma = 0;
   unsigned* d_status = nullptr;  // device status word of THIS plan: bit 0 dataflow wait, bit 1 DFT pair wait (pxm_wav_status)
-  double* d_noise = nullptr;     // [2 Cmax][ncoefs]: the ring-space step's fp64 noise, drawn by its Gram launch (GemmNoise)
-  bool noise_tasks = true;       // PXM_NO_NOISE_TASKS=1 (read at plan creation): fp64 noise inside the DFT epilogue instead
   uint64_t* iter_dev = nullptr;  // device-resident Philox iteration counter of THIS plan (pxm_wav_set_iter_counter)
   Profiler prof;                 // live kernel timing of THIS plan (pxm_wav_profile_*)
 };
@@ -545,8 +539,6 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   p->offS = w; w += (int64_t)p->Rp * p->ncol;
   if ((rc = dev_alloc(&p->ws, (size_t)w * sizeof(double), "wavelet plan workspace"))) return rc;
   if ((rc = dev_zero(p->ws, (size_t)w * sizeof(double)))) return rc;
-  p->noise_tasks = !getenv("PXM_NO_NOISE_TASKS");
-  if (p->noise_tasks && (rc = dev_alloc(&p->d_noise, (size_t)2 * p->Cmax * p->ncoefs * sizeof(double), "ring-space step noise buffer"))) return rc;
   // wavelet kernels: synthesis f_lm = kappa0 W^phi + sqrt(2pi) sum_j kappa_j W^j; analysis W^j = kappa_j f / sqrt(2pi)
   std::vector<double> k0, kap;
   tiling_axisym(L, B, J_min, k0, kap);
@@ -697,7 +689,6 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   deferred_free(p->d_wlk);
   deferred_free(p->d_flow_flags);
   deferred_free(p->d_status);
-  deferred_free(p->d_noise);
   // (side streams / events belong to the per-device pool)
   TaskList* tls[] = {&p->syn_fwd, &p->syn_inv, &p->adj_invadj, &p->adj_fwdadj, &p->adj_invadj_R, &p->gram, &p->adj_invadj_D,
                      &p->ana_fwd, &p->ana_inv, &p->anadj_invadj, &p->anadj_fwdadj, &p->wl_inv, &p->wl_invadj, &p->flow};
@@ -936,14 +927,13 @@ static bool wav_can_fuse_dft(pxm_wav_plan_t p) {
   return true;
 }
 
-static int wav_rings_update_rings(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st, uint64_t* bump = nullptr) {
+static int wav_rings_update_rings(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
   if (p->dft_group.d && p->dft_group.all) {  // one grid for every scale, small scales first
     proto.chain_stride = p->ncoefs;
     // (it also zeroes the counters of the dataflow GEMM launch: it runs between two of them in a stepping loop)
     return dft5_group_launch(p->dft_group, p->ws, p->ncol, proto, C, st, &p->prof, p->use_flow ? p->d_flow_flags : nullptr,
-                             p->use_flow ? p->L : 0, bump);
+                             p->use_flow ? p->L : 0);
   }
-  PXM_REQUIRE(!bump, "wav_rings_update_rings: the counter bump rides on the grouped launch only");
   bool used[pxm_wav_plan_s::NSIDE];
   int rc = wav_fork(p, st, used);
   if (rc) return rc;
@@ -1248,26 +1238,6 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
   PXM_REQUIRE(X != X_out, "pxm_wav_ring_step: X_out must not alias X");
   PXM_REQUIRE((mode & ~PXM_NOISE_F64) >= 0 && (mode & ~PXM_NOISE_F64) <= 2, "pxm_wav_ring_step: mode must be 0, 1 or 2 (| PXM_NOISE_F64)");
   hipStream_t st = (hipStream_t)stream;
-  PxOut out;
-  out.f = (double*)X_out;
-  out.X = (const double*)X;
-  out.T = T;
-  out.T_scalar = T_scalar;
-  out.delta = delta;
-  out.lmda = lmda;
-  out.noise = (const double*)noise;
-  out.mode = mode & ~PXM_NOISE_F64;
-  out.noise64 = (mode & PXM_NOISE_F64) ? 1 : 0;
-  out.seed = seed;
-  out.chain0 = chain0;
-  out.iter = iter;
-  out.iter_dev = p->iter_dev;
-  out.chain_stride = p->ncoefs;
-  // fp64 Philox noise: drawn by extra workgroups of the Gram launch into the plan's buffer (GemmNoise, sht_core.h) and
-  // read by the DFT epilogue as injected noise; the iteration counter is then bumped by the DFT launch
-  const bool noise_in_gram = p->use_gram && !p->use_flow && !noise && out.noise64 && p->noise_tasks && p->d_noise &&
-                             wav_can_fuse_dft(p) && p->dft_group.d && p->dft_group.all;
-  uint64_t* dft_bump = nullptr;
   if (p->use_gram) {
     // H' = w ((2L-1) B^T B H - B^T DFT(data)): inverse transform, ring residual and inverse-adjoint in one GEMM
     GemmAffine aff;
@@ -1285,19 +1255,6 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
                             (p->gram.mfma_units + p->adj_fwdadj.mfma_units) * ct * 2048.0, st, aff, p->d_flow_flags,
                             p->d_status, &p->prof);
       if (rc) return rc;
-    } else if (noise_in_gram) {
-      GemmNoise nz;
-      nz.o = out;
-      nz.o.f = p->d_noise;
-      nz.n = p->ncoefs;
-      nz.slots = C;
-      nz.nblocks = gemm_noise_blocks(nz.n, nz.slots);
-      aff.bump = nullptr;
-      dft_bump = p->iter_dev;
-      if ((rc = run_tasks(p->gram, p->ws, p->ws, p->ncol, C, st, aff, &p->prof, &nz))) return rc;
-      if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
-      out.noise = p->d_noise;
-      out.iter_dev = nullptr;
     } else {
       if ((rc = run_tasks(p->gram, p->ws, p->ws, p->ncol, C, st, aff, &p->prof))) return rc;
       if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
@@ -1313,9 +1270,23 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
     if ((rc = run_tasks(p->adj_invadj_R, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
     if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
   }
+  PxOut out;
+  out.f = (double*)X_out;
+  out.X = (const double*)X;
+  out.T = T;
+  out.T_scalar = T_scalar;
+  out.delta = delta;
+  out.lmda = lmda;
+  out.noise = (const double*)noise;
+  out.mode = mode & ~PXM_NOISE_F64;
+  out.noise64 = (mode & PXM_NOISE_F64) ? 1 : 0;
+  out.seed = seed;
+  out.chain0 = chain0;
+  out.iter = iter;
+  out.iter_dev = p->iter_dev;
   if (wav_can_fuse_dft(p)) {
     // rings -> X_out -> rings of X_out in one kernel per scale, then the per-scale forward GEMMs
-    if ((rc = wav_rings_update_rings(p, out, C, st, dft_bump))) return rc;
+    if ((rc = wav_rings_update_rings(p, out, C, st))) return rc;
     if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;
     if (p->use_gram) return 0;
     if (!p->fused_combine && (rc = launch_combine(p->comb_syn, p->ws, p->ws + p->offHL, st))) return rc;

@@ -262,21 +262,6 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
   const double* gw = nullptr;
 };
 
-// Noise of a ring-space step drawn by EXTRA WORKGROUPS OF ITS GRAM LAUNCH (sht_gemm.hip: k_sht_gemm_noise).  The fused
-// phi-DFT + update kernel is bound by VALU issue: the fp64 Box-Muller (~70 fp64 operations per pair) costs it 11 us there,
-// while the Gram launch is a latency chain of 1.5 workgroups per CU whose vector pipe idles -- the same arithmetic, same
-// Philox counters, written to a plan-owned buffer in the layout of injected noise and read back by the DFT epilogue.
-struct GemmNoise {
-  PxOut o;          // mode, seed, chain0, iter, iter_dev, noise64; o.f = the buffer, o.chain_stride = elements per chain
-  int64_t n = 0;    // elements per slot
-  int slots = 0;    // complex slots to draw for
-  int nblocks = 0;  // workgroups appended behind the GEMM tasks of the grid
-};
-int gemm_noise_blocks(int64_t n, int slots);
-int launch_gemm_noise(const GemmTask* d_tasks, int n_tasks, const double* X, double* Y, int ncol, int col0, int ct,
-                      double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff, const GemmNoise& nz,
-                      Profiler* prof);
-
 // grouped launches of a wavelet plan's member scales (dft5.hip): one grid for every scale
 struct DftGroupList {
   void* d = nullptr;  // device array of per-scale descriptors
@@ -300,7 +285,7 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
                       const std::vector<int64_t>& ring0, int ncol, const double* ws_base,
                       DftGroupList* out);  // 1 = not available
 int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st,
-                      Profiler* prof = nullptr, unsigned* zero_words = nullptr, int n_zero = 0, uint64_t* bump = nullptr);
+                      Profiler* prof = nullptr, unsigned* zero_words = nullptr, int n_zero = 0);
 // the plain transforms of every member scale in one grid each (blocks <-> rings of the generic wavelet operators)
 int dft5_group_px2ring(const DftGroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st);
 int dft5_group_ring2px(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st);

@@ -8,7 +8,6 @@
 // coalesced 16-B-per-lane load per two MFMA k-steps and the table never touches LDS.
 #include "../../include/pxmcmc_amd.h"
 #include "sht_core.h"
-#include "update.h"
 
 #include <type_traits>
 
@@ -351,47 +350,6 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
-// Gram launch + the step's noise (GemmNoise, sht_core.h): the GEMM tasks first in the grid, then nz.nblocks workgroups
-// that draw Philox + fp64 Box-Muller deviates for 2048 elements of one slot each and store them in the layout of
-// injected noise (update.h: px_noise_load).  The step's iteration number is the plan's counter AFTER its bump; here the
-// bump is left to the DFT launch that follows (dft5.hip), so every noise workgroup reads counter + 1 whatever the order
-// the workgroups start in.
-// ---------------------------------------------------------------------------------------
-constexpr int NZ_EPT = 4;  // elements per thread of a noise workgroup (512 threads)
-__device__ __forceinline__ void gemm_noise_body(const GemmNoise& nz, int blk) {
-  const int64_t per_slot = (nz.n + 512 * NZ_EPT - 1) / (512 * NZ_EPT);
-  const int c = (int)(blk / per_slot);
-  if (c >= nz.slots) return;
-  const PxOut& o = nz.o;
-  const uint64_t it = o.iter + (o.iter_dev ? *o.iter_dev + 1 : 0);
-  const int64_t e0 = (blk % per_slot) * (512 * NZ_EPT) + threadIdx.x;
-  double* buf = o.f;
-#pragma unroll
-  for (int u = 0; u < NZ_EPT; ++u) {
-    const int64_t e = e0 + 512 * u;
-    if (e >= nz.n) break;
-    const double2 w = px_noise_philox_t<true>(o, c, e, it);
-    if (o.mode == PXM_MODE_CPLX_NOISE) reinterpret_cast<double2*>(buf)[(int64_t)c * o.chain_stride + e] = w;
-    else if (o.mode == PXM_MODE_REAL_PAIRS) {
-      buf[(int64_t)(2 * c) * o.chain_stride + e] = w.x;
-      buf[(int64_t)(2 * c + 1) * o.chain_stride + e] = w.y;
-    } else buf[(int64_t)c * o.chain_stride + e] = w.x;
-  }
-}
-
-template <int CT>
-__global__ __launch_bounds__(512) void k_sht_gemm_noise(const GemmTask* __restrict__ tasks, int n_tasks,
-                                                        const double* __restrict__ X, double* __restrict__ Y, int ncol,
-                                                        int col0, GemmAffine aff, GemmNoise nz) {
-  __shared__ double xs[2][KC][GemmGeom<CT, 2>::PITCH];
-  if ((int)blockIdx.x >= n_tasks) {
-    gemm_noise_body(nz, blockIdx.x - n_tasks);
-    return;
-  }
-  sht_gemm_body<CT, 2, 8, 1, 2, true, false, 0>(tasks, blockIdx.x, X, Y, ncol, col0, aff, xs);
-}
-
-// ---------------------------------------------------------------------------------------
 // Dataflow launch of the ring-space step: the Gram tasks and the forward-adjoint tasks of EVERY scale in one grid.
 // A forward-adjoint task (m, scale, row block) reads H'[m], which the one or two Gram tasks of that m write: it waits
 // on a per-m counter the Gram tasks increment when their rows are stored, instead of on a launch boundary -- the
@@ -590,24 +548,6 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, int flags, cons
 #undef PXM_GEMM_L2
 #undef PXM_GEMM_L3
 #undef PXM_GEMM_L4
-  PXM_HIP(hipGetLastError());
-  return 0;
-}
-
-int gemm_noise_blocks(int64_t n, int slots) { return (int)(((n + 512 * NZ_EPT - 1) / (512 * NZ_EPT)) * slots); }
-
-// the Gram launch (+-m paired tables, two operands, affine epilogue) with the noise workgroups of the step behind its tasks
-int launch_gemm_noise(const GemmTask* d_tasks, int n_tasks, const double* X, double* Y, int ncol, int col0, int ct,
-                      double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff, const GemmNoise& nz,
-                      Profiler* prof) {
-  if (n_tasks == 0) return 0;
-  PXM_REQUIRE(ct == 1 || ct == 2, "launch_gemm_noise: one or two column tiles");
-  PXM_REQUIRE(nz.o.f && nz.n > 0 && nz.slots > 0 && nz.nblocks == gemm_noise_blocks(nz.n, nz.slots), "launch_gemm_noise: bad noise descriptor");
-  dim3 grid(n_tasks + nz.nblocks), block(512);
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (prof) prof->next(prof->gemm, &ev0, &ev1, alg_bytes + 16.0 * nz.slots * (double)nz.n, flops, n_tasks);
-  if (ct == 1) hipExtLaunchKernelGGL((k_sht_gemm_noise<1>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, n_tasks, X, Y, ncol, col0, aff, nz);
-  else hipExtLaunchKernelGGL((k_sht_gemm_noise<2>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, n_tasks, X, Y, ncol, col0, aff, nz);
   PXM_HIP(hipGetLastError());
   return 0;
 }

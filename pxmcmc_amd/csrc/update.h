@@ -14,9 +14,7 @@
 
 namespace pxm {
 
-#ifndef PXM_MODE_REAL_NOISE  // (translation units that include the public header have them as macros: same values)
 enum { PXM_MODE_REAL_NOISE = 0, PXM_MODE_CPLX_NOISE = 1, PXM_MODE_REAL_PAIRS = 2 };
-#endif
 
 // input element e of chain ch of a px2ring kernel: plain image, residual invcov .* (preds - data)
 // (pxmcmc/forward.py:66-69), and / or the scatter of a masked data vector into the image (mask_adjoint + cov_weight)

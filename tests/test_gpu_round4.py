@@ -137,48 +137,6 @@ def test_fused_step_fp64_noise_equals_injected_oracle_stream(L, pairs):
     assert plan.status() == 0
 
 
-def test_fp64_noise_drawn_by_gram_launch_equals_dft_epilogue(monkeypatch):
-    """With the fp64 stream the ring-space step draws its noise in EXTRA WORKGROUPS OF THE GRAM LAUNCH (k_sht_gemm_noise:
-    the fused DFT kernel is VALU-bound, the Gram launch is not) and the DFT epilogue reads it back; PXM_NO_NOISE_TASKS=1
-    (read at plan creation) keeps the Box-Muller inside the DFT epilogue.  Same counters, same arithmetic: equal states
-    after K steps of a stepping engine with a registered device counter (graph replay), C = 5 chains (odd: a padded pair)
-    and 16 complex slots (two GEMM column tiles)."""
-    import torch
-
-    from pxmcmc_amd import ops
-
-    L, B, J_min, K = 32, 2.0, 2, 5
-    rng = np.random.default_rng(8)
-    d = ops.as_device(rng.normal(size=L * (2 * L - 1)), torch.float64)
-    for pairs, slots in ((True, 3), (False, 16)):
-        res = []
-        for env in ("0", "1"):
-            if env == "1":
-                monkeypatch.setenv("PXM_NO_NOISE_TASKS", "1")
-            else:
-                monkeypatch.delenv("PXM_NO_NOISE_TASKS", raising=False)
-            plan = ops.WavPlan(L, B, J_min, max_chains=slots)
-            N = plan.ncoefs
-            r2 = np.random.default_rng(9)
-            X0 = r2.normal(size=(2 * slots if pairs else slots, N)) * 1e-2
-            T = ops.as_device(np.full(N, 1e-4), torch.float64)
-            plan.ring_set_data(torch.complex(d, d if pairs else torch.zeros_like(d)).contiguous())
-            X = torch.complex(ops.as_device(X0[0::2]), ops.as_device(X0[1::2])) if pairs else ops.as_device(X0, torch.complex128)
-            out = torch.empty_like(X)
-            cnt = ops.IterCounter(plan, 6)  # the steps use iterations 7, 8, ... (the step bumps the counter first)
-            plan.ring_init(X)
-            for _ in range(K):
-                plan.ring_step(X, complex(4.0, 0.0), T, 1e-4, 2e-3, seed=3, chain0=4, it=0, out=out, pairs=pairs, noise64=True)
-                X, out = out, X
-            assert int(cnt.t.item()) == 6 + K
-            cnt.close()
-            res.append(_np(X))
-            assert plan.status() == 0
-        scale = np.sqrt(2e-4)
-        assert np.abs(res[0] - res[1]).max() < 1e-13 * scale, (pairs, np.abs(res[0] - res[1]).max() / scale)
-    monkeypatch.delenv("PXM_NO_NOISE_TASKS", raising=False)
-
-
 def test_sampler_noise_bits_64_graph_equals_eager_and_tracks_default():
     """MYULA(noise_bits=64): HIP-graph replay == eager stepping (bit for bit), and the chain stays within the f32 units'
     accuracy of the default stream over a few iterations; PxMALA and the generic engine take the flag too."""
