@@ -670,3 +670,52 @@ def test_config5_pxmala_trajectory_matches_oracle_L272():
             np.testing.assert_allclose(s.L2s[c, 0], np.real(out["L2s"][0]), rtol=1e-9)
             np.testing.assert_allclose(s.priors[c, 0], out["priors"][0], rtol=1e-10)
     assert seen == {0, 1}, "the compared iterations should hold accepted AND rejected proposals"
+
+
+def test_config5_logtransition_and_propose_at_full_state_size():
+    """calc_logtransition at the state size of BASELINE configs[4] (N = 1 221 796 complex coefficients): the literal
+    -(1/2*delta) * sum((X2 - X1 - (delta/2) g)**2)**2 of pxmcmc/mcmc.py:281-289 -- a complex SQUARED sum over 1.2 M terms,
+    squared again -- from the two-stage device reduction (`pxm_logtransition`) and from the one-pass proposal kernel
+    (`pxm_pxmala_propose`: chain_step + soft + transition + prior, injected noise) against numpy's pairwise sum and
+    against an exactly rounded sum (math.fsum) of the same terms, two chains with their own delta; and the proposal /
+    prox / prior of the one-pass kernel against the oracle's formulae.  A reduction-order difference here is what would
+    flip a Metropolis accept: the three summation orders agree to 1e-12."""
+    import math
+
+    import torch
+
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd import ops
+
+    N, C = 1221796, 2
+    rng = np.random.default_rng(4)
+    X = (rng.normal(size=(C, N)) + 1j * rng.normal(size=(C, N))) * 1e-3
+    g = (rng.normal(size=(C, N)) + 1j * rng.normal(size=(C, N))) * 50.0
+    T = np.abs(rng.normal(size=N)) * 1e-9
+    w = np.abs(rng.normal(size=N)) + 0.1
+    noise = rng.normal(size=(C, N))
+    lmda = 5e-7
+    delta = np.array([1e-7, 3.3e-9])
+    px = np.stack([ref.soft(X[c], T) for c in range(C)])
+    dev = ops.device()
+    Xd, gd, pxd = (ops.as_device(a, torch.complex128) for a in (X, g, px))
+    dd = torch.as_tensor(delta, device=dev)
+    Xp, pxp = torch.empty_like(Xd), torch.empty_like(Xd)
+    lt, pr = torch.empty(C, dtype=torch.complex128, device=dev), torch.empty(C, dtype=torch.float64, device=dev)
+    ops.pxmala_propose(Xd, pxd, gd, ops.as_device(T, torch.float64), ops.as_device(w, torch.float64), dd, lmda, Xp, pxp, lt, pr,
+                       noise=ops.as_device(noise))
+    lt2 = ops.logtransition(Xd, Xp, pxd, gd, dd, lmda).cpu().numpy()
+    lt, pr, Xp_h, pxp_h = lt.cpu().numpy(), pr.cpu().numpy(), Xp.cpu().numpy(), pxp.cpu().numpy()
+    for c in range(C):
+        want_X = ref.chain_step(X[c], px[c], g[c], delta[c], lmda, noise[c])
+        assert np.abs(Xp_h[c] - want_X).max() <= 1e-13 * np.abs(want_X).max()
+        assert np.abs(pxp_h[c] - ref.soft(Xp_h[c], T)).max() <= 1e-13 * np.abs(want_X).max()
+        assert abs(pr[c] - np.sum(np.abs(w * Xp_h[c]))) <= 1e-12 * pr[c]
+        want = ref.calc_logtransition(X[c], Xp_h[c], px[c], g[c], delta[c], lmda)  # numpy pairwise summation
+        gg = -((X[c] - px[c]) / lmda) - g[c]
+        z2 = (Xp_h[c] - X[c] - (delta[c] / 2) * gg) ** 2
+        s_exact = complex(math.fsum(z2.real), math.fsum(z2.imag))  # exactly rounded sum of the same terms
+        want_exact = -(1 / 2 * delta[c]) * s_exact ** 2
+        for got in (lt[c], lt2[c]):
+            assert abs(got - want) <= 1e-12 * abs(want), (c, got, want)
+            assert abs(got - want_exact) <= 1e-12 * abs(want_exact), (c, got, want_exact)
