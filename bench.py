@@ -51,7 +51,7 @@ def stable_delta(transform, sigma, lmda, iters=30):
         x = y / torch.linalg.norm(y)
     return 0.8 / (lam / sigma ** 2 + 1.0 / lmda), lam
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
-MFMA_SUSTAINED_TFLOPS = 47.1  # fp64 MFMA-only loop on this part (scripts/mfma_rate.hip; spec 78.6)
+MFMA_SUSTAINED_TFLOPS = 47.1  # fp64 MFMA-only loop on this part (scripts/probes/mfma_rate.hip; spec 78.6)
 
 
 def synthetic_field(plan_inverse, L, seed, slope=-1.0):
@@ -802,7 +802,7 @@ def main():
                 # 47 TFLOP/s sustained by an MFMA-only loop on this part): the kernel is co-limited
                 "mfma_tflops": nf.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0,
                 "mfma_frac_of_spec": nf.value / (ms.value * 1e-3) / 78.6e12 if ms.value > 0 else 0.0,
-                # the rate an MFMA-ONLY loop sustains on this part (scripts/mfma_rate.hip: 8 independent accumulators, 2 waves
+                # the rate an MFMA-ONLY loop sustains on this part (scripts/probes/mfma_rate.hip: 8 independent accumulators, 2 waves
                 # per SIMD, 44.6 ns per v_mfma_f64_16x16x4_f64 and SIMD -- the part throttles under fp64 matrix load): the
                 # two grouped launches (1.42 GFLOP each) run at 0.90-0.95 of it, i.e. they are bound by the matrix pipe
                 "mfma_sustained_tflops": MFMA_SUSTAINED_TFLOPS,
