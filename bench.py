@@ -399,9 +399,6 @@ def config5_mask(L):
 
 def config5_problem():
     """BASELINE configs[4] on one GPU: L=512 weak-lensing shear operator + wavelet synthesis, one chain"""
-    import torch
-
-    from pxmcmc_amd import ops
     from pxmcmc_amd.forward import ForwardOperator
     from pxmcmc_amd.measurements import WeakLensing
     from pxmcmc_amd.prior import S2_Wavelets_L1
@@ -428,7 +425,6 @@ def config5_problem():
     op = ForwardOperator(data, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
     lmda = C5_DELTA0 / 2
     reg = S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, lmda * MU, L=L, B=C5_B, J_min=C5_JMIN)
-    del torch, ops
     return op, reg, tr, wl, lmda
 
 
