@@ -633,7 +633,7 @@ def main():
         assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
 
     dt = D.max_over_ranks(dt_rank)
-    per_rank_ms = [float(v) * 1e3 / args.steps for v in D.gather_summaries(np.array([dt_rank])).numpy().ravel()]
+    per_rank_ms = [v * 1e3 / args.steps for v in D.all_gather_float(dt_rank)]
     # cost of one empty start/stop barrier of this process group (synchronise + dist.barrier + synchronise), after the
     # run: what the clock WOULD have contained had the stop barrier been inside it
     barrier()

@@ -58,6 +58,18 @@ def max_over_ranks(value):
     return float(t.item())
 
 
+def all_gather_float(value):
+    """one python float per rank -> list of world_size floats in rank order (a plain fixed-size all-gather: no object
+    pickling on the path the 8-GPU benchmark takes)"""
+    if not dist.is_initialized():
+        return [float(value)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
 def count_ranks():
     """number of ranks that take part in the process group, by an all-reduce (SUM of ones) over the group's own
     transport (RCCL for ``nccl``): 1 without a group"""

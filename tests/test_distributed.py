@@ -26,6 +26,8 @@ WORKER = textwrap.dedent(
     mine = np.stack([philox.randn_real(N, SEED, first + c, IT) for c in range(count)])
     D.barrier()
     t = D.max_over_ranks(1.0 + rank)               # the slowest rank defines the elapsed time
+    per_rank = D.all_gather_float(0.5 + rank)      # bench.py's per-rank times, in rank order
+    assert per_rank == [0.5, 1.5] and D.count_ranks() == 2
     allc = D.gather_summaries(mine).numpy()
     if rank == 0:
         ref = np.stack([philox.randn_real(N, SEED, c, IT) for c in range(TOTAL)])
@@ -219,6 +221,7 @@ RCCL_WORKER = textwrap.dedent(
     assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
     D.barrier()
     assert D.max_over_ranks(1.5) == 1.5
+    assert D.all_gather_float(2.5) == [2.5]
     assert D.count_ranks() == 1
     g = D.gather_summaries(np.arange(12.0).reshape(3, 4)).numpy()
     assert g.shape == (3, 4) and np.array_equal(g, np.arange(12.0).reshape(3, 4))
