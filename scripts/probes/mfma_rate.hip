@@ -18,25 +18,25 @@ __global__ __launch_bounds__(256) void k(double* out, int iters) {
 template <int NACC>
 void run(int wgs_per_cu, int waves) {
   double* out;
-  hipMalloc(&out, 256 * 8 * 4096 * 8);
+  (void)hipMalloc(&out, 256 * 8 * 4096 * 8);
   int iters = 20000;
   hipEvent_t s, e;
-  hipEventCreate(&s);
-  hipEventCreate(&e);
+  (void)hipEventCreate(&s);
+  (void)hipEventCreate(&e);
   k<NACC><<<256 * wgs_per_cu, 64 * waves>>>(out, 100);
-  hipDeviceSynchronize();
-  hipEventRecord(s);
+  (void)hipDeviceSynchronize();
+  (void)hipEventRecord(s);
   k<NACC><<<256 * wgs_per_cu, 64 * waves>>>(out, iters);
-  hipEventRecord(e);
-  hipEventSynchronize(e);
+  (void)hipEventRecord(e);
+  (void)hipEventSynchronize(e);
   float ms;
-  hipEventElapsedTime(&ms, s, e);
+  (void)hipEventElapsedTime(&ms, s, e);
   double mf = (double)256 * wgs_per_cu * waves * iters * NACC;
   double tf = mf * 2048 / (ms * 1e-3) / 1e12;
   double per_simd_ns = ms * 1e6 / ((double)iters * NACC * wgs_per_cu * waves / 4.0);
   printf("NACC=%d wg/cu=%d waves/wg=%d: %.2f ms  %.1f TFLOP/s  %.1f ns per MFMA per SIMD (=%.0f cyc @2.4GHz)\n", NACC, wgs_per_cu, waves, ms, tf,
          per_simd_ns, per_simd_ns * 2.4);
-  hipFree(out);
+  (void)hipFree(out);
 }
 int main() {
   run<1>(1, 4);
