@@ -178,31 +178,33 @@ def test_bench_timed_region_holds_no_collective():
 
 
 @pytest.mark.gpu
-def test_bench_gpus2_self_launch_rehearsal():
-    """The driver's N > 1 command issued plainly: `python bench.py --gpus 2` (no torchrun in front).  On the test
-    box's single GPU the two ranks share cuda:0 and use gloo (PXM_BENCH_REHEARSE=1; RCCL refuses two ranks on one
-    device); the JSON line must report both ranks."""
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_bench_gpus2_self_launch_rehearsal(nranks):
+    """The driver's N > 1 command issued plainly: `python bench.py --gpus N` (no torchrun in front).  On the test
+    box's single GPU the ranks share cuda:0 and use gloo (PXM_BENCH_REHEARSE=1; RCCL refuses two ranks on one
+    device); the JSON line must report every rank."""
     import json
 
     env = dict(os.environ, PXM_BENCH_REHEARSE="1", OMP_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--ramp", "10"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "6", "--warmup", "2", "--ramp", "10"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-3000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 6 and out["warmup"] == 12
-    assert out["config"]["global_chains"] == 32 and out["value"] > 0 and out["scaling"] == "weak"
+    assert out["n_gpus"] == nranks and out["ranks_seen"] == nranks and out["steps"] == 6 and out["warmup"] == 12
+    assert out["config"]["global_chains"] == 16 * nranks and out["value"] > 0 and out["scaling"] == "weak"
     assert "cpu_baseline" not in out  # the CPU legs run at N = 1 only
     # the clock of a rank stops at its own device synchronise (no collective inside): per-rank times are reported, the
     # headline is their maximum, and the cost of one barrier of the group is measured separately
     per_rank = out["per_rank_ms_per_step"]
-    assert len(per_rank) == 2 and all(t > 0 for t in per_rank)
+    assert len(per_rank) == nranks and all(t > 0 for t in per_rank)
     assert abs(max(per_rank) - out["ms_per_step"]) <= 1e-9 * out["ms_per_step"]
     assert out["barrier_us"] > 0
-    assert abs(out["value"] - 32 * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
+    assert abs(out["value"] - 16 * nranks * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
+    assert out["value_f64_noise"] is None and out["configs"] is None  # the side legs run at N = 1 only
 
 
 RCCL_WORKER = textwrap.dedent(
