@@ -123,10 +123,11 @@ def cpu_baseline(data, T, n_iter, delta, procs=1):
     return procs * n_iter / wall, wall
 
 
-def self_launch(n, argv):
+def self_launch(n, argv, script=None):
     """Start the N ranks of ``bench.py --gpus N`` as a child ``python -m torch.distributed.run`` (one rank per GPU,
     rendezvous on 127.0.0.1 at a free port).  Called before torch is imported: the parent holds no GPU state, the
-    child is an ordinary subprocess (never an exec), rank 0 prints the JSON line on the inherited stdout."""
+    child is an ordinary subprocess (never an exec), rank 0 prints the JSON line on the inherited stdout.
+    (``script``: another program for the ranks -- the CPU rehearsal of the 8-rank rendezvous in tests/test_distributed.py.)"""
     import socket
     import subprocess
 
@@ -134,7 +135,7 @@ def self_launch(n, argv):
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("OMP_NUM_THREADS", "1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -282,7 +283,7 @@ def live_traffic(timeout_s=120):
     """PMC traffic of the timed iteration's k_sht_gemm launches: child passes of the headline step with --steps 10.
     Returns (bytes per launch, description, per-launch-class list) or (None, reason, None)."""
     classes, info = pmc_passes(["--steps", "10", "--warmup", "2", "--ramp", "0", "--no-cpu-baseline", "--no-layout-compare",
-                                "--no-live-traffic", "--no-config-legs"], timeout_s)
+                                "--no-live-traffic", "--no-config-legs", "--no-noise-leg"], timeout_s)
     if classes is None:
         return None, info, None
     # classes of the stepping loop: the ones launched (almost) once per step of the 12-step child
@@ -321,6 +322,10 @@ def join_pmc(classes, pmc):
         by_wgs.setdefault(c["workgroups"], []).append(c)
     for g in classes:
         cs = by_wgs.get(g["workgroups"])
+        if cs and max(c["hbm_MB"] for c in cs) > 1.02 * min(c["hbm_MB"] for c in cs):
+            # several kernel variants of this grid size with different traffic in the child pass: no honest join
+            g["pmc_ambiguous"] = sorted(c["kernel"] for c in cs)
+            continue
         if cs:
             n = sum(c["launches"] for c in cs)
             mb = sum(c["hbm_MB"] * c["launches"] for c in cs) / n
@@ -345,7 +350,7 @@ def config2_problem():
     reg = S2_Wavelets_L1("synthesis", op.transform.inverse, op.transform.inverse_adjoint, LMDA * MU, L=C2_L, B=C2_B, J_min=C2_JMIN)
     delta, _ = stable_delta(op.transform, SIGMA, LMDA)
     params = PxMCMCParams(lmda=LMDA, delta=delta, mu=MU, nsamples=1, nburn=0, ngap=1, verbosity=0)
-    s = MYULA(op, reg, params, nchains=1, rng="philox", seed=1)
+    s = MYULA(op, reg, params, nchains=1, rng="philox", seed=1, noise_bits=64)
     s._prepare()
     with contextlib.redirect_stdout(io.StringIO()):
         X, preds = s._initial_sample(np.zeros(op.nparams))
@@ -453,7 +458,7 @@ def config5_leg(n_iter=150, nrep=10, pmc=None):
     # (nburn beyond the run: no save candidates, i.e. no per-iteration host synchronisation; max_iter bounds the run --
     # the reference's loop only ends on accepted samples)
     p = PxMCMCParams(nsamples=1, nburn=10 ** 9, ngap=1, delta=C5_DELTA0, lmda=lmda, mu=MU, verbosity=0, track=[])
-    s = PxMALA(op, reg, p, tune_delta=True, nchains=1, seed=3, max_iter=n_iter)
+    s = PxMALA(op, reg, p, tune_delta=True, nchains=1, seed=3, max_iter=n_iter, noise_bits=64)
     with contextlib.redirect_stdout(io.StringIO()):
         s.run(start_point=np.zeros(tr.ncoefs))
     assert s.niter == n_iter
@@ -473,6 +478,26 @@ def config5_leg(n_iter=150, nrep=10, pmc=None):
             "ring_gemm_us_per_iteration": gemm_us, "gemm_launch_classes": classes,
             "note": "four ring GEMMs per iteration (two spin-0 group launches on the 8 + 1 wavelet scales, two spin-2 launches on "
                     "unpaired tables) stream ~4.2 GB of tables for 2 live MFMA columns: the bound is the table stream"}
+
+
+PARITY_TOL = 1e-9  # full-size parity leg: max |X_hip - X_oracle| / max |X| after 3 iterations
+
+
+def leg_failures(out):
+    """what must turn the exit code red although the headline line is printed: a side leg that raised or produced
+    non-finite state, a parity leg beyond PARITY_TOL"""
+    bad = []
+    for name, leg in (out.get("configs") or {}).items():
+        if isinstance(leg, dict) and "error" in leg:
+            bad.append(f"{name}: {leg['error']}")
+        elif isinstance(leg, dict) and leg.get("finite") is False:
+            bad.append(f"{name}: non-finite state")
+    par = out.get("parity")
+    if par is not None:
+        err = par.get("max_rel_err_X")
+        if "error" in par or err is None or not (err <= PARITY_TOL):
+            bad.append(f"parity: {par.get('error', err)} (tolerance {PARITY_TOL})")
+    return bad
 
 
 def pmc_child(which):
@@ -504,7 +529,11 @@ def main():
     ap.add_argument("--no-layout-compare", action="store_true", help="skip the reference-layout side measurement")
     ap.add_argument("--no-live-traffic", action="store_true", help="roofline.traffic from profiles/pmc_summary.json instead of two rocprofv3 --pmc child passes")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the side legs of BASELINE configs[1] (L=64) and configs[4] (L=512 weak lensing)")
-    ap.add_argument("--no-f64-noise-leg", action="store_true", help="skip the second timing with the fp64 Box-Muller (value_f64_noise)")
+    ap.add_argument("--noise-bits", type=int, default=64, choices=(32, 64),
+                    help="Box-Muller arithmetic of the HEADLINE's Philox stream: 64 (default) = fp64 as the reference's randn "
+                         "(pxmcmc/mcmc.py:193); 32 = the f32 transcendental units.  The other one is timed as the side leg")
+    ap.add_argument("--no-noise-leg", "--no-f64-noise-leg", dest="no_noise_leg", action="store_true",
+                    help="skip the second timing with the other Box-Muller precision (value_f32_noise)")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # internal: body of the side legs' rocprofv3 --pmc passes
     args = ap.parse_args()
     if args.pmc_child:
@@ -526,9 +555,13 @@ def main():
     if single and not args.no_live_traffic and not args.no_cpu_baseline:
         live = live_traffic()
         if not args.no_config_legs:
-            legs_pmc, info = pmc_passes(["--pmc-child", "config2,config5"], timeout_s=200)
-            legs_pmc_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of the side legs' launches in this run ({info:.0f} s), "
-                             "joined on the workgroup count") if legs_pmc is not None else f"child passes failed: {info}"
+            # one pair of child passes PER LEG: launches of equal grid size from different problems never share a key
+            legs_pmc, notes = {}, []
+            for leg, which in (("configs[1]", "config2"), ("configs[4]", "config5")):
+                legs_pmc[leg], info = pmc_passes(["--pmc-child", which], timeout_s=200)
+                notes.append(f"{leg}: {info:.0f} s" if legs_pmc[leg] is not None else f"{leg}: child passes failed: {info}")
+            legs_pmc_note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of each side leg's launches in this run ("
+                             + "; ".join(notes) + "), joined on the workgroup count within the leg")
 
     import torch
     import torch.distributed as dist
@@ -536,6 +569,7 @@ def main():
     from pxmcmc_amd import distributed as D
 
     rank, local_rank, world = D.env_rank_world()
+    failures = []
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} started with WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -567,7 +601,7 @@ def main():
     params = PxMCMCParams(lmda=LMDA, delta=delta, mu=MU, nsamples=1, nburn=0, ngap=1, verbosity=0)
     first_chain, _ = D.shard_chains(world * C, rank, world)  # weak scaling: C chains per GPU
     sampler = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain,
-                    real_pairs=not args.no_real_pairs)
+                    real_pairs=not args.no_real_pairs, noise_bits=args.noise_bits)
     sampler._prepare()
     assert sampler._fused_wav, "the fused wavelet path must be the one benchmarked"
     with contextlib.redirect_stdout(io.StringIO()):
@@ -649,7 +683,8 @@ def main():
     ref_layout_rate = None
     if rank == 0 and world == 1 and eng["pairs"] and not args.no_layout_compare:
         sampler._engine_stop()
-        s2 = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain, real_pairs=False)
+        s2 = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain, real_pairs=False,
+                   noise_bits=args.noise_bits)
         s2._prepare()
         with contextlib.redirect_stdout(io.StringIO()):
             X2, P2 = s2._initial_sample(np.zeros(op.nparams))
@@ -662,12 +697,13 @@ def main():
         ref_layout_rate = C * args.steps / (time.perf_counter() - t1)
         s2._engine_stop()
 
-    # The same timed region with the STRICTLY fp64 noise stream (flag PXM_NOISE_F64: Box-Muller's log / sqrt / sincos in
-    # double precision, as the reference's np.random.randn, pxmcmc/mcmc.py:193): same library, same run, same counts.
-    f64_leg = None
-    if rank == 0 and world == 1 and not args.no_f64_noise_leg:
+    # The same timed region with the OTHER Box-Muller precision (headline: fp64 log / sqrt / sincos, as the reference's
+    # np.random.randn, pxmcmc/mcmc.py:193; side leg: the f32 transcendental units): same library, same run, same counts.
+    other_bits = 96 - args.noise_bits
+    noise_leg = None
+    if rank == 0 and world == 1 and not args.no_noise_leg:
         s3 = MYULA(op, reg, params, nchains=C, rng="philox", seed=2, chain_offset=first_chain,
-                   real_pairs=not args.no_real_pairs, noise_bits=64)
+                   real_pairs=not args.no_real_pairs, noise_bits=other_bits)
         s3._prepare()
         with contextlib.redirect_stdout(io.StringIO()):
             X3, P3 = s3._initial_sample(np.zeros(op.nparams))
@@ -692,9 +728,10 @@ def main():
         X3, _ = s3._engine_state()
         assert bool(torch.isfinite(X3.real).all())
         s3._engine_stop()
-        f64_leg = {"value": C * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
-                   "dft_kernel_avg_launch_us": d3ms * 1e3 / max(d3n, 1), "noise": NOISE_NOTES[64],
-                   "what": "the timed region repeated with MYULA(noise_bits=64): same library, same run, same warm-up and step counts"}
+        noise_leg = {"noise_bits": other_bits, "value": C * args.steps / dt3, "ms_per_step": dt3 / args.steps * 1e3,
+                     "dft_kernel_avg_launch_us": d3ms * 1e3 / max(d3n, 1), "noise": NOISE_NOTES[other_bits],
+                     "what": f"the timed region repeated with MYULA(noise_bits={other_bits}): same library, same run, same "
+                             "warm-up and step counts"}
         del s3, e3, p3
 
     config_legs = None
@@ -704,7 +741,7 @@ def main():
         for name, fn in (("configs[1]", config2_leg), ("configs[4]", config5_leg)):
             t1 = time.perf_counter()
             try:
-                config_legs[name] = fn(pmc=legs_pmc)
+                config_legs[name] = fn(pmc=(legs_pmc or {}).get(name))
             except Exception as exc:  # a side leg must never take the headline down with it
                 config_legs[name] = {"error": repr(exc)}
             config_legs[name]["leg_wall_s"] = time.perf_counter() - t1
@@ -771,11 +808,14 @@ def main():
                 "graph_iterations_per_replay": 2 * sampler._GRAPH_PAIRS if used_graph else 0,
                 "warmup_requested": args.warmup,
                 "clock_ramp_steps": args.ramp,
-                    "noise": NOISE_NOTES.get(ops.noise_bits(), "unknown"),
+                "noise_bits": args.noise_bits,
+                "noise": NOISE_NOTES[args.noise_bits],
             },
-            # the strictly-fp64 headline: the same region with the fp64 Box-Muller (null when the leg was skipped)
-            "value_f64_noise": f64_leg["value"] if f64_leg else None,
-            "f64_noise": f64_leg,
+            # both noise precisions by name: the headline `value` is the one of config.noise_bits (64 unless --noise-bits 32),
+            # the other is the side leg (null when skipped)
+            "value_f64_noise": value if args.noise_bits == 64 else (noise_leg["value"] if noise_leg else None),
+            "value_f32_noise": value if args.noise_bits == 32 else (noise_leg["value"] if noise_leg else None),
+            "noise_leg": noise_leg,
             # BASELINE configs[1] and configs[4] on this GPU, outside the headline's timed region
             "configs": config_legs,
             "roofline": {
@@ -822,15 +862,23 @@ def main():
             assert abs(s_norm2 / NOMINAL_S_NORM2 - 1.0) < 0.05, "the CPU legs' nominal ||S||^2 is off"
             # free full-size parity evidence on this box: the benchmarked step vs the oracle on the same noise
             if eng["pairs"]:
-                out["parity"] = {
-                    "max_rel_err_X": parity_leg(plan, data, reg.T_dev, T, delta),
-                    "what": "3 iterations of the benchmarked step (ring-space + Gram + real pairs, injected noise) vs the "
-                            "oracle's literal loop, chains 0 and 9, error relative to max |X|",
-                }
+                out["parity"] = {"what": "3 iterations of the benchmarked step (ring-space + Gram + real pairs, injected noise) "
+                                         "vs the oracle's literal loop, chains 0 and 9, error relative to max |X|",
+                                 "tolerance": PARITY_TOL}
+                try:
+                    out["parity"]["max_rel_err_X"] = parity_leg(plan, data, reg.T_dev, T, delta)
+                except Exception as exc:  # reported in the line AND in the exit code (leg_failures)
+                    out["parity"]["error"] = repr(exc)
             out["cpu_baseline"] = cpu
+        failures = leg_failures(out)
+        out["legs_ok"] = not failures
+        out["leg_failures"] = failures
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and failures:  # the headline line is out; a broken side leg or parity leg still turns the run red
+        print("bench.py: " + "; ".join(failures), file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

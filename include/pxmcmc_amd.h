@@ -46,6 +46,9 @@ int pxm_version(void);
  *   present  log / sqrt / sincos evaluated in double precision (branch-free polynomials, csrc/philox.h): deviates equal
  *            numpy's float64 evaluation of the same formulae to ~1e-15.
  * Both read the same Philox4x32-10 counter stream and the same uniforms: the two streams agree to ~1e-6. */
+#ifdef PXM_NOISE_F64
+#error "the -DPXM_NOISE_F64 build switch was removed: pass the flag PXM_NOISE_F64 per call (one library serves both precisions)"
+#endif
 #define PXM_NOISE_F64 16
 int pxm_noise_bits(void);
 /* Host-only (no GPU) check that every global address a launch of the plans' GEMM task lists and DFT groups can form

@@ -34,9 +34,9 @@ def philox4x32_10(ctr, key):
 
 
 def normal_pairs(seed, chain, index, it, bits=32):
-    """two N(0,1) draws per counter: arrays z0, z1 shaped like ``index``.  ``bits``: the Box-Muller precision of the
-    library under test (pxm_noise_bits): 32 = the f32 transcendental units of the default build, mirrored in float32;
-    64 = the -DPXM_NOISE_F64 build, evaluated here with numpy's own float64 log / sqrt / cos / sin."""
+    """two N(0,1) draws per counter: arrays z0, z1 shaped like ``index``.  ``bits``: the Box-Muller precision the
+    call under test selects: 32 = the f32 transcendental units (no flag), mirrored in float32; 64 = the launch-time flag
+    PXM_NOISE_F64 of the entry point (MYULA(noise_bits=64)), evaluated here with numpy's own float64 log / sqrt / cos / sin."""
     index = np.asarray(index, dtype=np.uint64)
     with np.errstate(over="ignore"):
         key = np.uint64(seed) + np.uint64(chain) * np.uint64(0x9E3779B97F4A7C15)

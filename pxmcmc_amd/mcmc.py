@@ -239,15 +239,10 @@ class PxMCMC:
 
     # ---- device status -----------------------------------------------------------------
     def _device_plans(self):
-        """every transform plan this sampler's operators launch kernels on"""
-        plans = []
-        tr, ms = getattr(self.forward, "transform", None), getattr(self.forward, "measurement", None)
-        for owner, names in ((tr, ("_plan",)), (ms, ("_sht0", "_sht2")), (self, ("_pair_plan",))):
-            for n in names:
-                pl = getattr(owner, n, None) if owner is not None else None
-                if pl is not None and hasattr(pl, "raise_on_fault") and getattr(pl, "_h", None):
-                    plans.append(pl)
-        return plans
+        """every live transform plan of this process (``ops.live_plans``: a weak registry filled at plan creation) --
+        the operators' own plans AND those owned by a prior built on another transform object, by user operators or by
+        analysis-setting transforms under any attribute name"""
+        return ops.live_plans()
 
     def _check_device_status(self):
         """Fail loudly (PxmError) if a kernel reported an expired bounded wait since the last check -- called where the
@@ -843,6 +838,9 @@ class PxMALA(MYULA):
         self.delta_dev = delta_dev
         self._check_device_status()
         self.X_curr, self.curr_preds, self.niter = X_curr, curr_preds, i
+        # rows of chain / logPi / ... beyond nsaved[c] were never written (zeros): a ``max_iter`` stop says so
+        self.nsaved = j.copy() if C > 1 else int(j[0])
+        self.stopped_early = bool(j.min() < self.nsamples)
         print("\nDONE")
 
     def _tune_delta(self, i):

@@ -7,6 +7,7 @@ float64 or complex128; outputs are fresh tensors (the reference never mutates in
 SURVEY.md section 8b).
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -372,6 +373,14 @@ class CsrMatrix:
 
 
 # ---- transform plans -------------------------------------------------------------------
+_LIVE_PLANS = weakref.WeakSet()  # every ShtPlan / WavPlan with a live handle, whoever owns it (prior, user operator, ...)
+
+
+def live_plans():
+    """the plans of this process that still hold a device handle: what a sampler polls for expired bounded waits"""
+    return [pl for pl in list(_LIVE_PLANS) if getattr(pl, "_h", None)]
+
+
 class ShtPlan:
     """MW spin spherical-harmonic transforms at bandlimit L (replaces the pyssht calls)."""
 
@@ -382,6 +391,7 @@ class ShtPlan:
         h = C.c_void_p()
         check(lib.pxm_sht_plan_create(self.L, self.spin, self.max_chains, 0, C.byref(h)))
         self._h = h
+        _LIVE_PLANS.add(self)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -435,6 +445,7 @@ class WavPlan:
         h = C.c_void_p()
         check(lib.pxm_wav_plan_create(self.L, self.B, self.J_min, self.max_chains, 0, C.byref(h)))
         self._h = h
+        _LIVE_PLANS.add(self)
 
     def __del__(self):
         h = getattr(self, "_h", None)

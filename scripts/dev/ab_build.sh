@@ -17,7 +17,7 @@ for ent in "${LIBS[@]}"; do
   python - "$ent" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab/b.json"))
-print(sys.argv[1], "| f32 ms", round(d["ms_per_step"], 4), "dft", round(d["dft_kernel"]["avg_launch_us"], 1), "| f64 ms",
-      round(d["f64_noise"]["ms_per_step"], 4), "dft64", round(d["f64_noise"]["dft_kernel_avg_launch_us"], 1))
+print(sys.argv[1], "| f64 (headline) ms", round(d["ms_per_step"], 4), "dft", round(d["dft_kernel"]["avg_launch_us"], 1), "| f32 ms",
+      round(d["noise_leg"]["ms_per_step"], 4), "dft32", round(d["noise_leg"]["dft_kernel_avg_launch_us"], 1))
 PY
 done

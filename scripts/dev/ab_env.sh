@@ -2,7 +2,7 @@
 #   bash scripts/dev/ab_env.sh "PXM_X=0" "PXM_GEMM_VALU=1"
 mkdir -p gpurun_out/ab
 for kv in "$@"; do
-  env "$kv" python bench.py --no-config-legs --no-cpu-baseline --no-layout-compare --no-f64-noise-leg --steps 1000 > gpurun_out/ab/e.json 2> gpurun_out/ab/e.err || { echo "$kv: bench failed"; tail -3 gpurun_out/ab/e.err; continue; }
+  env "$kv" python bench.py --no-config-legs --no-cpu-baseline --no-layout-compare --no-noise-leg --steps 1000 > gpurun_out/ab/e.json 2> gpurun_out/ab/e.err || { echo "$kv: bench failed"; tail -3 gpurun_out/ab/e.err; continue; }
   python - "$kv" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab/e.json"))

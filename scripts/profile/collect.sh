@@ -12,9 +12,10 @@ set -o pipefail
 WHAT=${1:?what: bench | sq | config5 | any}
 TAG=${2:?tag}
 shift 2
-OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
-ROOT=$GRAFT_REPO_ROOT
-BENCH_FLAGS="--no-cpu-baseline --no-layout-compare --no-config-legs --no-f64-noise-leg"
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+[ -f "$ROOT/bench.py" ] || { echo "collect.sh: $ROOT/bench.py not found (run from the repo root or set GRAFT_REPO_ROOT)" >&2; exit 2; }
+OUT=$ROOT/gpurun_out/$TAG
+BENCH_FLAGS="--no-cpu-baseline --no-layout-compare --no-config-legs --no-noise-leg"
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 case $WHAT in

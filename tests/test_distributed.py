@@ -161,6 +161,81 @@ def test_bench_self_launch_command_is_a_child_torchrun(monkeypatch):
     assert e.value.code == 5
 
 
+RANKS8_WORKER = textwrap.dedent(
+    """
+    import json, os, sys
+    sys.path.insert(0, os.environ["PXM_ROOT"])
+    from pxmcmc_amd import distributed as D
+
+    rank, local_rank, world = D.init(backend="gloo")
+    assert world == 8 and local_rank == rank
+    first, count = D.shard_chains(world * 16, rank, world)   # bench.py: 16 chains per GPU, weak scaling
+    assert (first, count) == (16 * rank, 16)
+    D.barrier()
+    dt = D.max_over_ranks(0.001 * (1 + rank))
+    per_rank = D.all_gather_float(0.001 * (1 + rank))
+    seen = D.count_ranks()
+    D.barrier()
+    if rank == 0:
+        print(json.dumps({"ranks_seen": seen, "max": dt, "per_rank": per_rank}), flush=True)
+    """
+)
+
+
+def test_eight_rank_rendezvous_through_bench_self_launch(tmp_path, capfd):
+    """The driver's N = 8 launch shape on CPU: `bench.self_launch(8, ...)` -- the same child `torch.distributed.run`
+    command, free-port choice and environment `python bench.py --gpus 8` uses -- starts eight gloo ranks that run every
+    torch.distributed call of the benchmark (init from the torchrun environment, chain sharding, barrier, MAX
+    all-reduce, the all-gathered per-rank times, the rank count).  (Eight ranks on the ONE test GPU are not started:
+    the GPU box allows six processes on its card.)"""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench_mod8", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    script = tmp_path / "ranks8_worker.py"
+    script.write_text(RANKS8_WORKER)
+    old = {k: os.environ.get(k) for k in ("PXM_ROOT", "RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    os.environ["PXM_ROOT"] = ROOT
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    try:
+        rc = bench.self_launch(8, [], script=str(script))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    outerr = capfd.readouterr()
+    assert rc == 0, outerr.out[-2000:] + outerr.err[-3000:]
+    line = [ln for ln in outerr.out.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    out = json.loads(line[0])
+    assert out["ranks_seen"] == 8 and abs(out["max"] - 0.008) < 1e-12
+    assert np.allclose(out["per_rank"], 0.001 * np.arange(1, 9))
+
+
+def test_bench_leg_failures_turn_the_exit_code_red():
+    """bench.leg_failures: a side leg that raised, a non-finite leg or a parity error beyond the tolerance is listed
+    (=> `legs_ok: false`, exit code 3 after the JSON line); a clean record is not."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_modf", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ok = {"configs": {"pmc_source": "x", "configs[1]": {"finite": True}, "configs[4]": {"finite": True}},
+          "parity": {"max_rel_err_X": 3e-15}}
+    assert bench.leg_failures(ok) == [] and bench.leg_failures({"configs": None}) == []
+    bad = {"configs": {"pmc_source": "x", "configs[1]": {"error": "RuntimeError('boom')"}, "configs[4]": {"finite": False}},
+           "parity": {"max_rel_err_X": 2e-9}}
+    msgs = bench.leg_failures(bad)
+    assert len(msgs) == 3 and "boom" in msgs[0] and "configs[4]" in msgs[1] and "parity" in msgs[2]
+    assert len(bench.leg_failures({"parity": {"error": "x"}})) == 1
+    assert len(bench.leg_failures({"parity": {"max_rel_err_X": float("nan")}})) == 1
+
+
 def test_bench_timed_region_holds_no_collective():
     """bench.py's clock: `t0` right after the start barrier, `dt_rank` right after the rank's own device synchronise --
     no torch.distributed call (barrier, all-reduce, gather) between the two (the chains never cross ranks,
@@ -204,7 +279,9 @@ def test_bench_gpus2_self_launch_rehearsal(nranks):
     assert abs(max(per_rank) - out["ms_per_step"]) <= 1e-9 * out["ms_per_step"]
     assert out["barrier_us"] > 0
     assert abs(out["value"] - 16 * nranks * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
-    assert out["value_f64_noise"] is None and out["configs"] is None  # the side legs run at N = 1 only
+    assert out["noise_leg"] is None and out["value_f32_noise"] is None and out["configs"] is None  # side legs: N = 1 only
+    assert out["config"]["noise_bits"] == 64 and out["value_f64_noise"] == out["value"]  # headline = the fp64 noise stream
+    assert out["legs_ok"] is True and out["leg_failures"] == []
 
 
 RCCL_WORKER = textwrap.dedent(
