@@ -88,3 +88,157 @@ def test_pxmala_max_iter_stop_is_flagged():
     with contextlib.redirect_stdout(io.StringIO()):
         s2.run(start_point=np.zeros(n))
     assert not s2.stopped_early and s2.nsaved == 3
+
+
+# ---- G14: the HIP path against vectors the REFERENCE's own wavelet-path classes produced -----------------------------
+def _quiet(fn, **kw):
+    import warnings
+
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return fn(**kw)
+
+
+def _close(a, b, tol):
+    import torch
+
+    a = a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+    assert err <= tol, err
+
+
+@pytest.fixture(params=[10, 16], scope="module")
+def g14(request):
+    from conftest import golden
+
+    return golden(f"g14_wavelet_path_L{request.param}.npz")
+
+
+def test_g14_hip_transform_weaklensing_operator_prior(g14):
+    """HIP SphericalWaveletTransform / WeakLensing / SphericalWaveletTransformOperator / S2_Wavelets_L1 against the outputs
+    of the reference's own classes (pxmcmc/transforms.py:102-166, measurements.py:221-240, forward.py:91-123,
+    prior.py:67-84) run over the oracle-backed pys2let / pyssht stub (tests/golden/make_golden_r5.py)."""
+    from pxmcmc_amd.forward import ForwardOperator, SphericalWaveletTransformOperator
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    g = g14
+    L, B, J = int(g["L"]), int(g["B"]), int(g["J_min"])
+    P = L * (2 * L - 1)
+    tr = SphericalWaveletTransform(L, B, J)
+    nscal, nwav, ncoefs, J_max, nscales = (int(v) for v in g["sizes"])
+    assert (tr.nscal, tr.nwav, tr.ncoefs, tr.J_max, tr.nscales) == (nscal, nwav, ncoefs, J_max, nscales)
+    for tag, X, f in (("c", g["Xc"], g["fc"]), ("r", g["Xr"], g["fr"])):
+        _close(tr.forward(f), g[f"tr_forward_{tag}"], 1e-11)
+        _close(tr.inverse(X), g[f"tr_inverse_{tag}"], 1e-11)
+        _close(tr.inverse_adjoint(f), g[f"tr_inverse_adjoint_{tag}"], 1e-11)
+        _close(tr.forward_adjoint(X), g[f"tr_forward_adjoint_{tag}"], 1e-11)
+    wl = WeakLensing(L, g["wl_mask"], ngal=g["wl_ngal"])
+    _close(wl.inv_cov, g["wl_inv_cov"], 1e-15)
+    _close(wl.forward(g["wl_kappa"]), g["wl_forward"], 1e-11)
+    _close(wl.adjoint(g["wl_gamma"]), g["wl_adjoint"], 1e-11)
+    wl0 = WeakLensing(L)
+    _close(wl0.forward(g["wl_kappa"]), g["wl0_forward"], 1e-11)
+    _close(wl0.adjoint(g["wl_kappa"]), g["wl0_adjoint"], 1e-11)
+    sig = float(g["sig"])
+    for tag in "rc":
+        for setting, x in (("synthesis", g["Xc"]), ("analysis", g["fc"])):
+            op = SphericalWaveletTransformOperator(g[f"data_{tag}"], sig, setting, L, B, J)
+            assert op.nparams == int(g[f"op_{tag}_{setting}_nparams"])
+            _close(op.forward(x), g[f"op_{tag}_{setting}_forward"], 1e-11)
+            _close(op.calc_gradg(g[f"op_{tag}_{setting}_forward"]), g[f"op_{tag}_{setting}_gradg"], 1e-11)
+    lmda, mu = g["reg_params"]
+    reg = S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, lmda * mu, L=L, B=B, J_min=J)
+    _close(reg.map_weights, g["reg_map_weights"], 1e-13)
+    _close(reg.T, g["reg_T"], 1e-13)
+    _close(reg.prior(g["Xc"]), g["reg_prior_c"], 1e-12)
+    _close(reg.prior(g["Xr"]), g["reg_prior_r"], 1e-12)
+    _close(reg.proxf(g["Xc"] * 1e-3), g["reg_proxf_c"], 1e-13)
+    _close(reg.proxf(g["Xr"] * 1e-3), g["reg_proxf_r"], 1e-13)
+    # fused wavelet + weak-lensing operator and its unfused composition (experiments/weaklensing/main.py:98-105)
+    for fuse in (True, False):
+        op = ForwardOperator(g["wlop_data"], 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+        op.fuse_weaklensing = fuse
+        _close(op.forward(g["Xc"] * 1e-2), g["wlop_forward"], 1e-11)
+        _close(op.calc_gradg(g["wlop_forward"]), g["wlop_gradg"], 1e-11)
+
+
+def test_g14_hip_myula_on_wavelets(g14):
+    """HIP MYULA.run on the reference's numpy MT19937 stream (rng="numpy") against the reference's own seeded MYULA.run on
+    its SphericalWaveletTransformOperator + S2_Wavelets_L1 (pxmcmc/mcmc.py:150-183): real data, then params.complex."""
+    from pxmcmc_amd.forward import SphericalWaveletTransformOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMCMCParams
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+
+    g = g14
+    L, B, J = int(g["L"]), int(g["B"]), int(g["J_min"])
+    op = SphericalWaveletTransformOperator(g["data_r"], float(g["sig"]), "synthesis", L, B, J)
+    tr = op.transform
+    track = ["logposterior", "L2", "prior", "chain", "predictions"]
+    lmda, delta, mu, ns, nb, ng, seed = g["my_params"]
+    reg = S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, lmda * mu, L=L, B=B, J_min=J)
+    for fused in (True, False):
+        p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=int(ns), nburn=int(nb), ngap=int(ng), verbosity=0, track=track)
+        s = MYULA(op, reg, p, rng="numpy")
+        if not fused:
+            s._fusable_wavelet = lambda: False  # the reference's four-call order on the unfused kernels
+        np.random.seed(int(seed))
+        _quiet(s.run, start_point=g["my_X0"].copy())
+        _close(s.chain, g["my_chain"], 1e-9)
+        _close(s.logPi, g["my_logPi"], 1e-9)
+        _close(s.L2s, g["my_L2s"], 1e-9)
+        _close(s.priors, g["my_priors"], 1e-9)
+        _close(s.preds, g["my_preds"], 1e-9)
+    lmda, delta, mu, ns, nb, ng, seed = g["myc_params"]
+    p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=int(ns), nburn=int(nb), ngap=int(ng), verbosity=0, complex=True)
+    s = MYULA(op, reg, p, rng="numpy")
+    np.random.seed(int(seed))
+    _quiet(s.run, start_point=g["my_X0"].astype(complex))
+    assert np.iscomplexobj(s.chain)
+    _close(s.chain, g["myc_chain"], 1e-9)
+    _close(s.logPi, g["myc_logPi"], 1e-9)
+    _close(s.priors, g["myc_priors"], 1e-9)
+
+
+def test_g14_hip_samplers_on_wavelets_and_weaklensing(g14):
+    """HIP MYULA.run and PxMALA.run (tune_delta) on ForwardOperator(SphericalWaveletTransform, WeakLensing) with complex
+    data and sig_d = 1 / inv_cov (experiments/weaklensing/main.py:91-147 in small) against the reference's own seeded runs,
+    incl. acceptance_trace and deltas_trace (pxmcmc/mcmc.py:218-279)."""
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.mcmc import MYULA, PxMALA, PxMCMCParams
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.prior import S2_Wavelets_L1
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    g = g14
+    L, B, J = int(g["L"]), int(g["B"]), int(g["J_min"])
+    tr = SphericalWaveletTransform(L, B, J)
+    wl = WeakLensing(L, g["wl_mask"], ngal=g["wl_ngal"])
+    op = ForwardOperator(g["wlop_data"], 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+    track = ["logposterior", "L2", "prior", "chain", "predictions"]
+    lmda, delta, mu, ns, nb, ng, seed = g["wlmy_params"]
+    reg = S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, lmda * mu, L=L, B=B, J_min=J)
+    p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=int(ns), nburn=int(nb), ngap=int(ng), verbosity=0, track=track)
+    s = MYULA(op, reg, p, rng="numpy")
+    np.random.seed(int(seed))
+    _quiet(s.run, start_point=np.zeros(tr.ncoefs))
+    _close(s.chain, g["wlmy_chain"], 1e-9)
+    _close(s.logPi, g["wlmy_logPi"], 1e-9)
+    _close(s.L2s, g["wlmy_L2s"], 1e-9)
+    _close(s.priors, g["wlmy_priors"], 1e-9)
+    _close(s.preds, g["wlmy_preds"], 1e-9)
+    lmda, delta, mu, ns, nb, ng, seed = g["px_params"]
+    p = PxMCMCParams(lmda=lmda, delta=delta, mu=mu, nsamples=int(ns), nburn=int(nb), ngap=int(ng), verbosity=0, track=track)
+    s = PxMALA(op, reg, p, tune_delta=True, rng="numpy")
+    np.random.seed(int(seed))
+    _quiet(s.run, start_point=np.zeros(tr.ncoefs))
+    assert list(s.acceptance_trace) == list(g["px_acc"])
+    _close(s.deltas_trace, g["px_deltas"], 1e-12)
+    _close(s.chain, g["px_chain"], 1e-9)
+    _close(s.logPi, g["px_logPi"], 1e-9)
+    _close(s.L2s, g["px_L2s"], 1e-9)
+    _close(s.priors, g["px_priors"], 1e-9)
+    _close(s.preds, g["px_preds"], 1e-9)
