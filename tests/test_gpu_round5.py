@@ -59,6 +59,7 @@ def test_live_plan_registry_sees_plans_owned_by_anyone():
     assert len(live) == before + 2 and all(any(p is q for q in live) for p in holder.values())
     for p in live:
         p.raise_on_fault()  # nothing expired
+    del live, p
     holder.clear()
     gc.collect()
     assert len(ops.live_plans()) == before
