@@ -91,12 +91,24 @@ int pxm_mw_ring_weights(int L, double* q);
 /* dense per-m ring tables for tests (small L): Binv[t*L+el] = (-1)^s N_el d^el_{m,-s}(theta_t),
  * Afwd[el*L+t] = exact-quadrature forward matrix; either pointer may be NULL */
 int pxm_host_sht_tables(int L, int spin, int m, double* Binv, double* Afwd);
+/* the same Binv[t*L+el] as the table-free recursion kernels generate it (csrc/rec_core.h: three-term recursion in el in
+ * double precision on a per-ring scaled state; host emulation, operation for operation): what pyssht.inverse /
+ * inverse_adjoint (pxmcmc/measurements.py:225,237) multiply by when a plan takes the recursion path */
+int pxm_host_rec_table(int L, int spin, int m, double* Brec);
 
 /* ---- spin spherical-harmonic transforms on the MW grid ---------------------- */
 /* replaces pyssht.forward / inverse / inverse_adjoint / forward_adjoint
  * (pxmcmc/measurements.py:223,225,237,239).  flm: [C][L*L] c128, f: [C][L*(2L-1)] c128. */
 int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht_plan_t* plan);
 int pxm_sht_plan_destroy(pxm_sht_plan_t plan);
+/* Non-zero when the plan's inverse / inverse_adjoint (pyssht.inverse / inverse_adjoint, pxmcmc/measurements.py:225,237) run the
+ * table-free ring stage -- Wigner rows by three-term recursion in el on the vector pipe, csrc/sht_rec.hip -- instead of the
+ * ring-table GEMM: 16 * (ring blocks per wavefront) + (complex columns per order).  Chosen at plan creation: few-column
+ * plans at large L; PXM_REC=1 / 0 forces it on (where the column count allows) / off. */
+int pxm_sht_uses_recursion(pxm_sht_plan_t plan);
+/* self-test of the wavefront transpose-reduce of the ring -> el recursion kernel: out128[lane] = the sum the lane holds for
+ * 16 known per-lane values, out128[64 + lane] = the id of the value it claims to hold (test aid) */
+int pxm_rec_reduce_selftest(double* out128);
 int pxm_sht_inverse(pxm_sht_plan_t plan, const void* flm, void* f, int C, pxm_stream_t stream);
 int pxm_sht_forward(pxm_sht_plan_t plan, const void* f, void* flm, int C, pxm_stream_t stream);
 int pxm_sht_inverse_adjoint(pxm_sht_plan_t plan, const void* f, void* flm, int C, pxm_stream_t stream);

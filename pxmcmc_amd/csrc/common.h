@@ -70,6 +70,8 @@ void tiling_axisym(int L, double B, int J_min, std::vector<double>& kappa0, std:
 void mw_ring_weights(int L, double* q);
 // B^m[t][el] = (-1)^s sqrt((2el+1)/4pi) d^el_{m,-s}(theta_t), written with leading dimension ld (>= L)
 void wigner_ring_table(int L, int spin, int m, double* out, int ld);
+// the same table as the recursion kernels (csrc/sht_rec.hip) generate it: double precision, scaled state (rec_core.h)
+void rec_emulate_table(int L, int spin, int m, double* out, int ld);
 // Q^{par}[t'][t] (L x L, leading dimension ld): MW exact-quadrature Gram matrix, par = +1 / -1
 void quadrature_gram(int L, int par, double* Q, int ld);
 

@@ -261,4 +261,11 @@ int pxm_host_sht_tables(int L, int spin, int m, double* Binv, double* Afwd) {
   return 0;
 }
 
+
+int pxm_host_rec_table(int L, int spin, int m, double* Brec) {
+  PXM_REQUIRE(L >= 1 && std::abs(m) < L && Brec, "pxm_host_rec_table: need |m| < L and an output array");
+  pxm::rec_emulate_table(L, spin, m, Brec, L);
+  return 0;
+}
+
 }  // extern "C"

@@ -2,6 +2,7 @@
 #include "../../include/pxmcmc_amd.h"
 #include "elem.h"
 #include "sht_core.h"
+#include "sht_rec.h"
 
 #include <algorithm>
 #include <cmath>
@@ -174,6 +175,15 @@ static void free_tasks(TaskList* t) {
 
 static inline int64_t arr_size(int L, int ncol) { return (int64_t)(2 * L - 1) * round_up(L, 16) * ncol; }
 
+// Does a plan of this size take the table-free ring stage (sht_rec.hip) for its B-table contractions?  PXM_REC=1: wherever the
+// column count allows (tests run both paths at small L); PXM_REC=0: never; unset: few-column launches at large L, where the
+// table stream feeds a fraction of an MFMA tile.
+static bool rec_wanted(int L, int spin, int max_chains) {
+  if (!rec_supported(spin, max_chains)) return false;
+  if (const char* e = std::getenv("PXM_REC")) return std::atoi(e) != 0 && L >= 3;
+  return false;
+}
+
 }  // namespace pxm
 
 using namespace pxm;
@@ -184,6 +194,7 @@ using namespace pxm;
 struct pxm_sht_plan_s {
   int L = 0, spin = 0, Cmax = 0, Cp = 0, ncol = 0, Rp = 0;
   ShtTables* T = nullptr;
+  RecTables* rec = nullptr;  // table-free ring stage of inverse / inverse_adjoint (sht_rec.hip), when the plan takes it
   DftPlan dft;
   double* ws = nullptr;  // [G | H | scratch]
   int64_t offG = 0, offH = 0, offS = 0;
@@ -249,6 +260,7 @@ int pxm_sht_plan_create(int L, int spin, int max_chains, unsigned flags, pxm_sht
     rc = upload_tasks(v, p->T->paired, &p->tl[k], {L}, p->ncol, p->ws, "SHT stage");
     if (rc) return rc;
   }
+  if (rec_wanted(L, spin, max_chains) && (rc = rec_tables_create(L, spin, max_chains, p->Rp, p->ncol, &p->rec))) return rc;
   *plan = guard.release();
   return 0;
 }
@@ -260,6 +272,7 @@ int pxm_sht_plan_destroy(pxm_sht_plan_t p) {
   deferred_free(p->d_status);
   for (int k = 0; k < 4; ++k) free_tasks(&p->tl[k]);
   release_tables(p->T);
+  rec_tables_destroy(p->rec);
   delete p;
   drain_deferred();  // (a no-op while a stream capture is in progress: freed at the next safe point)
   return 0;
@@ -281,7 +294,8 @@ static int sht_el_to_ring(pxm_sht_plan_t p, int kind, const void* flm, void* f, 
   note_stream(st);
   int rc = launch_lm_to_mel((const double*)flm, p->ws + p->offH, p->L, p->Rp, p->ncol, C, p->spin, st);
   if (rc) return rc;
-  rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, C, st);
+  if (p->rec && kind == TAB_INV) rc = rec_launch_e2r(*p->rec, p->ws + p->offH, nullptr, nullptr, p->ws + p->offG, C, st);
+  else rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, C, st);
   if (rc) return rc;
   PxOut out;
   out.f = (double*)f;
@@ -296,7 +310,8 @@ static int sht_ring_to_el(pxm_sht_plan_t p, int kind, const void* f, void* flm, 
   in.chain_stride = (int64_t)p->L * (2 * p->L - 1);
   int rc = launch_px2ring(p->dft, in, p->ws + p->offG, p->ncol, C, st);
   if (rc) return rc;
-  rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, C, st);
+  if (p->rec && kind == TAB_INV_ADJ) rc = rec_launch_r2e(*p->rec, p->ws + p->offG, nullptr, p->ws + p->offH, C, st);
+  else rc = run_tasks(p->tl[kind], p->ws, p->ws, p->ncol, C, st);
   if (rc) return rc;
   return launch_mel_to_lm(p->ws + p->offH, (double*)flm, p->L, p->Rp, p->ncol, C, p->spin, st);
 }
@@ -321,6 +336,17 @@ int pxm_sht_inverse_adjoint(pxm_sht_plan_t p, const void* f, void* flm, int C, p
 int pxm_sht_status(pxm_sht_plan_t p, int clear, pxm_stream_t stream) {
   PXM_REQUIRE(p, "pxm_sht_status: null plan");
   return status_read(p->d_status, (hipStream_t)stream, clear);
+}
+
+int pxm_sht_uses_recursion(pxm_sht_plan_t p) {
+  PXM_REQUIRE(p, "pxm_sht_uses_recursion: null plan");
+  return p->rec ? p->rec->R * 16 + p->rec->NC : 0;
+}
+
+int pxm_rec_reduce_selftest(double* out128) {
+  PXM_REQUIRE(out128, "pxm_rec_reduce_selftest: null output");
+  PXM_REQUIRE(pxm_device_count() > 0, "pxm_rec_reduce_selftest: no HIP device visible");
+  return rec_reduce_selftest(out128);
 }
 
 int64_t pxm_sht_table_bytes(pxm_sht_plan_t p, int op) {

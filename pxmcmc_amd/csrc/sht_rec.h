@@ -1,0 +1,37 @@
+// Table-free ring stage (csrc/sht_rec.hip, csrc/rec_core.h): device tables and launches.
+#pragma once
+#include "sht_core.h"
+
+namespace pxm {
+
+struct RecTables {
+  int L = 0, spin = 0, Lp = 0, Tp = 0, n_m = 0, Rp = 0, ncol = 0;
+  bool paired = false;
+  int C = 0;    // chains the plan carries at most
+  int NC = 0;   // complex columns per stored order: C (all m stored) or 2 C (+-m pairs)
+  int R = 0;    // ring blocks of 64 rings per wavefront
+  int NW = 0;   // wavefronts per workgroup
+  int n_units = 0;
+  double *d_coefN = nullptr, *d_coefS = nullptr, *d_g = nullptr, *d_seed = nullptr, *d_zeta = nullptr, *d_hs = nullptr;
+  int *d_units = nullptr, *d_wdesc = nullptr;
+  size_t bytes = 0;
+};
+
+// C <= 4 chains at spin != 0, <= 2 at spin 0 (1, 2 or 4 complex columns per stored order); arrays in the plan's G / H layout
+int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out);
+void rec_tables_destroy(RecTables* T);
+inline bool rec_supported(int spin, int C) {
+  const int nc = C * (spin == 0 ? 2 : 1);
+  return nc == 1 || nc == 2 || nc == 4;
+}
+// G = B (ks .* (X + X2)):  X, X2 harmonic-side arrays (H layout), ks per-el scale or null, Y ring-side array (G layout)
+int rec_launch_e2r(const RecTables& T, const double* X, const double* X2, const double* ks, double* Y, int C, hipStream_t st,
+                   Profiler* prof = nullptr);
+// H = rs .* (B^T G):  Y ring-side array, rs per-el output scale or null, Xout harmonic-side array
+int rec_launch_r2e(const RecTables& T, const double* Y, const double* rs, double* Xout, int C, hipStream_t st,
+                   Profiler* prof = nullptr);
+double rec_alg_bytes(const RecTables& T, int C);
+double rec_alg_flops(const RecTables& T, bool e2r);
+int rec_reduce_selftest(double* host_out128);
+
+}  // namespace pxm

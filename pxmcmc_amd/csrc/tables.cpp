@@ -6,6 +6,7 @@
 // pys2let 2.2.6, which are not in its tree): McEwen & Wiaux 2011 (MW sampling,
 // weights w(m') as in pxmcmc/utils.py:249-259), Leistedt et al. 2013 (tiling).
 #include "common.h"
+#include "rec_core.h"
 
 #include <cmath>
 #include <complex>
@@ -132,6 +133,103 @@ void wigner_ring_table(int L, int spin, int m, double* out, int ld) {
       prev = cur;
       cur = nxt;
       row[l] = (double)(nrm[l] * cur);
+    }
+  }
+}
+
+// ---- table-free ring stage (rec_core.h): coefficients, normalisation and scaled seeds of one order ----------------
+void rec_ring_zeta(int L, double* zeta, int* north, int Tp) {
+  const int n = 2 * L - 1;
+  for (int t = 0; t < Tp; ++t) {
+    const long double th = PI_L * (2 * std::min(t, L - 1) + 1) / n;
+    const bool nh = 2 * (2 * t + 1) < n;  // theta_t < pi / 2 (padding rings: whatever)
+    const long double s = sinl(th / 2), c = cosl(th / 2);
+    north[t] = nh ? 1 : 0;
+    zeta[t] = t < L ? (double)(nh ? -2 * s * s : 2 * c * c) : 0.0;
+  }
+}
+
+void rec_order_tables(int L, int spin, int m, double* alpha, double* An, double* As, double* g, int Lp, double* seed_y,
+                      double* seed_sc, int Tp, RecOrder* info) {
+  const int nn = -spin;
+  const int el0 = std::max(std::abs(m), std::abs(nn));
+  const int n = 2 * L - 1;
+  for (int l = 0; l < Lp; ++l) alpha[l] = An[l] = As[l] = g[l] = 0.0;
+  for (int t = 0; t < Tp; ++t) seed_y[t] = seed_sc[t] = 0.0;
+  if (info) info->el0 = el0;
+  if (el0 >= L) return;
+  const long double mm = m, nl = nn;
+  auto N = [](int l) { return sqrtl((2.0L * l + 1) / (4 * PI_L)); };
+  // b_{l+1} = a_l (x - q_l) b_l - c_l b_{l-1}  (the recursion of wigner_ring_table with the norms folded in), then
+  // b_l = g_l y_l with g_{l+1} = c_l g_{l-1}:  y_{l+1} = alpha_l (x - q_l) y_l - y_{l-1},  alpha_l = a_l g_l / g_{l+1}
+  std::vector<long double> gl(L + 1, 0.0L);
+  gl[el0] = 1;
+  if (el0 + 1 <= L) gl[el0 + 1] = 1;
+  for (int l = el0; l < L; ++l) {
+    long double a, qq, c;
+    if (l == 0) {  // only (m, nn) = (0, 0): P_1 = x P_0
+      a = N(1) / N(0);
+      qq = 0;
+      c = 0;
+    } else {
+      const long double ll = l, lp = l + 1;
+      const long double D = sqrtl((lp * lp - mm * mm) * (lp * lp - nl * nl));
+      a = (N(l + 1) / N(l)) * (2 * ll + 1) * lp / D;
+      qq = mm * nl / (ll * lp);
+      c = l > el0 ? (N(l + 1) / N(l - 1)) * lp * sqrtl((ll * ll - mm * mm) * (ll * ll - nl * nl)) / (ll * D) : 0.0L;
+    }
+    if (l > el0) gl[l + 1] = c * gl[l - 1];
+    const long double al = a * gl[l] / gl[l + 1];
+    alpha[l] = (double)al;
+    An[l] = (double)(al * (1 - qq));
+    As[l] = (double)(-al * (1 + qq));
+  }
+  for (int l = el0; l < L; ++l) g[l] = (double)gl[l];
+  // seeds: the explicit sum for d^{el0}_{m nn} has the single term k = max(0, nn - m) (as in wigner_ring_table)
+  const int k = std::max(0, nn - m);
+  const int pc = 2 * el0 + nn - m - 2 * k, ps = m - nn + 2 * k;
+  const long double sgn = ((m - nn + k) % 2) ? -1.0L : 1.0L;
+  const int a0 = (el0 == std::abs(m)) ? nn : m;
+  const long double coef =
+      sgn * expl(0.5L * (lgammal(2.0L * el0 + 1) - lgammal((long double)el0 + a0 + 1) - lgammal((long double)el0 - a0 + 1)));
+  const long double sfac = (spin % 2) ? -1.0L : 1.0L;
+  for (int t = 0; t < L; ++t) {
+    const long double th = PI_L * (2 * t + 1) / n;
+    long double v = sfac * N(el0) * coef;
+    if (pc) v *= powl(cosl(th / 2), pc);
+    if (ps) v *= powl(sinl(th / 2), ps);
+    if (v == 0) continue;
+    int e;
+    (void)frexpl(v, &e);
+    // |y| = |v| 2^(-REC_S sc) with the exponent of y in (64 - REC_S, 64]: sc = 0 for every value a double holds well
+    int sc = 0;
+    while (e - REC_S * sc <= 64 - REC_S) --sc;
+    seed_y[t] = (double)ldexpl(v, -REC_S * sc);
+    seed_sc[t] = (double)sc;
+  }
+}
+
+// the device algorithm in double precision on the host: the table the recursion kernels effectively apply
+void rec_emulate_table(int L, int spin, int m, double* out, int ld) {
+  const int Lp = L + 8, Tp = L;
+  std::vector<double> al(Lp), An(Lp), As(Lp), g(Lp), sy(Tp), ss(Tp), zeta(Tp);
+  std::vector<int> north(Tp);
+  RecOrder info;
+  rec_order_tables(L, spin, m, al.data(), An.data(), As.data(), g.data(), Lp, sy.data(), ss.data(), Tp, &info);
+  rec_ring_zeta(L, zeta.data(), north.data(), Tp);
+  for (int t = 0; t < L; ++t) {
+    double* row = out + (size_t)t * ld;
+    for (int l = 0; l < L; ++l) row[l] = 0.0;
+    double y0 = 0, y1 = sy[t];
+    int sc = (int)ss[t];
+    for (int l = info.el0; l < L; ++l) {
+      if (sc == 0) row[l] = g[l] * y1;
+      rec_step(al[l], north[t] ? An[l] : As[l], zeta[t], y0, y1);
+      if (std::fabs(y1) > REC_BIG) {
+        y1 *= REC_SMALL;
+        y0 *= REC_SMALL;
+        ++sc;
+      }
     }
   }
 }

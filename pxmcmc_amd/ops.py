@@ -424,6 +424,11 @@ class ShtPlan:
     def table_bytes(self, op):
         return int(lib.pxm_sht_table_bytes(self._h, op))
 
+    def uses_recursion(self):
+        """0, or 16 * ring blocks per wavefront + complex columns per order when inverse / inverse_adjoint take the
+        table-free recursion kernels (csrc/sht_rec.hip) instead of the ring-table GEMM"""
+        return int(check(lib.pxm_sht_uses_recursion(self._h)))
+
     def status(self, clear=False):
         """bit mask of the bounded device waits of this plan that expired (0 = none); synchronises"""
         return int(check(lib.pxm_sht_status(self._h, int(bool(clear)), _stream())))
