@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <type_traits>
 
 #include <hip/hip_ext.h>
 
@@ -69,14 +70,67 @@ __global__ __launch_bounds__(256) void k_rec_pack(RecArgs a) {
   }
 }
 
+// ---- wave-uniform operands without scalar registers -----------------------------------------------------------------------
+// The coefficients {alpha, A} and the operand {re, im} of 16 consecutive degrees sit in lanes 0..15 of EVERY 16-lane row of
+// one register pair (lane i of a row loaded degree el_b + i); step j reads them through the DPP control `row_newbcast:j`
+// -- the one DPP control 64-bit VALU operations take on gfx950 -- as the source operand of the arithmetic itself.  No
+// scalar loads, no LDS, no SALU traffic: the first version fetched them with s_load_dwordx16 and spent as many issue
+// slots on the scalar unit (register ping-pong, addresses) as on the vector pipe (61 us per launch against 2x less).
+template <int J>
+__device__ __forceinline__ double bc64(double s) {
+  double d;
+  asm("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(s), "n"(J));
+  return d;
+}
+template <int J>  // acc += (lane J of a's row) * b
+__device__ __forceinline__ void fmac_bc(double& acc, double a, double b) {
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(a), "v"(b), "n"(J));
+}
+
+// DPP hazard: a VGPR written by a VALU instruction must not be read as a DPP source within the next two wait states.  The
+// compiler's hazard recogniser does not see inside inline assembly, and the register rotation of the look-ahead
+// (cf = cfn: v_mov_b64) writes exactly the registers the block's first DPP operations read.  Every 16-degree block
+// therefore passes its DPP sources through this fence: a volatile statement that takes them in and out, so that every
+// copy the compiler makes lands before it and every DPP read after it, with the two wait states inside.
+__device__ __forceinline__ void dpp_fence(double2& v) { asm volatile("s_nop 1" : "+v"(v.x), "+v"(v.y)); }
+
+template <int J, int R>
+__device__ __forceinline__ void rec_steps_bc(const double2& cf, const double (&zeta)[R], double (&y0)[R], double (&y1)[R]) {
+  if constexpr (R == 1) {
+    double w = bc64<J>(cf.y);
+    fmac_bc<J>(w, cf.x, zeta[0]);  // w = fma(alpha, zeta, A): rec_step()
+    const double y2 = fma(w, y1[0], -y0[0]);
+    y0[0] = y1[0];
+    y1[0] = y2;
+  } else {
+    const double al = bc64<J>(cf.x), A = bc64<J>(cf.y);
+#pragma unroll
+    for (int r = 0; r < R; ++r) rec_step(al, A, zeta[r], y0[r], y1[r]);
+  }
+}
+
 // ---- el -> ring ---------------------------------------------------------------------------------------------------------
-// (the wave-uniform streams -- coefficients, packed operand, unit list, wave descriptors -- are separate const __restrict__
-// kernel arguments: only then does the compiler know them invariant and fetch them with scalar loads)
+template <int J, int R, int NC>
+__device__ __forceinline__ void e2r_block(const double2& cf, const double2 (&h)[NC], const double (&zeta)[R], double (&y0)[R],
+                                          double (&y1)[R], double (&ar)[R][NC], double (&ai)[R][NC]) {
+  if constexpr (J < 16) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        fmac_bc<J>(ar[r][c], h[c].x, y1[r]);
+        fmac_bc<J>(ai[r][c], h[c].y, y1[r]);
+      }
+    rec_steps_bc<J, R>(cf, zeta, y0, y1);
+    e2r_block<J + 1, R, NC>(cf, h, zeta, y0, y1, ar, ai);
+  }
+}
+
 template <int R, int NC>
 __global__ __launch_bounds__(512) void k_rec_e2r(RecArgs a, const double2* __restrict__ coefN, const double2* __restrict__ coefS,
                                                  const double2* __restrict__ hs_all, const int* __restrict__ units,
                                                  const int4* __restrict__ wdesc) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int4 wd = wdesc[wave];
   const double2* __restrict__ coefH = wd.z ? coefN : coefS;
@@ -96,8 +150,8 @@ __global__ __launch_bounds__(512) void k_rec_e2r(RecArgs a, const double2* __res
     const int m = a.paired ? mi : mi - (L - 1);
     const int am = m < 0 ? -m : m, as = a.spin < 0 ? -a.spin : a.spin;
     const int el0 = am > as ? am : as;
-    const double2* __restrict__ cf = coefH + (int64_t)mi * Lp;
-    const double2* __restrict__ hs = hs_all + (int64_t)mi * Lp * NC;
+    const double2* __restrict__ cfp = coefH + (int64_t)mi * Lp + l15;
+    const double2* __restrict__ hsp = hs_all + ((int64_t)mi * Lp + l15) * NC;
     double y0[R], y1[R], ar[R][NC], ai[R][NC];
     int sc[R];
 #pragma unroll
@@ -109,44 +163,26 @@ __global__ __launch_bounds__(512) void k_rec_e2r(RecArgs a, const double2* __res
 #pragma unroll
       for (int c = 0; c < NC; ++c) ar[r][c] = ai[r][c] = 0.0;
     }
-    // groups of four degrees; the coefficients and operands of the NEXT group are fetched (scalar loads) before this
-    // group's arithmetic, so that their latency lies under it (Lp >= L + 8: the look-ahead stays inside the arrays)
-    double2 c2n[4], hn[4][NC];
+    // blocks of 16 degrees; the next block's coefficients and operands are loaded before this block's arithmetic
+    // (Lp >= L + 48: the look-ahead stays inside the zero-padded arrays; alpha = A = 0 and h = 0 beyond L - 1)
+    double2 cf = cfp[el0], h[NC], cfn = cfp[el0 + 16], hn[NC];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      c2n[k] = cf[el0 + k];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) hn[k][c] = hs[(int64_t)(el0 + k) * NC + c];
+    for (int c = 0; c < NC; ++c) {
+      h[c] = hsp[(int64_t)el0 * NC + c];
+      hn[c] = hsp[(int64_t)(el0 + 16) * NC + c];
     }
-    for (int el = el0; el < L; el += 4) {
-      double2 c2[4], h[4][NC];
+    for (int el = el0; el < L; el += 16) {
+      const double2 cfnn = cfp[el + 32];  // two blocks ahead: 8 + 8 MB of coefficients / operands stream from HBM once
+      double2 hnn[NC];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        c2[k] = c2n[k];
+      for (int c = 0; c < NC; ++c) hnn[c] = hsp[(int64_t)(el + 32) * NC + c];
+      dpp_fence(cf);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) h[k][c] = hn[k][c];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        c2n[k] = cf[el + 4 + k];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) hn[k][c] = hs[(int64_t)(el + 4 + k) * NC + c];
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            ar[r][c] = fma(y1[r], h[k][c].x, ar[r][c]);
-            ai[r][c] = fma(y1[r], h[k][c].y, ai[r][c]);
-          }
-          rec_step(c2[k].x, c2[k].y, zeta[r], y0[r], y1[r]);
-        }
-      }
+      for (int c = 0; c < NC; ++c) dpp_fence(h[c]);
+      e2r_block<0, R, NC>(cf, h, zeta, y0, y1, ar, ai);
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        if (fabs(y1[r]) > REC_BIG) {  // (only lanes still below the double range: sc < 0)
+        if (fabs(y1[r]) > REC_BIG) {  // (only lanes still below the double range, sc < 0; <= 2^6 of growth per step)
           y1[r] *= REC_SMALL;
           y0[r] *= REC_SMALL;
 #pragma unroll
@@ -156,6 +192,13 @@ __global__ __launch_bounds__(512) void k_rec_e2r(RecArgs a, const double2* __res
           }
           ++sc[r];
         }
+      cf = cfn;
+      cfn = cfnn;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        h[c] = hn[c];
+        hn[c] = hnn[c];
+      }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -237,19 +280,39 @@ __global__ void k_rec_reduce_selftest(double* out) {
   out[64 + lane] = (double)reduce16_id(lane);
 }
 
+template <int J, int JEND, int R, int NC>  // degrees J .. JEND - 1 of a block: products of degree J into V, then the step
+__device__ __forceinline__ void r2e_degrees(const double2& cf, const double (&zeta)[R], double (&y0)[R], double (&y1)[R],
+                                            const double (&gr)[R][NC], const double (&gi)[R][NC], double (&V)[16]) {
+  if constexpr (J < JEND) {
+    constexpr int K = 8 / NC, k = J % K;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      double pr = y1[0] * gr[0][c], pi = y1[0] * gi[0][c];
+#pragma unroll
+      for (int r = 1; r < R; ++r) {
+        pr = fma(y1[r], gr[r][c], pr);
+        pi = fma(y1[r], gi[r][c], pi);
+      }
+      V[(k * NC + c) * 2] = pr;
+      V[(k * NC + c) * 2 + 1] = pi;
+    }
+    rec_steps_bc<J, R>(cf, zeta, y0, y1);
+    r2e_degrees<J + 1, JEND, R, NC>(cf, zeta, y0, y1, gr, gi, V);
+  }
+}
+
 template <int R, int NC>
 __global__ __launch_bounds__(512) void k_rec_r2e(RecArgs a, const double2* __restrict__ coefN, const double2* __restrict__ coefS,
                                                  const int* __restrict__ units, const int4* __restrict__ wdesc) {
-  constexpr int K = 8 / NC;      // degrees per reduction block: 2 NC K = 16 values
-  constexpr int CHK = K < 4 ? K : 4;
-  extern __shared__ double part[];  // [NW][L + 8][2 NC]
-  const int lane = threadIdx.x & 63;
+  constexpr int K = 8 / NC;         // degrees per reduction group: 2 NC K = 16 values
+  extern __shared__ double part[];  // [NW][L + 16][2 NC]
+  const int lane = threadIdx.x & 63, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nw = blockDim.x >> 6;
   const int4 wd = wdesc[wave];
   const double2* __restrict__ coefH = wd.z ? coefN : coefS;
   const int L = a.L, Lp = a.Lp, sides = a.paired ? 2 : 1;
-  const int LR = L + 8;
+  const int LR = L + 16;
   double* mypart = part + (int64_t)wave * LR * 2 * NC;
   const int vid = reduce16_id(lane);
   int t[R];
@@ -267,7 +330,7 @@ __global__ __launch_bounds__(512) void k_rec_r2e(RecArgs a, const double2* __res
     const int m = a.paired ? mi : mi - (L - 1);
     const int am = m < 0 ? -m : m, as = a.spin < 0 ? -a.spin : a.spin;
     const int el0 = am > as ? am : as;
-    const double2* __restrict__ cf = coefH + (int64_t)mi * Lp;
+    const double2* __restrict__ cfp = coefH + (int64_t)mi * Lp + l15;
     double y0[R], y1[R], gr[R][NC], gi[R][NC];
     int sc[R];
     auto load_g = [&](int r) {
@@ -293,36 +356,39 @@ __global__ __launch_bounds__(512) void k_rec_r2e(RecArgs a, const double2* __res
       for (int c = 0; c < NC; ++c) gr[r][c] = gi[r][c] = 0.0;
       if (live[r] && sc[r] == 0) load_g(r);  // (a lane still below the double range contributes nothing: its operand is 0)
     }
-    for (int lb = el0; lb < L; lb += K) {
-      double V[16];
+    double2 cf = cfp[el0], cfn = cfp[el0 + 16];
+    for (int lb = el0; lb < L; lb += 16) {
+      const double2 cfnn = cfp[lb + 32];
+      dpp_fence(cf);
+      auto group = [&](auto qc) {  // degrees lb + q K .. lb + q K + K - 1: products, steps, rescale check, sums over the rings
+        constexpr int q = decltype(qc)::value;
+        double V[16];
+        r2e_degrees<q * K, q * K + K, R, NC>(cf, zeta, y0, y1, gr, gi, V);
 #pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const double2 c2 = cf[lb + k];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          double pr = y1[0] * gr[0][c], pi = y1[0] * gi[0][c];
-#pragma unroll
-          for (int r = 1; r < R; ++r) {
-            pr = fma(y1[r], gr[r][c], pr);
-            pi = fma(y1[r], gi[r][c], pi);
+        for (int r = 0; r < R; ++r)
+          if (fabs(y1[r]) > REC_BIG) {
+            y1[r] *= REC_SMALL;
+            y0[r] *= REC_SMALL;
+            if (++sc[r] == 0) load_g(r);
           }
-          V[(k * NC + c) * 2] = pr;
-          V[(k * NC + c) * 2 + 1] = pi;
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) rec_step(c2.x, c2.y, zeta[r], y0[r], y1[r]);
-        if ((k % CHK) == CHK - 1) {
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-            if (fabs(y1[r]) > REC_BIG) {
-              y1[r] *= REC_SMALL;
-              y0[r] *= REC_SMALL;
-              if (++sc[r] == 0) load_g(r);
-            }
-        }
+        const double sum = reduce16(V, lane);
+        // value id = (k NC + c) 2 + {re, im}: the offset inside the group's 2 NC K doubles
+        if ((lane & 3) == 0) mypart[(int64_t)(lb + q * K) * 2 * NC + vid] = sum;
+      };
+      group(std::integral_constant<int, 0>());
+      if constexpr (K <= 8) group(std::integral_constant<int, 1>());
+      if constexpr (K <= 4) {
+        group(std::integral_constant<int, 2>());
+        group(std::integral_constant<int, 3>());
       }
-      const double s = reduce16(V, lane);
-      if ((lane & 3) == 0) mypart[(int64_t)lb * 2 * NC + vid] = s;  // value id = (k NC + c) 2 + {re, im}: the offset in the block
+      if constexpr (K <= 2) {
+        group(std::integral_constant<int, 4>());
+        group(std::integral_constant<int, 5>());
+        group(std::integral_constant<int, 6>());
+        group(std::integral_constant<int, 7>());
+      }
+      cf = cfn;
+      cfn = cfnn;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < L * NC; idx += blockDim.x) {
@@ -356,7 +422,7 @@ int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out)
   T->spin = spin;
   T->paired = spin == 0;
   T->n_m = T->paired ? L : 2 * L - 1;
-  T->Lp = round_up(L + 8, 4);
+  T->Lp = round_up(L + 48, 4);
   T->Tp = round_up(L, 64);
   T->Rp = Rp;
   T->ncol = ncol;
@@ -438,10 +504,12 @@ int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out)
     return x.first != y.first ? x.first > y.first : x.second < y.second;
   });
   std::vector<int> units;
+  bool pair_orders = true;
+  if (const char* e = std::getenv("PXM_REC_PAIR")) pair_orders = std::atoi(e) != 0;
   for (size_t lo = 0, hi = ord.size(); lo < hi;) {
     const int a0 = ord[lo++].second;
     int b0 = -1;
-    if (lo < hi && ord[lo - 1].first + ord[hi - 1].first <= L + 2) b0 = ord[--hi].second;
+    if (pair_orders && lo < hi && ord[lo - 1].first + ord[hi - 1].first <= L + 2) b0 = ord[--hi].second;
     units.push_back(a0);
     units.push_back(b0);
   }
@@ -524,7 +592,7 @@ static int launch_e2r_nc(const RecTables& T, const RecArgs& a, hipStream_t st, h
 template <int NC>
 static int launch_r2e_nc(const RecTables& T, const RecArgs& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid(T.n_units), block(64 * T.NW);
-  const size_t lds = (size_t)T.NW * (T.L + 8) * 2 * NC * sizeof(double);
+  const size_t lds = (size_t)T.NW * (T.L + 16) * 2 * NC * sizeof(double);
   switch (T.R) {
 #define PXM_R2E(R_) hipExtLaunchKernelGGL((k_rec_r2e<R_, NC>), grid, block, lds, st, e0, e1, 0, a, a.coefN, a.coefS, a.units, a.wdesc)
     case 1: PXM_R2E(1); break;
