@@ -246,6 +246,9 @@ int pxm_wav_ring_preds(pxm_wav_plan_t plan, void* preds, int C, pxm_stream_t str
  *   pxm_wav_wl_adjoint : X_out [C][ncoefs] = transform.inverse_adjoint(WeakLensing.adjoint(g)), g = gamma, or the
  *                        residual invcov .* (gamma - data) when data / invcov ([ndata]) are given (calc_gradg). */
 int pxm_wav_wl_attach(pxm_wav_plan_t plan, const int32_t* pix2data, const double* weight, int64_t ndata);
+/* non-zero (as pxm_sht_uses_recursion) when the attached spin-2 stage of pxm_wav_wl_forward / _adjoint -- pyssht.inverse /
+ * inverse_adjoint with Spin=2, pxmcmc/measurements.py:225,237 -- runs the table-free recursion kernels */
+int pxm_wav_wl_uses_recursion(pxm_wav_plan_t plan);
 int pxm_wav_wl_forward(pxm_wav_plan_t plan, const void* X, void* gamma, int C, pxm_stream_t stream);
 int pxm_wav_wl_adjoint(pxm_wav_plan_t plan, const void* gamma, const void* data, const void* invcov,
                        int invcov_complex, void* X_out, int C, pxm_stream_t stream);

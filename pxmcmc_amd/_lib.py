@@ -83,6 +83,7 @@ SIGNATURES = {
     ),
     "pxm_wav_ring_preds": (c_int, [c_vp, c_vp, c_int, c_vp]),
     "pxm_wav_wl_attach": (c_int, [c_vp, c_vp, c_vp, c_i64]),
+    "pxm_wav_wl_uses_recursion": (c_int, [c_vp]),
     "pxm_wav_wl_forward": (c_int, [c_vp, c_vp, c_vp, c_int, c_vp]),
     "pxm_wav_wl_adjoint": (c_int, [c_vp, c_vp, c_vp, c_vp, c_int, c_vp, c_int, c_vp]),
     "pxm_soft": (c_int, [c_vp, c_vp, c_dbl, c_vp, c_i64, c_int, c_int, c_vp]),

@@ -181,7 +181,7 @@ static inline int64_t arr_size(int L, int ncol) { return (int64_t)(2 * L - 1) * 
 static bool rec_wanted(int L, int spin, int max_chains) {
   if (!rec_supported(spin, max_chains)) return false;
   if (const char* e = std::getenv("PXM_REC")) return std::atoi(e) != 0 && L >= 3;
-  return false;
+  return L >= 128;  // (below, the launches are latency-bound either way and the tables are small)
 }
 
 }  // namespace pxm
@@ -467,6 +467,7 @@ struct pxm_wav_plan_s {
   DftGroupList dft_group;   // every scale's rings -> X' -> rings kernel in one grid (ring-space step)
   // weak-lensing attachment (pxm_wav_wl_attach): spin-2 ring tables at L, their ring array, the harmonic kernel
   ShtTables* T2 = nullptr;
+  RecTables* rec2 = nullptr;  // ... or the table-free spin-2 ring stage (sht_rec.hip) when the plan carries few chains
   int64_t offG2 = 0;
   double* d_wlk = nullptr;             // [Rp] k_l = -sqrt((l+2)(l-1)/((l+1)l)), zero for l < 2 (measurements.py:151-171)
   TaskList wl_inv, wl_invadj;          // class buffers --k_l B2--> G2 ; G2 --B2^T, k_l--> H_L
@@ -721,6 +722,7 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   for (TaskList* t : tls) free_tasks(t);
   profiler_release(&p->prof);
   for (ShtTables* T : p->held) release_tables(T);
+  rec_tables_destroy(p->rec2);
   delete p;
   drain_deferred();
   return 0;
@@ -1337,13 +1339,19 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
   const int64_t P = (int64_t)p->L * (2 * p->L - 1);
   PXM_REQUIRE(ndata >= 0 && ndata <= P && (pix2data || ndata == P), "pxm_wav_wl_attach: bad mask description");
   int rc;
-  if (!p->T2) {
-    if ((rc = get_tables(p->L, 2, (1u << TAB_INV) | (1u << TAB_INV_ADJ), &p->T2))) { p->T2 = nullptr; return rc; }
-    wav_hold(p, p->T2);
+  if (!p->T2 && !p->rec2) {
     std::vector<double> k((size_t)p->Rp, 0.0);
     for (int el = 2; el < p->L; ++el) k[el] = -std::sqrt(((el + 2.0) * (el - 1.0)) / ((el + 1.0) * el));
     if ((rc = dev_alloc(&p->d_wlk, k.size() * sizeof(double), "weak-lensing harmonic kernel k_l [Rp]"))) return rc;
     if ((rc = dev_upload(p->d_wlk, k.data(), k.size() * sizeof(double)))) return rc;
+  }
+  if (!p->T2 && !p->rec2 && rec_wanted(p->L, 2, p->Cmax)) {
+    // few chains: Wigner rows of the two spin-2 contractions by recursion (no 2 x 8 L^3-byte tables, no table build)
+    if ((rc = rec_tables_create(p->L, 2, p->Cmax, p->Rp, p->ncol, &p->rec2))) { p->rec2 = nullptr; return rc; }
+  }
+  if (!p->T2 && !p->rec2) {
+    if ((rc = get_tables(p->L, 2, (1u << TAB_INV) | (1u << TAB_INV_ADJ), &p->T2))) { p->T2 = nullptr; return rc; }
+    wav_hold(p, p->T2);
     std::vector<GemmTask> v;
     GemmFuse sum2;
     sum2.x2_base = p->offHB;
@@ -1361,14 +1369,21 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
   return 0;
 }
 
+int pxm_wav_wl_uses_recursion(pxm_wav_plan_t p) {
+  PXM_REQUIRE(p, "pxm_wav_wl_uses_recursion: null plan");
+  return p->rec2 ? p->rec2->R * 16 + p->rec2->NC : 0;
+}
+
 int pxm_wav_wl_forward(pxm_wav_plan_t p, const void* X, void* gamma, int C, pxm_stream_t stream) {
   int rc = wav_check(p, X, gamma, C, "pxm_wav_wl_forward");
   if (rc) return rc;
-  PXM_REQUIRE(p->T2, "pxm_wav_wl_forward: call pxm_wav_wl_attach first");
+  PXM_REQUIRE(p->T2 || p->rec2, "pxm_wav_wl_forward: call pxm_wav_wl_attach first");
   hipStream_t st = (hipStream_t)stream;
   if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
   if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;      // f_lm (class buffers)
-  if ((rc = run_tasks(p->wl_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;       // rings of the shear
+  if (p->rec2) rc = rec_launch_e2r(*p->rec2, p->ws + p->offHA, p->ws + p->offHB, p->d_wlk, p->ws + p->offG2, C, st, &p->prof);
+  else rc = run_tasks(p->wl_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);                  // rings of the shear
+  if (rc) return rc;
   PxOut out;
   out.f = (double*)gamma;
   out.chain_stride = p->wl_gidx ? p->wl_ndata : (int64_t)p->L * (2 * p->L - 1);
@@ -1384,7 +1399,7 @@ int pxm_wav_wl_adjoint(pxm_wav_plan_t p, const void* gamma, const void* data, co
                        void* X_out, int C, pxm_stream_t stream) {
   int rc = wav_check(p, gamma, X_out, C, "pxm_wav_wl_adjoint");
   if (rc) return rc;
-  PXM_REQUIRE(p->T2, "pxm_wav_wl_adjoint: call pxm_wav_wl_attach first");
+  PXM_REQUIRE(p->T2 || p->rec2, "pxm_wav_wl_adjoint: call pxm_wav_wl_attach first");
   PXM_REQUIRE((data == nullptr) == (invcov == nullptr), "pxm_wav_wl_adjoint: data and invcov come together");
   PXM_REQUIRE(p->wl_gidx || !p->wl_gw, "pxm_wav_wl_adjoint: a covariance weight needs the pixel -> data map");
   hipStream_t st = (hipStream_t)stream;
@@ -1397,7 +1412,9 @@ int pxm_wav_wl_adjoint(pxm_wav_plan_t p, const void* gamma, const void* data, co
   in.gidx = p->wl_gidx;
   in.gw = p->wl_gidx ? p->wl_gw : nullptr;
   if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offG2, p->ncol, C, st))) return rc;
-  if ((rc = run_tasks(p->wl_invadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;    // k_l B2^T -> H_L
+  if (p->rec2) rc = rec_launch_r2e(*p->rec2, p->ws + p->offG2, p->d_wlk, p->ws + p->offHL, C, st, &p->prof);
+  else rc = run_tasks(p->wl_invadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);               // k_l B2^T -> H_L
+  if (rc) return rc;
   if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;   // -> rings of every scale
   PxOut out;
   out.f = (double*)X_out;

@@ -625,6 +625,10 @@ class WavPlan:
         self._wl = (pix2data, weight, int(ndata))
         check(lib.pxm_wav_wl_attach(self._h, _p(pix2data), _p(weight), int(ndata)))
 
+    def wl_uses_recursion(self):
+        """non-zero when the attached spin-2 stage runs the table-free recursion kernels (csrc/sht_rec.hip)"""
+        return int(check(lib.pxm_wav_wl_uses_recursion(self._h)))
+
     def wl_forward(self, X, out=None):
         x, squeeze = _batched(as_device(X, _CPLX))
         if x.shape[1] != self.ncoefs or x.shape[0] > self.max_chains:
