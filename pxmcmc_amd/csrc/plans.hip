@@ -179,7 +179,7 @@ static inline int64_t arr_size(int L, int ncol) { return (int64_t)(2 * L - 1) * 
 // column count allows (tests run both paths at small L); PXM_REC=0: never; unset: few-column launches at large L, where the
 // table stream feeds a fraction of an MFMA tile.
 static bool rec_wanted(int L, int spin, int max_chains) {
-  if (!rec_supported(spin, max_chains)) return false;
+  if (!rec_supported(L, spin, max_chains)) return false;
   if (const char* e = std::getenv("PXM_REC")) return std::atoi(e) != 0 && L >= 3;
   return L >= 128;  // (below, the launches are latency-bound either way and the tables are small)
 }

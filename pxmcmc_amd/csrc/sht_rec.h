@@ -20,9 +20,11 @@ struct RecTables {
 // C <= 4 chains at spin != 0, <= 2 at spin 0 (1, 2 or 4 complex columns per stored order); arrays in the plan's G / H layout
 int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out);
 void rec_tables_destroy(RecTables* T);
-inline bool rec_supported(int spin, int C) {
-  const int nc = C * (spin == 0 ? 2 : 1);
-  return nc == 1 || nc == 2 || nc == 4;
+bool rec_geometry(int L, int spin, int C, int* R, int* NW, size_t* lds);
+inline bool rec_supported(int L, int spin, int C) {
+  int R, NW;
+  size_t lds;
+  return rec_geometry(L, spin, C, &R, &NW, &lds);
 }
 // G = B (ks .* (X + X2)):  X, X2 harmonic-side arrays (H layout), ks per-el scale or null, Y ring-side array (G layout)
 int rec_launch_e2r(const RecTables& T, const double* X, const double* X2, const double* ks, double* Y, int C, hipStream_t st,

@@ -415,6 +415,41 @@ __global__ __launch_bounds__(512) void k_rec_r2e(RecArgs a, const double2* __res
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------
+// ring blocks per wave R, waves per workgroup NW and the LDS of the ring -> el kernel for a plan of this size; false when
+// the size has no geometry (more than 8 waves per unit, or more LDS than a CU has)
+bool rec_geometry(int L, int spin, int C, int* R_out, int* NW_out, size_t* lds_out) {
+  const int nc = C * (spin == 0 ? 2 : 1);
+  if (nc != 1 && nc != 2 && nc != 4) return false;
+  const int nb = (L + 63) / 64, n = 2 * L - 1;
+  // as many waves as fill the chip once (1024 SIMDs), at most 4 blocks per wave
+  const int n_units_est = spin == 0 ? (L + 1) / 2 : L;
+  int R = 4;
+  while (R > 1 && (int64_t)n_units_est * ((nb + R - 1) / R) < 1024) R >>= 1;
+  if (const char* e = std::getenv("PXM_REC_R")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4) R = v;
+  }
+  for (;; R <<= 1) {
+    // waves: runs of up to R consecutive blocks of one hemisphere (block b is northern when its centre ring is)
+    int nw = 0;
+    for (int b = 0; b < nb;) {
+      const int north = 2 * (64 * b + std::min(64 * b + 63, L - 1) + 1) < n;
+      int cnt = 1;
+      while (cnt < R && b + cnt < nb && (2 * (64 * (b + cnt) + std::min(64 * (b + cnt) + 63, L - 1) + 1) < n) == north) ++cnt;
+      b += cnt;
+      ++nw;
+    }
+    const size_t lds = (size_t)nw * (L + 16) * 2 * nc * sizeof(double);
+    if (nw <= 8 && lds <= 150 * 1024) {
+      *R_out = R;
+      *NW_out = nw;
+      *lds_out = lds;
+      return true;
+    }
+    if (R >= 4) return false;
+  }
+}
+
 int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out) {
   std::unique_ptr<RecTables, void (*)(RecTables*)> guard(new RecTables(), rec_tables_destroy);
   RecTables* T = guard.get();
@@ -433,13 +468,11 @@ int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out)
     return -1;
   }
   const int nb = (L + 63) / 64;
-  // ring blocks per wave: as many waves as fill the chip once (1024 SIMDs), at most 4 blocks per wave
-  const int n_units_est = T->paired ? (L + 1) / 2 : L;
-  int R = 4;
-  while (R > 1 && (int64_t)n_units_est * ((nb + R - 1) / R) < 1024) R >>= 1;
-  if (const char* e = std::getenv("PXM_REC_R")) {
-    const int v = std::atoi(e);
-    if (v == 1 || v == 2 || v == 4) R = v;
+  int R = 0, NWg = 0;
+  size_t lds_need = 0;
+  if (!rec_geometry(L, spin, C, &R, &NWg, &lds_need)) {
+    set_error("rec_tables_create: no geometry for this size (rec_geometry)");
+    return -1;
   }
   T->R = R;
   // hemispheres: block b is northern when its centre ring is (the pole-distance form only has to be the right one near
@@ -458,8 +491,8 @@ int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out)
     b += cnt;
   }
   T->NW = (int)wdesc.size() / 4;
-  if (T->NW > 8) {
-    set_error("rec_tables_create: more than 8 waves per unit (L > 2048 with this R)");
+  if (T->NW != NWg) {
+    set_error("rec_tables_create: wave descriptors disagree with rec_geometry");
     return -1;
   }
   // host tables
@@ -589,10 +622,24 @@ static int launch_e2r_nc(const RecTables& T, const RecArgs& a, hipStream_t st, h
   return 0;
 }
 
+template <int R, int NC>
+static int r2e_allow_lds() {  // (dynamic LDS beyond 64 KB has to be allowed per kernel, once)
+  static bool done = false;
+  if (!done) {
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_r2e<R, NC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done = true;
+  }
+  return 0;
+}
+
 template <int NC>
 static int launch_r2e_nc(const RecTables& T, const RecArgs& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const dim3 grid(T.n_units), block(64 * T.NW);
   const size_t lds = (size_t)T.NW * (T.L + 16) * 2 * NC * sizeof(double);
+  if (lds > 48 * 1024) {
+    const int rc = T.R == 1 ? r2e_allow_lds<1, NC>() : T.R == 2 ? r2e_allow_lds<2, NC>() : r2e_allow_lds<4, NC>();
+    if (rc) return rc;
+  }
   switch (T.R) {
 #define PXM_R2E(R_) hipExtLaunchKernelGGL((k_rec_r2e<R_, NC>), grid, block, lds, st, e0, e1, 0, a, a.coefN, a.coefS, a.units, a.wdesc)
     case 1: PXM_R2E(1); break;
