@@ -5,6 +5,8 @@
 
 #include <cstdint>
 
+#include "noise_tables.h"
+
 namespace pxm {
 
 struct NormalPair {
@@ -63,7 +65,7 @@ __device__ inline NormalPair box_muller_fast(double u1, double u2) {
 //           (radius 1e-150: zero for every purpose; the f32 path and the oracle give 0 there);
 //   angle   2 pi u2 = k pi / 2 + a, k = rint(4 u2), |a| <= pi / 4: Taylor polynomials of sin / cos (nine terms each),
 //           quadrant by swapping and sign flips.
-__device__ inline NormalPair box_muller_f64(double u1, double u2) {
+__device__ inline NormalPair box_muller_f64_poly(double u1, double u2) {
   int ex = __builtin_amdgcn_frexp_exp(u1);
   double m = __builtin_amdgcn_frexp_mant(u1);  // [0.5, 1)
   const bool lo = m < 0.70710678118654752440;
@@ -113,6 +115,60 @@ __device__ inline NormalPair box_muller_f64(double u1, double u2) {
   const double ss = odd ? cs : sn, cc = odd ? sn : cs;
   const double S = (q & 2) ? -ss : ss, C = ((q + 1) & 2) ? -cc : cc;
   return NormalPair{g * C, g * S};
+}
+
+// Table-driven form of the same transform (round 5; the polynomial form above stays as the cross-check, -DPXM_NOISE_F64_POLY
+// selects it): 8 + 12 fewer fp64 operations per pair, two 16-byte look-ups in L1-resident tables (csrc/noise_tables.h,
+// generated with 60-digit arithmetic by scripts/dev/gen_noise_tables.py).
+//   ln u1   u1 = m 2^e with m in [1/2, 1) as frexp gives it; j = rint(256 m) in [128, 256], table {rc_j = fl(256 / j), 2 ln rc_j}:
+//           r = fma(m, rc_j, -1), |r| <= 2^-8, ln m = -ln rc_j + log1p(r) EXACTLY (the table holds the logarithm of the rounded
+//           reciprocal), seven terms of log1p; j = 256 is the entry {1, 0}: next to u1 = 1 (e = 0, m -> 1) nothing cancels,
+//           so the range needs no re-centring on 1;
+//   angle   2 pi u2 = 2 pi k / 256 + a, k = rint(256 u2), |a| <= pi / 256: table {cos, sin}(2 pi k / 256), sin a and
+//           cos a - 1 by four / three terms, angle addition with the small parts added last.
+// 1.2e-15 against a 40-digit evaluation over 2 x 10^4 uniforms incl. the edges (a = 0, 2^53 - 1, m at the range ends).
+__device__ inline NormalPair box_muller_f64_tab(double u1, double u2) {
+  const int ex = __builtin_amdgcn_frexp_exp(u1);
+  const double m = __builtin_amdgcn_frexp_mant(u1);  // [0.5, 1)
+  const int j = (int)__builtin_rint(m * 256.0);      // 128 .. 256
+  const double2 lt = *reinterpret_cast<const double2*>(&NOISE_LOG_TAB[j - NOISE_LOG_J0][0]);
+  const double r = fma(m, lt.x, -1.0);
+  double p = 1.0 / 7.0;
+  p = fma(p, r, -1.0 / 6.0);
+  p = fma(p, r, 1.0 / 5.0);
+  p = fma(p, r, -0.25);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  p = fma(p, r, 1.0);
+  p *= r;  // log1p(r)
+  const double e = (double)ex;
+  // -2 ln u1 = -2 e ln 2 + 2 ln rc - 2 log1p(r)   (ln 2 split so that e * hi is exact for |e| <= 54)
+  double x = fma(-2.0, p, fma(e, -2.0 * 0.693147180369123816490, fma(e, -2.0 * 1.90821492927058770002e-10, lt.y)));
+  x = fmax(x, 1e-300);  // u1 == 1.0: x = -0.0 (see box_muller_f64_poly)
+  double h = __builtin_amdgcn_rsq(x);
+  double g = x * h;
+  h *= 0.5;
+  const double rr = fma(-h, g, 0.5);
+  g = fma(g, rr, g);
+  g = fma(fma(-g, g, x), h, g);  // sqrt(x)
+  const double t = 256.0 * u2;
+  const double k = __builtin_rint(t);
+  const double a = (t - k) * 0.024543692606170259675;  // 2 pi / 256
+  const double2 cs = *reinterpret_cast<const double2*>(&NOISE_SINCOS_TAB[(int)k & 255][0]);
+  const double a2 = a * a;
+  const double q = fma(fma(a2, -1.0 / 5040.0, 1.0 / 120.0), a2, -1.0 / 6.0);
+  const double sa = fma(a * a2, q, a);                                                // sin a
+  const double cm1 = fma(fma(a2, -1.0 / 720.0, 1.0 / 24.0), a2, -0.5) * a2;           // cos a - 1
+  const double C = cs.x + fma(-cs.y, sa, cs.x * cm1);
+  const double S = cs.y + fma(cs.x, sa, cs.y * cm1);
+  return NormalPair{g * C, g * S};
+}
+__device__ inline NormalPair box_muller_f64(double u1, double u2) {
+#ifdef PXM_NOISE_F64_POLY
+  return box_muller_f64_poly(u1, u2);
+#else
+  return box_muller_f64_tab(u1, u2);
+#endif
 }
 
 // The two Box-Muller evaluations above are selected per LAUNCH (flag PXM_NOISE_F64 of the stepping entry points): F64

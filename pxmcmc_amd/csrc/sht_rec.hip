@@ -421,10 +421,13 @@ bool rec_geometry(int L, int spin, int C, int* R_out, int* NW_out, size_t* lds_o
   const int nc = C * (spin == 0 ? 2 : 1);
   if (nc != 1 && nc != 2 && nc != 4) return false;
   const int nb = (L + 63) / 64, n = 2 * L - 1;
-  // as many waves as fill the chip once (1024 SIMDs), at most 4 blocks per wave
+  // at least two waves per SIMD (1024 SIMDs), at most 4 blocks per wave.  Measured at L = 512, one chain (us per launch,
+  // el -> ring / ring -> el): spin 2  R = 4: 51 / 82, R = 2: 34 / 66, R = 1: 36 / 87;  spin 0  R = 4: 44 / 86, R = 2: 30 / 65,
+  // R = 1: 29 / 85 -- one wave per SIMD cannot issue back to back (3.5 against 2.1 ns per instruction,
+  // scripts/probes/rec_inst_rates.hip), four waves of one block each pay the lane reduction four times
   const int n_units_est = spin == 0 ? (L + 1) / 2 : L;
   int R = 4;
-  while (R > 1 && (int64_t)n_units_est * ((nb + R - 1) / R) < 1024) R >>= 1;
+  while (R > 1 && (int64_t)n_units_est * ((nb + R - 1) / R) < 2048) R >>= 1;
   if (const char* e = std::getenv("PXM_REC_R")) {
     const int v = std::atoi(e);
     if (v == 1 || v == 2 || v == 4) R = v;
