@@ -27,10 +27,16 @@ struct TaskList {
   bool gram = false;     // Gram launch: the stored Gram tiles, TWO harmonic operand arrays read, one written, the data term
   double gram_table_bytes = 0;  // bytes of the Gram table as stored (16-row / 16-k tiles from round_down(m, 16))
   int flags = 0;         // bit 0: tasks sum a second operand in while staging; bit 1: per-row operand scale (kernel variant)
+  int pk = 0;            // packed column tile (few-chain plans, sht_gemm.hip: k_sht_gemm_pk): live columns per slab, 0 = off
+  std::vector<char> tab_shared;  // packed lists: transform i streams its table together with transform i - 1 (one pass)
 };
 
 static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std::vector<int> bls, int ncol,
-                        const double* ws_base, const char* name, std::vector<int> los = {}, bool keep_order = false) {
+                        const double* ws_base, const char* name, std::vector<int> los = {}, bool keep_order = false,
+                        int pk = 0, std::vector<char> tab_shared = {}) {
+  out->pk = pk;
+  tab_shared.resize(bls.size(), 0);
+  out->tab_shared = tab_shared;
   out->bls = bls;
   los.resize(bls.size(), 0);
   out->los = los;
@@ -119,13 +125,13 @@ static int upload_tasks(std::vector<GemmTask> v, bool paired, TaskList* out, std
   }
   out->n = (int)v.size();
   out->paired = paired;
-  out->nslab = paired ? 2 : 1;
+  out->nslab = pk ? 4 : (paired ? 2 : 1);
   for (const GemmTask& t : v) {
     // shape invariants the kernel relies on (its clamped prefetches stay inside the task's own rows and chunks)
     PXM_REQUIRE(t.n_rt >= 0 && t.n_rt <= 8 && t.row0 >= 0 && t.row0 % 16 == 0 && t.k_beg >= 0 && t.k_beg % 16 == 0 &&
                     (t.n_rt == 0 || (t.k_end > t.k_beg && (t.k_end - t.k_beg) % 16 == 0)),
                 "upload_tasks: malformed GEMM task");
-    out->mfma_units += (double)t.n_rt * ((t.k_end - t.k_beg) / 4) * t.nslab;
+    out->mfma_units += (double)t.n_rt * ((t.k_end - t.k_beg) / 4) * (pk ? 1 : t.nslab);  // (packed: one column tile per task)
     for (int sl = 0; sl < 4; ++sl)
       if (t.x2_off[sl]) out->flags |= 1;
     if (t.ks_off[0] || t.ks_off[1]) out->flags |= 2;
@@ -146,6 +152,9 @@ static double tasklist_bytes(const TaskList& tl, int cg) {
     // array, (l, m) entries with l >= |m| only (16 B each: L^2 per array and chain slot), and the data term of chain 0
     if (tl.gram) bytes += tl.gram_table_bytes + 3 * 16.0 * cg * Ld * Ld + 16.0 * Ld * Ld;
     else bytes += gemm_alg_bytes(tl.bls[i], tl.paired, cg, tl.los[i]);
+    // a transform that rides on the previous one's pass over the table (packed pair: the support cut of the pass is the
+    // smaller of the two, i.e. the previous entry's -- scales are listed coarse to fine)
+    if (!tl.gram && tl.pk && tl.tab_shared[i]) bytes -= gemm_table_bytes(tl.bls[i], tl.paired, tl.los[i]);
   }
   return bytes;
 }
@@ -154,6 +163,8 @@ static double tasklist_bytes(const TaskList& tl, int cg) {
 static int run_tasks(const TaskList& tl, const double* X, double* Y, int ncol, int C, hipStream_t st,
                      const GemmAffine& aff = GemmAffine(), Profiler* prof = nullptr) {
   note_stream(st);
+  if (tl.pk)  // few-chain plan: one launch, the live columns of every slab packed into one column tile
+    return launch_gemm_packed(tl.d, tl.n, tl.pk, tl.flags, X, Y, ncol, 0, tasklist_bytes(tl, C), tl.mfma_units * 2048.0, st, prof);
   for (int col0 = 0; col0 < ncol; col0 += 32) {
     const int ct = (ncol - col0 >= 32) ? 2 : 1;
     const int cg = std::max(0, std::min(C - col0 / 2, 8 * ct));  // live chains in this column group
@@ -639,9 +650,31 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   }
   p->table_bytes[0] += p->TL->bytes[TAB_INV];
   p->table_bytes[1] += p->TL->bytes[TAB_INV_ADJ];
-  if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl, p->ncol, p->ws, "synthesis forward (all scales)", el_lo))) return rc;
   p->h_adj_fwdadj = v_adj_fwdadj;
-  if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl, p->ncol, p->ws, "synthesis-adjoint forward-adjoint (all scales)", el_lo))) return rc;
+  // Few-chain plans (<= 2 chains): the forward / forward-adjoint group launches in PACKED form -- the 2 C live columns of
+  // every slab side by side in one MFMA column tile, and scales of equal bandlimit (the two L-band-limited ones) streaming
+  // their table in one pass.  PXM_NO_GEMM_PACK=1: the 16-columns-per-slab lists (A/B, tests).
+  const int pk = (max_chains <= 2 && !getenv("PXM_NO_GEMM_PACK")) ? 2 * max_chains : 0;
+  std::vector<char> shared(p->nsc, 0);
+  if (pk) {
+    v_syn_fwd.clear();
+    v_adj_fwdadj.clear();
+    for (int s = 0; s < p->nsc; ++s) {
+      const bool pair = s + 1 < p->nsc && p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s];
+      for (int w = 0; w < 2; ++w) {
+        const GemmSide a = side(s, w);
+        if (pair) {
+          const GemmSide b = side(s + 1, w);
+          append_gemm_tasks_packed(*p->T[s], kinds[w], p->ncol, a, &b, p->offS, p->ws, *lists[w]);
+        } else {
+          append_gemm_tasks_packed(*p->T[s], kinds[w], p->ncol, a, nullptr, p->offS, p->ws, *lists[w]);
+        }
+      }
+      if (pair) shared[++s] = 1;
+    }
+  }
+  if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl, p->ncol, p->ws, "synthesis forward (all scales)", el_lo, false, pk, shared))) return rc;
+  if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl, p->ncol, p->ws, "synthesis-adjoint forward-adjoint (all scales)", el_lo, false, pk, shared))) return rc;
   if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl, p->ncol, p->ws, "analysis inverse (all scales)", el_lo))) return rc;
   if ((rc = upload_tasks(v_anadj_invadj, true, &p->anadj_invadj, p->bl, p->ncol, p->ws, "analysis-adjoint inverse-adjoint (all scales)", el_lo))) return rc;
   v.clear();

@@ -138,6 +138,11 @@ struct GemmSide {
   GemmFuse fuse;
 };
 
+void append_gemm_tasks_packed(const ShtTables& T, int kind, int ncol, const GemmSide& side_a, const GemmSide* side_b,
+                              int64_t scratch_off, const double* ws_base, std::vector<GemmTask>& tasks);
+int launch_gemm_packed(const GemmTask* d_tasks, int n_tasks, int pk, int flags, const double* X, double* Y, int ncol, int col0,
+                       double alg_bytes, double flops, hipStream_t stream, Profiler* prof = nullptr);
+
 // launch: tasks on device; X/Y = workspace base; col0 = first column of this chain group, ct = column
 // tiles (1 or 2) of the group
 // alg_bytes: algorithmic bytes of this launch (table once + operand + result), for the live profiler

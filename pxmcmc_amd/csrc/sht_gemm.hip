@@ -83,7 +83,13 @@ struct GemmGeom {
   static constexpr int COLS = 16 * NCT;                       // staged operand columns
   static constexpr int PITCH = COLS + (COLS == 16 ? 0 : 16);  // doubles; PITCH*8 = 128 (mod 256)
 };
-template <int CT, int NSLAB, int NW, int RT, int NSET, bool TWO, bool SK, int FLOW>
+// PK (packed columns, few-chain plans): 0 = off.  PK = 2 C in {2, 4}: ONE column tile whose 16 columns are up to 16 / PK
+// slabs of PK live columns each -- slab s = column / PK reads / writes columns col0 .. col0 + PK - 1 of ITS operand / result
+// array (x_off[s] / y_off[s]), slabs 2g, 2g + 1 being the +m / -m slabs of transform g of a task that streams one table
+// for up to two transforms (the two L-band-limited wavelet scales).  With one chain the unpacked launch spends two MFMA
+// column tiles per table fragment on 4 live columns and streams the 512-table once per scale; packed, one tile carries the
+// 8 live columns of both scales: half the table bytes and a quarter of the MFMAs.  Instantiated with CT = NSLAB = 1.
+template <int CT, int NSLAB, int NW, int RT, int NSET, bool TWO, bool SK, int FLOW, int PK = 0>
 __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks, const int bid,
                                               const double* __restrict__ X, double* __restrict__ Y, int ncol, int col0,
                                               const GemmAffine& aff, double (*xs)[KC][GemmGeom<CT, NSLAB>::PITCH]) {
@@ -132,7 +138,9 @@ __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks
     const int q0 = tid + NT * i;
     const int q = q0 % NV;
     const int kr = (q / (COLS / VW)) % KC, col = VW * (q % (COLS / VW));
-    const int slab = col / (16 * CT), cin = col % (16 * CT);
+    // (packed: columns of slabs the task does not have re-read slab 0; their products are never stored)
+    const int slab = PK ? ((col / (PK ? PK : 1)) < tasks[bid].nslab ? col / (PK ? PK : 1) : 0) : col / (16 * CT);
+    const int cin = PK ? col % (PK ? PK : 1) : col % (16 * CT);
     sv[i] = q0 < NV;
     // (per-thread slab: read from the task in memory -- a runtime index into the register copy would push
     // the whole struct into scratch)
@@ -275,7 +283,7 @@ __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks
   // Epilogue operands first -- the per-row data term of the Gram step and the per-row scale of the fused combine --
   // ALL loads in flight together, then the arithmetic and the stores: one memory latency instead of one per output
   // row (a per-workgroup timeline of the Gram launch showed 5-8 us of its 10-23 us in serial epilogue loads).
-  constexpr int NGRP = 1;  // (slab groups: one transform per task)
+  constexpr int NGRP = PK ? 2 : 1;  // slab groups (transforms) per task: one, or up to two in packed lists
   double hdv[RT][NSLAB][4], rsv[RT][NGRP][4];
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
@@ -290,6 +298,26 @@ __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks
 #pragma unroll
       for (int q = 0; q < 4; ++q) rsv[r][g][q] = t.rs_off[g] ? (X + t.rs_off[g])[rowb + 4 * q] : 1.0;
   }
+  if constexpr (PK != 0) {
+    // packed tile: this lane's column cl belongs to slab cl / PK (dead beyond the task's slabs), column cl % PK of its array
+    const int slab = cl / PK, grp = slab >> 1;
+    const bool live = slab < t.nslab;
+    const double sgn = (slab & 1) ? t.sign1 : 1.0;
+    const int64_t yo = tasks[bid].y_off[live ? slab : 0];  // (from memory: a run-time index into the register copy would spill it)
+    const int row_lo = grp ? t.row_lo[1] : t.row_lo[0], row_hi = grp ? t.row_hi[1] : t.row_hi[0];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      if (r >= n_my) continue;
+      const int rowb = t.row0 + 16 * (RT * wave + r) + kq;
+      double* yb = Y + yo + col0 + (cl % PK) + (int64_t)rowb * ncol;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = rowb + 4 * q;
+        const double rs = grp ? rsv[r][NGRP - 1][q] : rsv[r][0][q];
+        if (live && row >= row_lo && row < row_hi) yb[(int64_t)(4 * q) * ncol] = sgn * rs * acc[r][0][q];
+      }
+    }
+  } else {
 #pragma unroll
   for (int r = 0; r < RT; ++r) {
     if (r >= n_my) continue;
@@ -319,6 +347,7 @@ __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks
       }
     }
   }
+  }
 #ifdef PXM_GEMM_TRACE
   __syncthreads();
   if (tid == 0 && g_gemm_trace) {
@@ -347,6 +376,13 @@ __global__ __launch_bounds__(64 * NW) void k_sht_gemm(const GemmTask* __restrict
   __shared__ double xs[2][KC][GemmGeom<CT, NSLAB>::PITCH];
   if (aff.bump && blockIdx.x == 0 && threadIdx.x == 0) *aff.bump += 1;  // Philox iteration counter of the ring-space step
   sht_gemm_body<CT, NSLAB, NW, RT, NSET, TWO, SK, 0>(tasks, blockIdx.x, X, Y, ncol, col0, aff, xs);
+}
+// packed column tile (few-chain plans): PK live columns per slab, up to 16 / PK slabs in the one tile
+template <int PK, int NW, int RT, int NSET, bool TWO, bool SK>
+__global__ __launch_bounds__(64 * NW) void k_sht_gemm_pk(const GemmTask* __restrict__ tasks, const double* __restrict__ X,
+                                                         double* __restrict__ Y, int ncol, int col0, GemmAffine aff) {
+  __shared__ double xs[2][KC][GemmGeom<1, 1>::PITCH];
+  sht_gemm_body<1, 1, NW, RT, NSET, TWO, SK, 0, PK>(tasks, blockIdx.x, X, Y, ncol, col0, aff, xs);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -552,6 +588,38 @@ int launch_gemm(const GemmTask* d_tasks, int n_tasks, int nslab, int flags, cons
   return 0;
 }
 
+// packed launch (pk = live columns per slab: 2 or 4); tasks carry up to 4 slabs
+int launch_gemm_packed(const GemmTask* d_tasks, int n_tasks, int pk, int flags, const double* X, double* Y, int ncol, int col0,
+                       double alg_bytes, double flops, hipStream_t stream, Profiler* prof) {
+  if (n_tasks == 0) return 0;
+  PXM_REQUIRE(pk == 2 || pk == 4, "launch_gemm_packed: 2 or 4 live columns per slab");
+  dim3 grid(n_tasks), block(512);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (prof) prof->next(prof->gemm, &ev0, &ev1, alg_bytes, flops, n_tasks);
+  GemmAffine aff;
+  // look-ahead of the table / operand streams: NSET - 1 chunks.  The packed launches carry a quarter of the MFMA work per table
+  // byte of the 16-columns-per-slab ones and 44 - 54 VGPRs: with one chunk of look-ahead their waves spent half their cycles
+  // in s_waitcnt (SQ_WAIT_INST_ANY 425 M of 825 M wave-cycles, 2.5 TB/s); PXM_GEMM_PK_NSET = 2 | 3 | 4 for A/B runs
+  static const int pk_nset = getenv("PXM_GEMM_PK_NSET") ? atoi(getenv("PXM_GEMM_PK_NSET")) : 3;
+#define PXM_PK_L(PK_, NSET_, TWO_, SK_) \
+  hipExtLaunchKernelGGL((k_sht_gemm_pk<PK_, 8, 1, NSET_, TWO_, SK_>), grid, block, 0, stream, ev0, ev1, 0, d_tasks, X, Y, ncol, col0, aff)
+#define PXM_PK_N(PK_, NSET_)                                     \
+  switch (flags & 3) {                                           \
+    case 0: PXM_PK_L(PK_, NSET_, false, false); break;           \
+    case 1: PXM_PK_L(PK_, NSET_, true, false); break;            \
+    case 2: PXM_PK_L(PK_, NSET_, false, true); break;            \
+    default: PXM_PK_L(PK_, NSET_, true, true); break;            \
+  }
+#define PXM_PK_F(PK_)                                            \
+  if (pk_nset == 2) { PXM_PK_N(PK_, 2) } else if (pk_nset == 4) { PXM_PK_N(PK_, 4) } else { PXM_PK_N(PK_, 3) }
+  if (pk == 2) { PXM_PK_F(2) } else { PXM_PK_F(4) }
+#undef PXM_PK_N
+#undef PXM_PK_F
+#undef PXM_PK_L
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_gemm_flow(const GemmTask* d_tasks, int n_tasks, int nslab, const double* X, double* Y, int ncol, int ct,
                      double alg_bytes, double flops, hipStream_t stream, const GemmAffine& aff, unsigned* flags,
                      unsigned* err, Profiler* prof) {
@@ -642,6 +710,28 @@ static void append_tasks_impl(const ShtTables& T, int kind, int ncol, const Gemm
       g.n_rt = std::min(rpt, n_rt_total - rt);
       g.sign1 = (kind == TAB_GRAM) ? 1.0 : ((m & 1) ? -1.0 : 1.0);  // the Gram table is even in m
       tasks.push_back(g);
+    }
+  }
+}
+
+// Packed lists: the tasks of one transform (side_b == nullptr) or of TWO transforms at the same bandlimit that stream the table
+// once (slabs 0, 1 = +-m of side_a, slabs 2, 3 = +-m of side_b).  The support cut of a pair is the smaller of the two: the
+// row masks (ring->el kinds) / zero scale rows (el->ring kinds) of the transform with the narrower support do the rest.
+void append_gemm_tasks_packed(const ShtTables& T, int kind, int ncol, const GemmSide& side_a, const GemmSide* side_b,
+                              int64_t scratch_off, const double* ws_base, std::vector<GemmTask>& tasks) {
+  GemmSide sa = side_a;
+  if (side_b) sa.el_lo = std::min(side_a.el_lo, side_b->el_lo);
+  const size_t first = tasks.size();
+  append_tasks_impl(T, kind, ncol, sa, scratch_off, ws_base, tasks);
+  for (size_t i = first; i < tasks.size(); ++i) {
+    GemmTask& g = tasks[i];
+    const int m = T.paired ? g.m_unit : g.m_unit - (T.L - 1);
+    fill_side(g, 0, T, kind, m, ncol, side_a, scratch_off, ws_base);
+    fill_side(g, 1, T, kind, m, ncol, side_b ? *side_b : side_a, scratch_off, ws_base);
+    g.nslab = side_b ? 4 : 2;
+    if (!T.paired) {  // all m stored: one slab per transform -- slabs 0 (a) and 1 (b); the kernel's group index is slab >> 1,
+      // so an unpaired packed list carries ONE transform per task
+      g.nslab = 1;
     }
   }
 }
