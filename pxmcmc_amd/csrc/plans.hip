@@ -477,6 +477,15 @@ struct pxm_wav_plan_s {
   std::vector<int> lane_of;  // per scale: -1 = caller's stream, else side stream index
   DftGroupList dft_group;   // every scale's rings -> X' -> rings kernel in one grid (ring-space step)
   // weak-lensing attachment (pxm_wav_wl_attach): spin-2 ring tables at L, their ring array, the harmonic kernel
+  // twin top scales (weak-lensing path, one chain): two scales of equal bandlimit above the DFT group share ONE ring array
+  // -- the finer scale sits in chain slot 1 of the coarser one's 128-B lines -- so that their blocks <-> rings transforms
+  // are one two-"chain" launch instead of two one-chain launches and the packed GEMM stages both from the same lines
+  int pk = 0;                   // live columns per slab of the packed per-scale lists, 0 = unpacked (more than 2 chains)
+  int twin_s = -1;              // the coarser scale of the pair, -1 = none
+  double* d_twin = nullptr;     // [2 bl - 1][Rp_bl][ncol]
+  int64_t offGT = 0;            // d_twin relative to ws (doubles)
+  TaskList wl_syn_fwd, wl_adj_fwdadj;  // packed per-scale lists of the weak-lensing path reading / writing the twin array
+  std::vector<int> el_lo_s, sup_lo_s;  // per scale: rows / contraction steps skipped, first degree of the support
   ShtTables* T2 = nullptr;
   RecTables* rec2 = nullptr;  // ... or the table-free spin-2 ring stage (sht_rec.hip) when the plan carries few chains
   int64_t offG2 = 0;
@@ -503,6 +512,63 @@ static void wav_hold(pxm_wav_plan_s* p, ShtTables* T) {
   if (std::find(p->held.begin(), p->held.end(), T) != p->held.end()) return;
   retain_tables(T);
   p->held.push_back(T);
+}
+
+// the four per-scale ring stages as GemmSide descriptors (which: 0 synthesis forward, 1 its adjoint, 2 analysis inverse,
+// 3 its adjoint); g_base != null replaces the scale's ring array (twin array of the weak-lensing path: a separate allocation,
+// so its offset from the workspace base can have either sign)
+static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const int64_t* g_base) {
+  const int L = p->L, b = p->bl[s], Rb = round_up(b, 16);
+  const int64_t G = g_base ? *g_base : p->offG[s];
+  GemmSide g;
+  g.el_lo = p->el_lo_s[s];
+  g.fuse = GemmFuse();
+  g.kscale = nullptr;
+  const int cls = (s == 0) ? 1 : ((s - 1) & 1);
+  const int64_t hcls = cls ? p->offHB : p->offHA;
+  switch (which) {
+    case 0:  // synthesis: G_s --A_s--> c_s kappa_s(l) * (...) written straight into the class buffer in L layout
+      g.x_base = G; g.x_L = b; g.x_Rp = Rb;
+      g.fuse.row_lo = p->sup_lo_s[s]; g.fuse.row_hi = b;
+      if (p->fused_combine) { g.y_base = hcls; g.y_L = L; g.y_Rp = p->Rp; g.fuse.rscale = p->d_kc_syn + (size_t)s * p->Rp; }
+      else { g.y_base = p->offH[s]; g.y_L = b; g.y_Rp = Rb; g.fuse = GemmFuse(); }
+      break;
+    case 1:  // synthesis adjoint: H_L (scaled by c_s kappa_s per el) --A_s^T--> G_s
+      g.x_base = p->offHL; g.x_L = L; g.x_Rp = p->Rp; g.y_base = G; g.y_L = b; g.y_Rp = Rb;
+      g.kscale = p->d_kc_syn + (size_t)s * p->Rp;
+      break;
+    case 2:  // analysis: H_L (scaled by c_a kappa_s) --B_s--> G_s
+      g.x_base = p->offHL; g.x_L = L; g.x_Rp = p->Rp; g.y_base = G; g.y_L = b; g.y_Rp = Rb;
+      g.kscale = p->d_kc_ana + (size_t)s * p->Rp;
+      break;
+    default:  // analysis adjoint: G_s --B_s^T--> class buffer (or H_s)
+      g.x_base = G; g.x_L = b; g.x_Rp = Rb;
+      g.fuse.row_lo = p->sup_lo_s[s]; g.fuse.row_hi = b;
+      if (p->fused_combine) { g.y_base = hcls; g.y_L = L; g.y_Rp = p->Rp; g.fuse.rscale = p->d_kc_ana + (size_t)s * p->Rp; }
+      else { g.y_base = p->offH[s]; g.y_L = b; g.y_Rp = Rb; g.fuse = GemmFuse(); }
+      break;
+  }
+  return g;
+}
+
+// packed per-scale lists (sht_gemm.hip: k_sht_gemm_pk) of stage `which` for every scale; scales of equal bandlimit stream their
+// table in one pass.  twin_s >= 0: scales twin_s / twin_s + 1 read / write chain slots 0 / 1 of the array at g_twin.
+static void wav_packed_lists(const pxm_wav_plan_s* p, int which, int kind, int twin_s, int64_t g_twin, std::vector<GemmTask>& out,
+                             std::vector<char>* shared) {
+  if (shared) shared->assign(p->nsc, 0);
+  for (int s = 0; s < p->nsc; ++s) {
+    const bool pair = s + 1 < p->nsc && p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s];
+    const int64_t ga = g_twin, gb = g_twin + 2;
+    const GemmSide a = wav_side(p, s, which, s == twin_s ? &ga : nullptr);
+    if (pair) {
+      const GemmSide b = wav_side(p, s + 1, which, s == twin_s ? &gb : nullptr);
+      append_gemm_tasks_packed(*p->T[s], kind, p->ncol, a, &b, p->offS, p->ws, out);
+      if (shared) (*shared)[s + 1] = 1;
+      ++s;
+    } else {
+      append_gemm_tasks_packed(*p->T[s], kind, p->ncol, a, nullptr, p->offS, p->ws, out);
+    }
+  }
 }
 
 extern "C" {
@@ -604,39 +670,10 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   }
   // task lists
   std::vector<GemmTask> v_syn_fwd, v_adj_fwdadj, v_ana_inv, v_anadj_invadj, v;
-  auto cls_of = [&](int s) { return (s == 0) ? 1 : ((s - 1) & 1); };
   // the four per-scale stages as GemmSide descriptors
-  auto side = [&](int s, int which) {
-    const int b = p->bl[s], Rb = round_up(b, 16);
-    GemmSide g;
-    g.el_lo = el_lo[s];
-    g.fuse = GemmFuse();
-    g.kscale = nullptr;
-    const int64_t hcls = cls_of(s) ? p->offHB : p->offHA;
-    switch (which) {
-      case 0:  // synthesis: G_s --A_s--> c_s kappa_s(l) * (...) written straight into the class buffer in L layout
-        g.x_base = p->offG[s]; g.x_L = b; g.x_Rp = Rb;
-        g.fuse.row_lo = sup_lo[s]; g.fuse.row_hi = b;
-        if (p->fused_combine) { g.y_base = hcls; g.y_L = L; g.y_Rp = p->Rp; g.fuse.rscale = p->d_kc_syn + (size_t)s * p->Rp; }
-        else { g.y_base = p->offH[s]; g.y_L = b; g.y_Rp = Rb; g.fuse = GemmFuse(); }
-        break;
-      case 1:  // synthesis adjoint: H_L (scaled by c_s kappa_s per el) --A_s^T--> G_s
-        g.x_base = p->offHL; g.x_L = L; g.x_Rp = p->Rp; g.y_base = p->offG[s]; g.y_L = b; g.y_Rp = Rb;
-        g.kscale = p->d_kc_syn + (size_t)s * p->Rp;
-        break;
-      case 2:  // analysis: H_L (scaled by c_a kappa_s) --B_s--> G_s
-        g.x_base = p->offHL; g.x_L = L; g.x_Rp = p->Rp; g.y_base = p->offG[s]; g.y_L = b; g.y_Rp = Rb;
-        g.kscale = p->d_kc_ana + (size_t)s * p->Rp;
-        break;
-      default:  // analysis adjoint: G_s --B_s^T--> class buffer (or H_s)
-        g.x_base = p->offG[s]; g.x_L = b; g.x_Rp = Rb;
-        g.fuse.row_lo = sup_lo[s]; g.fuse.row_hi = b;
-        if (p->fused_combine) { g.y_base = hcls; g.y_L = L; g.y_Rp = p->Rp; g.fuse.rscale = p->d_kc_ana + (size_t)s * p->Rp; }
-        else { g.y_base = p->offH[s]; g.y_L = b; g.y_Rp = Rb; g.fuse = GemmFuse(); }
-        break;
-    }
-    return g;
-  };
+  p->el_lo_s = el_lo;
+  p->sup_lo_s = sup_lo;
+  auto side = [&](int s, int which) { return wav_side(p, s, which, nullptr); };
   const int kinds[4] = {TAB_FWD, TAB_FWD_ADJ, TAB_INV, TAB_INV_ADJ};
   std::vector<GemmTask>* lists[4] = {&v_syn_fwd, &v_adj_fwdadj, &v_ana_inv, &v_anadj_invadj};
   for (int s = 0; s < p->nsc; ++s) {
@@ -659,20 +696,10 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   if (pk) {
     v_syn_fwd.clear();
     v_adj_fwdadj.clear();
-    for (int s = 0; s < p->nsc; ++s) {
-      const bool pair = s + 1 < p->nsc && p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s];
-      for (int w = 0; w < 2; ++w) {
-        const GemmSide a = side(s, w);
-        if (pair) {
-          const GemmSide b = side(s + 1, w);
-          append_gemm_tasks_packed(*p->T[s], kinds[w], p->ncol, a, &b, p->offS, p->ws, *lists[w]);
-        } else {
-          append_gemm_tasks_packed(*p->T[s], kinds[w], p->ncol, a, nullptr, p->offS, p->ws, *lists[w]);
-        }
-      }
-      if (pair) shared[++s] = 1;
-    }
+    wav_packed_lists(p, 0, TAB_FWD, -1, 0, v_syn_fwd, &shared);
+    wav_packed_lists(p, 1, TAB_FWD_ADJ, -1, 0, v_adj_fwdadj, nullptr);
   }
+  p->pk = pk;
   if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl, p->ncol, p->ws, "synthesis forward (all scales)", el_lo, false, pk, shared))) return rc;
   if ((rc = upload_tasks(v_adj_fwdadj, true, &p->adj_fwdadj, p->bl, p->ncol, p->ws, "synthesis-adjoint forward-adjoint (all scales)", el_lo, false, pk, shared))) return rc;
   if ((rc = upload_tasks(v_ana_inv, true, &p->ana_inv, p->bl, p->ncol, p->ws, "analysis inverse (all scales)", el_lo))) return rc;
@@ -756,6 +783,9 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   profiler_release(&p->prof);
   for (ShtTables* T : p->held) release_tables(T);
   rec_tables_destroy(p->rec2);
+  deferred_free(p->d_twin);
+  free_tasks(&p->wl_syn_fwd);
+  free_tasks(&p->wl_adj_fwdadj);
   delete p;
   drain_deferred();
   return 0;
@@ -925,7 +955,9 @@ static inline hipStream_t wav_group_stream(pxm_wav_plan_t p, hipStream_t st, boo
   return p->side[0];
 }
 
-static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st, uint64_t* bump = nullptr) {
+// twin (weak-lensing path, C == 1): scales twin_s and twin_s + 1 as the two "chains" of ONE launch on the twin array -- chain
+// stride = the distance of their coefficient blocks
+static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream_t st, uint64_t* bump = nullptr, bool twin = false) {
   const bool grp = p->dft_group.d && p->dft_group.five && p->plain_group;
   if (grp && p->dft_group.all) {  // every scale in the one grid: no side streams at all
     PxIn in;
@@ -940,13 +972,19 @@ static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream
   bool bumped = false;
   for (int s = p->nsc - 1; s >= 0; --s) {  // largest first
     if (wav_in_group(p, s)) continue;
+    if (twin && s == p->twin_s + 1) continue;  // rides with twin_s
     PxIn in;
     in.f = (const double*)X;
     in.chain_stride = p->ncoefs;
     in.ring0 = p->coef_off[s];
     if (!bumped) in.bump = bump;  // once per call, by a kernel that runs after every reader of the counter
     bumped = true;
-    rc = launch_px2ring(p->dft[s], in, p->ws + p->offG[s], p->ncol, C, grp ? st : wav_stream(p, s, st));
+    if (twin && s == p->twin_s) {
+      in.chain_stride = p->coef_off[s + 1] - p->coef_off[s];
+      rc = launch_px2ring(p->dft[s], in, p->ws + p->offGT, p->ncol, 2, grp ? st : wav_stream(p, s, st));
+    } else {
+      rc = launch_px2ring(p->dft[s], in, p->ws + p->offG[s], p->ncol, C, grp ? st : wav_stream(p, s, st));
+    }
     if (rc) return rc;
   }
   if (grp) {
@@ -959,7 +997,7 @@ static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream
   return wav_join(p, st, used);
 }
 
-static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st) {
+static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t st, bool twin = false) {
   const bool grp = p->dft_group.d && p->dft_group.five && p->plain_group;
   proto.chain_stride = p->ncoefs;
   if (grp && p->dft_group.all) return dft5_group_ring2px(p->dft_group, p->ws, p->ncol, proto, C, st);
@@ -968,9 +1006,15 @@ static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t
   if (rc) return rc;
   for (int s = p->nsc - 1; s >= 0; --s) {
     if (wav_in_group(p, s)) continue;
+    if (twin && s == p->twin_s + 1) continue;
     PxOut out = proto;
     out.ring0 = p->coef_off[s];
-    rc = launch_ring2px(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, grp ? st : wav_stream(p, s, st));
+    if (twin && s == p->twin_s) {  // (plain output only: the two "chains" are two blocks of one coefficient vector)
+      out.chain_stride = p->coef_off[s + 1] - p->coef_off[s];
+      rc = launch_ring2px(p->dft[s], p->ws + p->offGT, p->ncol, out, 2, grp ? st : wav_stream(p, s, st));
+    } else {
+      rc = launch_ring2px(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, grp ? st : wav_stream(p, s, st));
+    }
     if (rc) return rc;
   }
   if (grp) {
@@ -1396,6 +1440,25 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
     append_gemm_tasks(*p->T2, TAB_INV_ADJ, p->ncol, p->offG2, p->L, p->Rp, p->offHL, p->L, p->Rp, nullptr, p->offS, p->ws, v, 0, rs);
     if ((rc = upload_tasks(v, false, &p->wl_invadj, {p->L}, p->ncol, p->ws, "weak-lensing spin-2 inverse-adjoint"))) return rc;
   }
+  // one chain, two top scales of equal bandlimit outside the DFT group (L = 512, B = 2: scales 8 and 9): twin ring array
+  if (p->twin_s < 0 && p->pk == 2 && p->Cmax == 1 && !getenv("PXM_NO_TWIN")) {
+    for (int s = 0; s + 1 < p->nsc; ++s)
+      if (p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s] && !wav_in_group(p, s) && !wav_in_group(p, s + 1)) {
+        // (+ one row: the address model of the GEMM stage counts 16 columns from a slab's first, and slot 1 starts at column 2)
+        const int64_t n = arr_size(p->bl[s], p->ncol) + p->ncol;
+        if ((rc = dev_alloc(&p->d_twin, (size_t)n * sizeof(double), "twin ring array of the two top scales"))) return rc;
+        if ((rc = dev_zero(p->d_twin, (size_t)n * sizeof(double)))) return rc;
+        p->offGT = p->d_twin - p->ws;
+        std::vector<GemmTask> vf, va;
+        std::vector<char> shared;
+        wav_packed_lists(p, 0, TAB_FWD, s, p->offGT, vf, &shared);
+        wav_packed_lists(p, 1, TAB_FWD_ADJ, s, p->offGT, va, nullptr);
+        if ((rc = upload_tasks(vf, true, &p->wl_syn_fwd, p->bl, p->ncol, p->ws, "weak-lensing synthesis forward (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
+        if ((rc = upload_tasks(va, true, &p->wl_adj_fwdadj, p->bl, p->ncol, p->ws, "weak-lensing forward-adjoint (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
+        p->twin_s = s;
+        break;
+      }
+  }
   p->wl_gidx = pix2data;
   p->wl_gw = weight;
   p->wl_ndata = ndata;
@@ -1412,8 +1475,9 @@ int pxm_wav_wl_forward(pxm_wav_plan_t p, const void* X, void* gamma, int C, pxm_
   if (rc) return rc;
   PXM_REQUIRE(p->T2 || p->rec2, "pxm_wav_wl_forward: call pxm_wav_wl_attach first");
   hipStream_t st = (hipStream_t)stream;
-  if ((rc = wav_blocks_to_rings(p, X, C, st))) return rc;
-  if ((rc = run_tasks(p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;      // f_lm (class buffers)
+  const bool twin = p->twin_s >= 0 && C == 1;
+  if ((rc = wav_blocks_to_rings(p, X, C, st, nullptr, twin))) return rc;
+  if ((rc = run_tasks(twin ? p->wl_syn_fwd : p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;  // f_lm (class buffers)
   if (p->rec2) rc = rec_launch_e2r(*p->rec2, p->ws + p->offHA, p->ws + p->offHB, p->d_wlk, p->ws + p->offG2, C, st, &p->prof);
   else rc = run_tasks(p->wl_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);                  // rings of the shear
   if (rc) return rc;
@@ -1448,10 +1512,11 @@ int pxm_wav_wl_adjoint(pxm_wav_plan_t p, const void* gamma, const void* data, co
   if (p->rec2) rc = rec_launch_r2e(*p->rec2, p->ws + p->offG2, p->d_wlk, p->ws + p->offHL, C, st, &p->prof);
   else rc = run_tasks(p->wl_invadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);               // k_l B2^T -> H_L
   if (rc) return rc;
-  if ((rc = run_tasks(p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;   // -> rings of every scale
+  const bool twin = p->twin_s >= 0 && C == 1;
+  if ((rc = run_tasks(twin ? p->wl_adj_fwdadj : p->adj_fwdadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;  // -> rings of every scale
   PxOut out;
   out.f = (double*)X_out;
-  return wav_rings_to_blocks(p, out, C, st);
+  return wav_rings_to_blocks(p, out, C, st, twin);
 }
 
 int pxm_wav_analysis(pxm_wav_plan_t p, const void* f, void* X, int C, pxm_stream_t stream) {

@@ -243,3 +243,93 @@ def test_g14_hip_samplers_on_wavelets_and_weaklensing(g14):
     _close(s.L2s, g["px_L2s"], 1e-9)
     _close(s.priors, g["px_priors"], 1e-9)
     _close(s.preds, g["px_preds"], 1e-9)
+
+
+def test_twin_top_scales_in_the_weaklensing_path_match_oracle(monkeypatch):
+    """One chain, two top scales of equal bandlimit: the weak-lensing path keeps the finer scale in chain slot 1 of the coarser
+    one's ring array (one two-"chain" DFT launch per direction, one pass of the packed GEMM over their shared table).  The
+    path is taken above the DFT group (L > 256); PXM_NO_PLAIN_DFT_GROUP=1 moves every scale out of the group, so that the
+    same code runs at sizes the oracle covers -- fused operator and its gradient against the oracle's literal composition."""
+    import torch
+
+    from oracle import pxmcmc_np as ref
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    monkeypatch.setenv("PXM_NO_PLAIN_DFT_GROUP", "1")
+    for L in (16, 40):
+        B, J = 2, 2
+        rng = np.random.default_rng(L)
+        mask = (rng.random((L, 2 * L - 1)) > 0.3).astype(int)
+        ngal = rng.integers(5, 40, size=mask.shape).astype(float)
+        tr = SphericalWaveletTransform(L, B, J, max_chains=1)
+        wl = WeakLensing(L, mask, ngal=ngal, max_chains=1)
+        nd = int(mask.sum())
+        data = rng.normal(size=nd) + 1j * rng.normal(size=nd)
+        op = ForwardOperator(data, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+        plan = op._wl_plan()
+        assert plan is not None
+        X = rng.normal(size=tr.ncoefs) + 1j * rng.normal(size=tr.ncoefs)
+        got_f = op.forward(X)
+        got_g = op.calc_gradg(got_f)
+        otr = ref.SphericalWaveletTransform(L, B, J)
+        owl = ref.WeakLensing(L, mask, ngal)
+        oop = ref.ForwardOperator(data, 1 / owl.inv_cov, "synthesis", otr, owl, otr.ncoefs)
+        want_f = oop.forward(X)
+        want_g = oop.calc_gradg(want_f)
+        host = lambda a: a.cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+        got_f, got_g = host(got_f), host(got_g)
+        assert np.abs(got_f - want_f).max() <= 1e-11 * np.abs(want_f).max()
+        assert np.abs(got_g - want_g).max() <= 1e-11 * np.abs(want_g).max()
+        # the same plan without the twin path (two chains' worth of capacity never twins)
+        tr2 = SphericalWaveletTransform(L, B, J, max_chains=2)
+        wl2 = WeakLensing(L, mask, ngal=ngal, max_chains=2)
+        op2 = ForwardOperator(data, 1 / wl2.inv_cov, "synthesis", transform=tr2, measurement=wl2, nparams=tr2.ncoefs)
+        f2 = op2.forward(X)
+        assert np.abs(host(f2) - got_f).max() <= 1e-12 * np.abs(got_f).max()
+        assert np.abs(host(op2.calc_gradg(f2)) - got_g).max() <= 1e-12 * np.abs(got_g).max()
+
+
+def test_config5_one_chain_path_equals_the_two_chain_path_L512():
+    """BASELINE configs[4] per GPU is ONE chain at L = 512: that plan takes the table-free spin-2 recursion kernels, the
+    packed per-scale GEMM lists and the twin ring array of the two 512-band-limited scales.  The two-chain plan of the same
+    problem (ring-table spin-2 GEMMs are replaced by the recursion there too, but no twin array and four-column slabs) is the
+    one `test_config5_fused_weaklensing_operator_closed_form_L512` holds against closed forms: forward and gradient of the
+    two must agree to round-off."""
+    import torch
+
+    from pxmcmc_amd import ops
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.measurements import WeakLensing
+    from pxmcmc_amd.transforms import SphericalWaveletTransform
+
+    L, B, J = 512, 2, 2
+    rng = np.random.default_rng(77)
+    theta = np.pi * (2 * np.arange(L) + 1) / (2 * L - 1)
+    mask = np.ones((L, 2 * L - 1), dtype=int)
+    mask[np.abs(90 - np.degrees(theta)) < 8, :] = 0
+    mask[:, 100:140] = 0
+    ngal = rng.integers(10, 40, size=mask.shape).astype(float)
+    res = {}
+    X = None
+    for C in (1, 2):
+        tr = SphericalWaveletTransform(L, B, J, max_chains=C)
+        wl = WeakLensing(L, mask, ngal=ngal, max_chains=C)
+        if X is None:
+            X = rng.normal(size=tr.ncoefs) + 1j * rng.normal(size=tr.ncoefs)
+            data = rng.normal(size=wl.ndata) + 1j * rng.normal(size=wl.ndata)
+        op = ForwardOperator(data, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+        plan = op._wl_plan()
+        assert plan is not None and plan.wl_uses_recursion() > 0
+        Xd = ops.as_device(X)
+        f = op.forward(Xd)
+        g = op.calc_gradg(f)
+        f_again = op.forward(Xd)  # (a second pass over the same plan: nothing accumulates in the twin array)
+        assert torch.equal(f, f_again)
+        res[C] = (f.cpu().numpy(), g.cpu().numpy())
+        del op, plan, tr, wl
+        ops.tables_trim()
+    for k in (0, 1):
+        a, b = res[1][k], res[2][k]
+        assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-11 * np.abs(b).max()
