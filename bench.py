@@ -51,6 +51,8 @@ def stable_delta(transform, sigma, lmda, iters=30):
         x = y / torch.linalg.norm(y)
     return 0.8 / (lam / sigma ** 2 + 1.0 / lmda), lam
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
+FP64_VECTOR_SPEC_TFLOPS = 78.6   # dense fp64 vector peak of the part
+FP64_VECTOR_FMA_TFLOPS = 62.3    # what a v_fma_f64-only loop sustains (scripts/probes/mfma_valu_mix.hip, rec_inst_rates.hip)
 MFMA_SUSTAINED_TFLOPS = 47.1  # fp64 MFMA-only loop on this part (scripts/probes/mfma_rate.hip; spec 78.6)
 
 
@@ -450,6 +452,13 @@ def config5_operator_loop(op, nrep, seed=0):
     torch.cuda.synchronize()
 
 
+def rec_stage_flops(L, spin, ncols):
+    """fp64 operations of one launch of the table-free ring stage (csrc/sht_rec.hip): per (ring, el, order) two fused
+    multiply-adds of the recursion and two per complex column"""
+    steps = sum(L - max(abs(m), abs(spin)) for m in range(-(L - 1), L) if max(abs(m), abs(spin)) < L)
+    return steps * L * (2 + 2 * ncols) * 2.0
+
+
 def config5_leg(n_iter=150, nrep=10, pmc=None):
     import torch
 
@@ -471,19 +480,41 @@ def config5_leg(n_iter=150, nrep=10, pmc=None):
     ms_iter = s.loop_seconds / n_iter * 1e3  # the iterations alone (PxMALA.run times its loop between two synchronisations)
     acc, used_graph = float(np.mean(s.acceptance_trace)), bool(s.used_graph)
     finite = bool(torch.isfinite(s.X_curr.real).all())
+    # the same loop with a step small enough to be accepted (the reference's parameters, experiments/weaklensing/main.py:110-119,
+    # are rejected throughout the first iterations from a zero start): the conditional copy of the accepted state
+    # (pxm_select_copy_many, 78 MB) inside the clock
+    pa = PxMCMCParams(nsamples=1, nburn=10 ** 9, ngap=1, delta=1e-12, lmda=lmda, mu=MU, verbosity=0, track=[])
+    sa = PxMALA(op, reg, pa, tune_delta=False, nchains=1, seed=3, max_iter=n_iter, noise_bits=64)
+    with contextlib.redirect_stdout(io.StringIO()):
+        sa.run(start_point=np.zeros(tr.ncoefs))
+    accepting = {"ms_per_iteration": sa.loop_seconds / n_iter * 1e3, "acceptance": float(np.mean(sa.acceptance_trace)),
+                 "delta": 1e-12, "tune_delta": False, "finite": bool(torch.isfinite(sa.X_curr.real).all()),
+                 "what": "the same iteration with a step that is accepted: the conditional copy of the accepted state runs in the clock"}
     plan.profile_enable(4 * nrep + 8)
     config5_operator_loop(op, nrep)
     classes = join_pmc(launch_classes(plan, 4 * nrep + 8), pmc, min_launches=PMC_CHILD_REPS["config5"])
     plan.profile_enable(0)
+    rec = bool(plan.wl_uses_recursion())
+    for c in classes:  # the launches of the table-free spin-2 ring stage against BOTH rooflines
+        if rec and c["alg_MB"] < 100.0:
+            fl = rec_stage_flops(C5_L, 2, 1)
+            c.update(kernel="k_rec_e2r (+ operand pass) / k_rec_r2e: Wigner rows by recursion, no table", fp64_GFLOP=fl / 1e9,
+                     fp64_TFLOPs=fl / c["avg_us"] / 1e6, fp64_frac_of_spec=fl / c["avg_us"] / 1e6 / FP64_VECTOR_SPEC_TFLOPS,
+                     fp64_frac_of_fma_rate=fl / c["avg_us"] / 1e6 / FP64_VECTOR_FMA_TFLOPS, bound="fp64 vector")
+        else:
+            c.update(kernel="k_sht_gemm_pk (packed column tile) / k_sht_gemm: per-scale spin-0 ring tables", bound="hbm")
     gemm_us = sum(c["avg_us"] * c["launches"] for c in classes) / nrep
     return {"workload": f"PxMALA (tune_delta), wavelet synthesis L={C5_L} B={C5_B} J_min={C5_JMIN} (N=1221796) + weak-lensing shear "
                         f"measurement with a mask ({wl.ndata} of {wl.npix} pixels kept) and ngal = {C5_NGAL:.0f}, 1 chain, fused operator, "
                         "one-pass propose / accept kernels, HIP graph",
             "iterations": n_iter, "ms_per_iteration": ms_iter, "samples_per_s": 1e3 / ms_iter,
-            "acceptance": acc, "hip_graph": used_graph, "finite": finite, "setup_s": t_setup,
-            "ring_gemm_us_per_iteration": gemm_us, "gemm_launch_classes": classes,
-            "note": "four ring GEMMs per iteration (two spin-0 group launches on the 8 + 1 wavelet scales, two spin-2 launches on "
-                    "unpaired tables) stream ~4.2 GB of tables for 2 live MFMA columns: the bound is the table stream"}
+            "acceptance": acc, "hip_graph": used_graph, "finite": finite and accepting["finite"], "setup_s": t_setup,
+            "accepting_iterations": accepting,
+            "ring_stage_us_per_iteration": gemm_us, "gemm_launch_classes": classes,
+            "spin2_stage": "table-free recursion (csrc/sht_rec.hip)" if rec else "ring-table GEMM",
+            "note": "four ring stages per iteration: two spin-0 group launches on the 8 + 1 wavelet scales (packed column tile, the two "
+                    "512-band-limited scales in one pass over their table and one twin ring array) and two spin-2 stages (Wigner "
+                    "rows by three-term recursion on the vector pipe: no table, 25 MB instead of 1.09 GB per launch)"}
 
 
 PARITY_TOL = 1e-9  # full-size parity leg: max |X_hip - X_oracle| / max |X| after 3 iterations

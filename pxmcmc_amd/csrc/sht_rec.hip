@@ -611,7 +611,9 @@ template <int NC>
 static int launch_e2r_nc(const RecTables& T, const RecArgs& a, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   const int64_t total = (int64_t)T.n_m * T.Lp * NC;
   const int pb = (int)std::min<int64_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(k_rec_pack<NC>, dim3(pb), dim3(256), 0, st, a);
+  // (the live profiler's event pair brackets the operand pass AND the recursion kernel: start on the first, stop on the second)
+  hipExtLaunchKernelGGL(k_rec_pack<NC>, dim3(pb), dim3(256), 0, st, e0, nullptr, 0, a);
+  e0 = nullptr;
   const dim3 grid(T.n_units), block(64 * T.NW);
   switch (T.R) {
 #define PXM_E2R(R_) hipExtLaunchKernelGGL((k_rec_e2r<R_, NC>), grid, block, 0, st, e0, e1, 0, a, a.coefN, a.coefS, \
@@ -675,7 +677,9 @@ int rec_launch_e2r(const RecTables& T, const double* X, const double* X2, const 
   a.ks = ks;
   a.Y = Y;
   hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (prof) prof->next(prof->gemm, &e0, &e1, rec_alg_bytes(T, C), rec_alg_flops(T, true), T.n_units);
+  // + the operand pass: the harmonic-side operand(s) read once more and the packed copy written and read
+  const double pack_bytes = 16.0 * C * (X2 ? 4.0 : 3.0) * ((double)T.L * T.L);
+  if (prof) prof->next(prof->gemm, &e0, &e1, rec_alg_bytes(T, C) + pack_bytes, rec_alg_flops(T, true), T.n_units);
   switch (T.NC) {
     case 1: return launch_e2r_nc<1>(T, a, st, e0, e1);
     case 2: return launch_e2r_nc<2>(T, a, st, e0, e1);
