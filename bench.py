@@ -262,7 +262,8 @@ def pmc_passes(child_args, timeout_s=150):
             with open(files[0]) as fh:
                 for row in csv.DictReader(fh):
                     # every ring-GEMM launch, keyed by launch class = (kernel variant, workgroups)
-                    if row["Counter_Name"] == counter and row["Kernel_Name"].startswith("void pxm::k_sht_gemm<"):
+                    # (k_sht_gemm<..>, k_sht_gemm_pk<..>: ring-table GEMMs; k_rec_e2r / k_rec_r2e: table-free recursion stage)
+                    if row["Counter_Name"] == counter and row["Kernel_Name"].startswith(("void pxm::k_sht_gemm", "void pxm::k_rec_e2r", "void pxm::k_rec_r2e")):
                         wgs = int(row["Grid_Size"]) // max(int(row["Workgroup_Size"]), 1)
                         per.setdefault((row["Kernel_Name"].split("(")[0], wgs), []).append(float(row["Counter_Value"]))
         shutil.rmtree(d, ignore_errors=True)
@@ -330,6 +331,8 @@ def join_pmc(classes, pmc, min_launches=1):
             by_wgs.setdefault(c["workgroups"], []).append(c)
     for g in classes:
         cs = by_wgs.get(g["workgroups"])
+        if cs and g.get("kernel_match"):  # (two kernels of one grid size told apart by name: the recursion pair)
+            cs = [c for c in cs if g["kernel_match"] in c["kernel"]] or None
         if cs and max(c["hbm_MB"] for c in cs) > 1.02 * min(c["hbm_MB"] for c in cs):
             # several kernel variants of this grid size with different traffic in the child pass: no honest join
             g["pmc_ambiguous"] = sorted(c["kernel"] for c in cs)
@@ -492,9 +495,13 @@ def config5_leg(n_iter=150, nrep=10, pmc=None):
                  "what": "the same iteration with a step that is accepted: the conditional copy of the accepted state runs in the clock"}
     plan.profile_enable(4 * nrep + 8)
     config5_operator_loop(op, nrep)
-    classes = join_pmc(launch_classes(plan, 4 * nrep + 8), pmc, min_launches=PMC_CHILD_REPS["config5"])
-    plan.profile_enable(0)
     rec = bool(plan.wl_uses_recursion())
+    classes = launch_classes(plan, 4 * nrep + 8)
+    for c in classes:  # (ring -> el: 25 MB; el -> ring incl. its operand pass: 42 MB; both 512 workgroups)
+        if rec and c["alg_MB"] < 100.0:
+            c["kernel_match"] = "k_rec_r2e" if c["alg_MB"] < 30.0 else "k_rec_e2r"
+    classes = join_pmc(classes, pmc, min_launches=PMC_CHILD_REPS["config5"])
+    plan.profile_enable(0)
     for c in classes:  # the launches of the table-free spin-2 ring stage against BOTH rooflines
         if rec and c["alg_MB"] < 100.0:
             fl = rec_stage_flops(C5_L, 2, 1)
