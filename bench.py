@@ -505,7 +505,7 @@ def config5_leg(n_iter=150, nrep=10, pmc=None):
     for c in classes:  # the launches of the table-free spin-2 ring stage against BOTH rooflines
         if rec and c["alg_MB"] < 100.0:
             fl = rec_stage_flops(C5_L, 2, 1)
-            c.update(kernel="k_rec_e2r (+ operand pass) / k_rec_r2e: Wigner rows by recursion, no table", fp64_GFLOP=fl / 1e9,
+            c.update(kernel=c["kernel_match"] + (" (+ its operand pass k_rec_pack)" if c["kernel_match"] == "k_rec_e2r" else "") + ": Wigner rows by recursion, no table", fp64_GFLOP=fl / 1e9,
                      fp64_TFLOPs=fl / c["avg_us"] / 1e6, fp64_frac_of_spec=fl / c["avg_us"] / 1e6 / FP64_VECTOR_SPEC_TFLOPS,
                      fp64_frac_of_fma_rate=fl / c["avg_us"] / 1e6 / FP64_VECTOR_FMA_TFLOPS, bound="fp64 vector")
         else:
