@@ -16,7 +16,15 @@ What it restates (file:line are relative to the reference tree, pxmcmc v1.0.1):
   weights (pxmcmc/utils.py:249-283), the weak-lensing harmonic kernel
   (pxmcmc/measurements.py:151-171).
   PARITY: PINNED against golden vectors captured from the reference itself
-  (tests/golden/*.npz, generator tests/golden/make_golden.py).
+  (tests/golden/*.npz, generator tests/golden/make_golden.py).  The wavelet-path glue
+  (SphericalWaveletTransform, WeakLensing, SphericalWaveletTransformOperator,
+  S2_Wavelets_L1 and the samplers on them) is pinned by G14: the reference's own
+  classes executed over ``oracle.ext_stub`` (tests/golden/make_golden_r5.py).
+
+* ``oracle.ext_stub``  -- the ``pys2let`` / ``pyssht`` names and call shapes the
+  reference uses, served by ``oracle.s2let`` / ``oracle.ssht``: what G14's generator
+  installs in ``sys.modules`` so that the reference's own code runs in the build
+  container.  It pins the reference's glue, not the third-party numerics.
 
 * ``oracle.wigner`` / ``oracle.ssht`` / ``oracle.s2let`` -- the O(L^3) half the
   reference delegates to un-vendored third-party wheels: pyssht 1.5.2
