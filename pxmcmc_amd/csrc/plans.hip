@@ -482,8 +482,13 @@ struct pxm_wav_plan_s {
   // are one two-"chain" launch instead of two one-chain launches and the packed GEMM stages both from the same lines
   int pk = 0;                   // live columns per slab of the packed per-scale lists, 0 = unpacked (more than 2 chains)
   int twin_s = -1;              // the coarser scale of the pair, -1 = none
-  double* d_twin = nullptr;     // [2 bl - 1][Rp_bl][ncol]
+  double* d_twin = nullptr;     // [2 bl - 1][Rp_bl][ncol_t]
   int64_t offGT = 0;            // d_twin relative to ws (doubles)
+  int ncol_t = 0;               // doubles per row of the twin array: 4 (narrow: its two slots and nothing else) or ncol
+  // narrow ring array of the spin-2 stage (recursion kernels <-> DFT at L): 2 Cmax doubles per row instead of a 128-B line of
+  // eight chain slots -- both its producers and its consumers take the row stride as an argument
+  double* d_g2n = nullptr;
+  int ncol_g2 = 0;
   TaskList wl_syn_fwd, wl_adj_fwdadj;  // packed per-scale lists of the weak-lensing path reading / writing the twin array
   std::vector<int> el_lo_s, sup_lo_s;  // per scale: rows / contraction steps skipped, first degree of the support
   ShtTables* T2 = nullptr;
@@ -517,10 +522,12 @@ static void wav_hold(pxm_wav_plan_s* p, ShtTables* T) {
 // the four per-scale ring stages as GemmSide descriptors (which: 0 synthesis forward, 1 its adjoint, 2 analysis inverse,
 // 3 its adjoint); g_base != null replaces the scale's ring array (twin array of the weak-lensing path: a separate allocation,
 // so its offset from the workspace base can have either sign)
-static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const int64_t* g_base) {
+static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const int64_t* g_base, int g_ncol = 0) {
   const int L = p->L, b = p->bl[s], Rb = round_up(b, 16);
   const int64_t G = g_base ? *g_base : p->offG[s];
   GemmSide g;
+  // (row stride of the ring array when it is replaced: the ring side is x for the forward kinds, y for the adjoint ones)
+  if (g_base && g_ncol) { if (which == 0 || which == 3) g.x_ncol = g_ncol; else g.y_ncol = g_ncol; }
   g.el_lo = p->el_lo_s[s];
   g.fuse = GemmFuse();
   g.kscale = nullptr;
@@ -554,14 +561,14 @@ static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const int64_
 // packed per-scale lists (sht_gemm.hip: k_sht_gemm_pk) of stage `which` for every scale; scales of equal bandlimit stream their
 // table in one pass.  twin_s >= 0: scales twin_s / twin_s + 1 read / write chain slots 0 / 1 of the array at g_twin.
 static void wav_packed_lists(const pxm_wav_plan_s* p, int which, int kind, int twin_s, int64_t g_twin, std::vector<GemmTask>& out,
-                             std::vector<char>* shared) {
+                             std::vector<char>* shared, int twin_ncol = 0) {
   if (shared) shared->assign(p->nsc, 0);
   for (int s = 0; s < p->nsc; ++s) {
     const bool pair = s + 1 < p->nsc && p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s];
     const int64_t ga = g_twin, gb = g_twin + 2;
-    const GemmSide a = wav_side(p, s, which, s == twin_s ? &ga : nullptr);
+    const GemmSide a = wav_side(p, s, which, s == twin_s ? &ga : nullptr, twin_ncol);
     if (pair) {
-      const GemmSide b = wav_side(p, s + 1, which, s == twin_s ? &gb : nullptr);
+      const GemmSide b = wav_side(p, s + 1, which, s == twin_s ? &gb : nullptr, twin_ncol);
       append_gemm_tasks_packed(*p->T[s], kind, p->ncol, a, &b, p->offS, p->ws, out);
       if (shared) (*shared)[s + 1] = 1;
       ++s;
@@ -784,6 +791,7 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   for (ShtTables* T : p->held) release_tables(T);
   rec_tables_destroy(p->rec2);
   deferred_free(p->d_twin);
+  deferred_free(p->d_g2n);
   free_tasks(&p->wl_syn_fwd);
   free_tasks(&p->wl_adj_fwdadj);
   delete p;
@@ -981,7 +989,7 @@ static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream
     bumped = true;
     if (twin && s == p->twin_s) {
       in.chain_stride = p->coef_off[s + 1] - p->coef_off[s];
-      rc = launch_px2ring(p->dft[s], in, p->ws + p->offGT, p->ncol, 2, grp ? st : wav_stream(p, s, st));
+      rc = launch_px2ring(p->dft[s], in, p->ws + p->offGT, p->ncol_t, 2, grp ? st : wav_stream(p, s, st));
     } else {
       rc = launch_px2ring(p->dft[s], in, p->ws + p->offG[s], p->ncol, C, grp ? st : wav_stream(p, s, st));
     }
@@ -1011,7 +1019,7 @@ static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t
     out.ring0 = p->coef_off[s];
     if (twin && s == p->twin_s) {  // (plain output only: the two "chains" are two blocks of one coefficient vector)
       out.chain_stride = p->coef_off[s + 1] - p->coef_off[s];
-      rc = launch_ring2px(p->dft[s], p->ws + p->offGT, p->ncol, out, 2, grp ? st : wav_stream(p, s, st));
+      rc = launch_ring2px(p->dft[s], p->ws + p->offGT, p->ncol_t, out, 2, grp ? st : wav_stream(p, s, st));
     } else {
       rc = launch_ring2px(p->dft[s], p->ws + p->offG[s], p->ncol, out, C, grp ? st : wav_stream(p, s, st));
     }
@@ -1424,7 +1432,13 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
   }
   if (!p->T2 && !p->rec2 && rec_wanted(p->L, 2, p->Cmax)) {
     // few chains: Wigner rows of the two spin-2 contractions by recursion (no 2 x 8 L^3-byte tables, no table build)
-    if ((rc = rec_tables_create(p->L, 2, p->Cmax, p->Rp, p->ncol, &p->rec2))) { p->rec2 = nullptr; return rc; }
+    p->ncol_g2 = getenv("PXM_NO_NARROW") ? p->ncol : 2 * p->Cmax;
+    if (p->ncol_g2 != p->ncol) {
+      const size_t nb = (size_t)(2 * p->L - 1) * p->Rp * p->ncol_g2 * sizeof(double);
+      if ((rc = dev_alloc(&p->d_g2n, nb, "narrow spin-2 ring array"))) return rc;
+      if ((rc = dev_zero(p->d_g2n, nb))) return rc;
+    }
+    if ((rc = rec_tables_create(p->L, 2, p->Cmax, p->Rp, p->ncol, &p->rec2, p->ncol_g2))) { p->rec2 = nullptr; return rc; }
   }
   if (!p->T2 && !p->rec2) {
     if ((rc = get_tables(p->L, 2, (1u << TAB_INV) | (1u << TAB_INV_ADJ), &p->T2))) { p->T2 = nullptr; return rc; }
@@ -1444,15 +1458,17 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
   if (p->twin_s < 0 && p->pk == 2 && p->Cmax == 1 && !getenv("PXM_NO_TWIN")) {
     for (int s = 0; s + 1 < p->nsc; ++s)
       if (p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s] && !wav_in_group(p, s) && !wav_in_group(p, s + 1)) {
-        // (+ one row: the address model of the GEMM stage counts 16 columns from a slab's first, and slot 1 starts at column 2)
-        const int64_t n = arr_size(p->bl[s], p->ncol) + p->ncol;
+        // narrow: 4 doubles per row (the two slots); PXM_NO_NARROW=1: the plan's eight-slot lines
+        p->ncol_t = getenv("PXM_NO_NARROW") ? p->ncol : 4;
+        // (+ one row: the address model of the GEMM stage counts a row's width from a slab's first column, and slot 1 starts at 2)
+        const int64_t n = (int64_t)(2 * p->bl[s] - 1) * round_up(p->bl[s], 16) * p->ncol_t + p->ncol_t;
         if ((rc = dev_alloc(&p->d_twin, (size_t)n * sizeof(double), "twin ring array of the two top scales"))) return rc;
         if ((rc = dev_zero(p->d_twin, (size_t)n * sizeof(double)))) return rc;
         p->offGT = p->d_twin - p->ws;
         std::vector<GemmTask> vf, va;
         std::vector<char> shared;
-        wav_packed_lists(p, 0, TAB_FWD, s, p->offGT, vf, &shared);
-        wav_packed_lists(p, 1, TAB_FWD_ADJ, s, p->offGT, va, nullptr);
+        wav_packed_lists(p, 0, TAB_FWD, s, p->offGT, vf, &shared, p->ncol_t);
+        wav_packed_lists(p, 1, TAB_FWD_ADJ, s, p->offGT, va, nullptr, p->ncol_t);
         if ((rc = upload_tasks(vf, true, &p->wl_syn_fwd, p->bl, p->ncol, p->ws, "weak-lensing synthesis forward (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
         if ((rc = upload_tasks(va, true, &p->wl_adj_fwdadj, p->bl, p->ncol, p->ws, "weak-lensing forward-adjoint (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
         p->twin_s = s;
@@ -1478,7 +1494,9 @@ int pxm_wav_wl_forward(pxm_wav_plan_t p, const void* X, void* gamma, int C, pxm_
   const bool twin = p->twin_s >= 0 && C == 1;
   if ((rc = wav_blocks_to_rings(p, X, C, st, nullptr, twin))) return rc;
   if ((rc = run_tasks(twin ? p->wl_syn_fwd : p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;  // f_lm (class buffers)
-  if (p->rec2) rc = rec_launch_e2r(*p->rec2, p->ws + p->offHA, p->ws + p->offHB, p->d_wlk, p->ws + p->offG2, C, st, &p->prof);
+  double* const g2 = p->d_g2n ? p->d_g2n : p->ws + p->offG2;  // (narrow only with the recursion stage: set together)
+  const int g2n = p->d_g2n ? p->ncol_g2 : p->ncol;
+  if (p->rec2) rc = rec_launch_e2r(*p->rec2, p->ws + p->offHA, p->ws + p->offHB, p->d_wlk, g2, C, st, &p->prof);
   else rc = run_tasks(p->wl_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);                  // rings of the shear
   if (rc) return rc;
   PxOut out;
@@ -1487,7 +1505,7 @@ int pxm_wav_wl_forward(pxm_wav_plan_t p, const void* X, void* gamma, int C, pxm_
   out.gidx = p->wl_gidx;
   out.gw = p->wl_gidx ? p->wl_gw : nullptr;
   PXM_REQUIRE(p->wl_gidx || !p->wl_gw, "pxm_wav_wl_forward: a covariance weight needs the pixel -> data map");
-  return launch_ring2px(p->dftL, p->ws + p->offG2, p->ncol, out, C, st);
+  return launch_ring2px(p->dftL, g2, g2n, out, C, st);
 }
 
 // X_out = transform.inverse_adjoint(WeakLensing.adjoint(g)),  g = gamma  or, with data / invcov given, the
@@ -1508,8 +1526,10 @@ int pxm_wav_wl_adjoint(pxm_wav_plan_t p, const void* gamma, const void* data, co
   in.invcov_complex = invcov_complex;
   in.gidx = p->wl_gidx;
   in.gw = p->wl_gidx ? p->wl_gw : nullptr;
-  if ((rc = launch_px2ring(p->dftL, in, p->ws + p->offG2, p->ncol, C, st))) return rc;
-  if (p->rec2) rc = rec_launch_r2e(*p->rec2, p->ws + p->offG2, p->d_wlk, p->ws + p->offHL, C, st, &p->prof);
+  double* const g2 = p->d_g2n ? p->d_g2n : p->ws + p->offG2;
+  const int g2n = p->d_g2n ? p->ncol_g2 : p->ncol;
+  if ((rc = launch_px2ring(p->dftL, in, g2, g2n, C, st))) return rc;
+  if (p->rec2) rc = rec_launch_r2e(*p->rec2, g2, p->d_wlk, p->ws + p->offHL, C, st, &p->prof);
   else rc = run_tasks(p->wl_invadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);               // k_l B2^T -> H_L
   if (rc) return rc;
   const bool twin = p->twin_s >= 0 && C == 1;

@@ -53,6 +53,9 @@ struct GemmTask {
   int m_unit;          // the order this task belongs to: m (paired tables: m >= 0 serves +-m) or m + L - 1
   int hd_stride;       // doubles between consecutive rows of the affine constants: 2 = the chain-less [m][row] complex
                        // array of the Gram step (whole 64-B segments per wave), ncol = columns 0, 1 of an H-layout array
+  int x_ncol, y_ncol;  // packed lists: doubles per row of THIS task's operand / result arrays (a narrow ring array of a
+                       // few-chain plan has 2 C or 4 columns per row instead of the plan's 16); the 16-columns-per-slab
+                       // kernels take the launch's ncol for both
 };
 
 // affine epilogue of the Gram launch: out = w * (ns * acc - hd[row]) as a complex product per chain
@@ -136,6 +139,7 @@ struct GemmSide {
   const double* kscale;
   int el_lo;
   GemmFuse fuse;
+  int x_ncol = 0, y_ncol = 0;  // 0 = the launch's ncol
 };
 
 void append_gemm_tasks_packed(const ShtTables& T, int kind, int ncol, const GemmSide& side_a, const GemmSide* side_b,

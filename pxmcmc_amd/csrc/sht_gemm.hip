@@ -109,6 +109,7 @@ __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks
   const GemmTask t = tasks[bid];
   const int tid = threadIdx.x, lane = tid & 63;
   if (t.n_rt == 0) return;  // padding entry of the XCD-queue order (plans.hip: upload_tasks)
+  const int xn = PK ? t.x_ncol : ncol, yn = PK ? t.y_ncol : ncol;  // doubles per operand / result row
 #ifdef PXM_GEMM_TRACE
   const unsigned long long trace_t0 = wall_clock64();
   unsigned long long trace_t1 = 0, trace_t2 = 0;
@@ -145,7 +146,7 @@ __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks
     // (per-thread slab: read from the task in memory -- a runtime index into the register copy would push
     // the whole struct into scratch)
     const int64_t xo = tasks[bid].x_off[slab];
-    sp[i] = X + xo + col0 + cin + (int64_t)(t.k_beg + kr) * ncol;
+    sp[i] = X + xo + col0 + cin + (int64_t)(t.k_beg + kr) * xn;
     sp2[i] = sp[i];
     skp[i] = sp[i];
     if (TWO) {  // a task of a TWO launch without a second operand (x2_off = 0) re-reads the first and adds zero
@@ -167,9 +168,9 @@ __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks
   {                                                                                                 \
     const int cs = min((CH), nch - 1);                                                              \
     _Pragma("unroll") for (int i = 0; i < IT; ++i) {                                                \
-      st[SET][i] = FLOW == 2 ? ld_agent(reinterpret_cast<const stage_t*>(sp[i] + (int64_t)cs * KC * ncol))  \
-                             : *reinterpret_cast<const stage_t*>(sp[i] + (int64_t)cs * KC * ncol);  \
-      if (TWO) st2[SET][i] = *reinterpret_cast<const stage_t*>(sp2[i] + (int64_t)cs * KC * ncol);   \
+      st[SET][i] = FLOW == 2 ? ld_agent(reinterpret_cast<const stage_t*>(sp[i] + (int64_t)cs * KC * xn))  \
+                             : *reinterpret_cast<const stage_t*>(sp[i] + (int64_t)cs * KC * xn);  \
+      if (TWO) st2[SET][i] = *reinterpret_cast<const stage_t*>(sp2[i] + (int64_t)cs * KC * xn);   \
       if (SK) ssc[SET][i] = skp[i][cs * KC];                                                        \
     }                                                                                               \
   }
@@ -309,12 +310,12 @@ __device__ __forceinline__ void sht_gemm_body(const GemmTask* __restrict__ tasks
     for (int r = 0; r < RT; ++r) {
       if (r >= n_my) continue;
       const int rowb = t.row0 + 16 * (RT * wave + r) + kq;
-      double* yb = Y + yo + col0 + (cl % PK) + (int64_t)rowb * ncol;
+      double* yb = Y + yo + col0 + (cl % PK) + (int64_t)rowb * yn;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = rowb + 4 * q;
         const double rs = grp ? rsv[r][NGRP - 1][q] : rsv[r][0][q];
-        if (live && row >= row_lo && row < row_hi) yb[(int64_t)(4 * q) * ncol] = sgn * rs * acc[r][0][q];
+        if (live && row >= row_lo && row < row_hi) yb[(int64_t)(4 * q) * yn] = sgn * rs * acc[r][0][q];
       }
     }
   } else {
@@ -522,7 +523,9 @@ int check_gemm_task_ranges(const std::vector<GemmTask>& v, int nslab, int flags,
       const int CT = (ncol - col0 >= 32) ? 2 : 1;
       for (int slab = 0; slab < nslab; ++slab) {
         // operand staging: X + x_off[slab] + col0 + cin + (k_beg + kr + cs KC) ncol, cin < 16 CT, kr < KC, cs <= nch - 1
-        const int64_t lo = col0 + (int64_t)t.k_beg * ncol, hi = col0 + 16 * CT - 1 + (int64_t)(t.k_end - 1) * ncol;
+        const int xn = t.x_ncol ? t.x_ncol : ncol, yn = t.y_ncol ? t.y_ncol : ncol;
+        const int wx = std::min(16 * CT, xn), wy = std::min(16 * CT, yn);  // (a narrow array has fewer than 16 columns per row)
+        const int64_t lo = col0 + (int64_t)t.k_beg * xn, hi = col0 + wx - 1 + (int64_t)(t.k_end - 1) * xn;
         if (!ok(t.x_off[slab] + lo, t.x_off[slab] + hi)) return bad(ti, "operand staging", col0);
         if (TWO && t.x2_off[slab] && !ok(t.x2_off[slab] + lo, t.x2_off[slab] + hi)) return bad(ti, "second operand staging", col0);
         // per-k operand scale: X + ks_off[slab >> 1] + k_beg + kr + cs KC
@@ -537,7 +540,7 @@ int check_gemm_task_ranges(const std::vector<GemmTask>& v, int nslab, int flags,
           return bad(ti, "per-row output scale", col0);
         // stores: Y + y_off[slab] + col0 + cin + cl + row ncol for the owned rows inside [row_lo, row_hi)
         const int64_t s_lo = std::max<int64_t>(r_lo, t.row_lo[slab >> 1]), s_hi = std::min<int64_t>(r_hi, (int64_t)t.row_hi[slab >> 1] - 1);
-        if (s_lo <= s_hi && !ok(t.y_off[slab] + col0 + s_lo * ncol, t.y_off[slab] + col0 + 16 * CT - 1 + s_hi * ncol))
+        if (s_lo <= s_hi && !ok(t.y_off[slab] + col0 + s_lo * yn, t.y_off[slab] + col0 + wy - 1 + s_hi * yn))
           return bad(ti, "result rows", col0);
       }
     }
@@ -643,15 +646,16 @@ int launch_gemm_flow(const GemmTask* d_tasks, int n_tasks, int nslab, const doub
 static void fill_side(GemmTask& g, int grp, const ShtTables& T, int kind, int m, int ncol, const GemmSide& sd,
                       int64_t scratch_off, const double* ws_base) {
   const int s0 = 2 * grp, s1 = 2 * grp + 1;
-  g.x_off[s0] = sd.x_base + (int64_t)(m + sd.x_L - 1) * sd.x_Rp * ncol;
-  g.y_off[s0] = sd.y_base + (int64_t)(m + sd.y_L - 1) * sd.y_Rp * ncol;
+  const int xn = sd.x_ncol ? sd.x_ncol : ncol, yn = sd.y_ncol ? sd.y_ncol : ncol;  // doubles per row of the two arrays
+  g.x_off[s0] = sd.x_base + (int64_t)(m + sd.x_L - 1) * sd.x_Rp * xn;
+  g.y_off[s0] = sd.y_base + (int64_t)(m + sd.y_L - 1) * sd.y_Rp * yn;
   if (T.paired) {
     if (m == 0) {
       g.x_off[s1] = g.x_off[s0];
       g.y_off[s1] = scratch_off;
     } else {
-      g.x_off[s1] = sd.x_base + (int64_t)(-m + sd.x_L - 1) * sd.x_Rp * ncol;
-      g.y_off[s1] = sd.y_base + (int64_t)(-m + sd.y_L - 1) * sd.y_Rp * ncol;
+      g.x_off[s1] = sd.x_base + (int64_t)(-m + sd.x_L - 1) * sd.x_Rp * xn;
+      g.y_off[s1] = sd.y_base + (int64_t)(-m + sd.y_L - 1) * sd.y_Rp * yn;
     }
   } else {
     g.x_off[s1] = g.x_off[s0];
@@ -663,8 +667,8 @@ static void fill_side(GemmTask& g, int grp, const ShtTables& T, int kind, int m,
   g.row_hi[grp] = sd.fuse.row_hi;
   g.x2_off[s0] = g.x2_off[s1] = 0;
   if (sd.fuse.x2_base >= 0) {
-    g.x2_off[s0] = sd.fuse.x2_base + (int64_t)(m + sd.x_L - 1) * sd.x_Rp * ncol;
-    g.x2_off[s1] = (T.paired && m != 0) ? sd.fuse.x2_base + (int64_t)(-m + sd.x_L - 1) * sd.x_Rp * ncol : g.x2_off[s0];
+    g.x2_off[s0] = sd.fuse.x2_base + (int64_t)(m + sd.x_L - 1) * sd.x_Rp * xn;
+    g.x2_off[s1] = (T.paired && m != 0) ? sd.fuse.x2_base + (int64_t)(-m + sd.x_L - 1) * sd.x_Rp * xn : g.x2_off[s0];
   }
   g.hd_off[s0] = g.hd_off[s1] = 0;
   g.hd_stride = sd.fuse.hd_stride > 0 ? sd.fuse.hd_stride : ncol;
@@ -709,6 +713,8 @@ static void append_tasks_impl(const ShtTables& T, int kind, int ncol, const Gemm
       g.row0 = row_beg + 16 * rt;
       g.n_rt = std::min(rpt, n_rt_total - rt);
       g.sign1 = (kind == TAB_GRAM) ? 1.0 : ((m & 1) ? -1.0 : 1.0);  // the Gram table is even in m
+      g.x_ncol = side.x_ncol ? side.x_ncol : ncol;
+      g.y_ncol = side.y_ncol ? side.y_ncol : ncol;
       tasks.push_back(g);
     }
   }
@@ -729,6 +735,8 @@ void append_gemm_tasks_packed(const ShtTables& T, int kind, int ncol, const Gemm
     fill_side(g, 0, T, kind, m, ncol, side_a, scratch_off, ws_base);
     fill_side(g, 1, T, kind, m, ncol, side_b ? *side_b : side_a, scratch_off, ws_base);
     g.nslab = side_b ? 4 : 2;
+    g.x_ncol = side_a.x_ncol ? side_a.x_ncol : ncol;  // (the two transforms of a pair share the strides of their arrays)
+    g.y_ncol = side_a.y_ncol ? side_a.y_ncol : ncol;
     if (!T.paired) {  // all m stored: one slab per transform -- slabs 0 (a) and 1 (b); the kernel's group index is slab >> 1,
       // so an unpaired packed list carries ONE transform per task
       g.nslab = 1;

@@ -6,6 +6,7 @@ namespace pxm {
 
 struct RecTables {
   int L = 0, spin = 0, Lp = 0, Tp = 0, n_m = 0, Rp = 0, ncol = 0;
+  int ncol_ring = 0;  // doubles per row of the ring-side array (= ncol unless the plan keeps it narrow)
   bool paired = false;
   int C = 0;    // chains the plan carries at most
   int NC = 0;   // complex columns per stored order: C (all m stored) or 2 C (+-m pairs)
@@ -18,7 +19,8 @@ struct RecTables {
 };
 
 // C <= 4 chains at spin != 0, <= 2 at spin 0 (1, 2 or 4 complex columns per stored order); arrays in the plan's G / H layout
-int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out);
+// ncol: doubles per row of the harmonic-side arrays (H layout of the plan); ncol_ring: of the ring-side array (0 = the same)
+int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out, int ncol_ring = 0);
 void rec_tables_destroy(RecTables* T);
 bool rec_geometry(int L, int spin, int C, int* R, int* NW, size_t* lds);
 inline bool rec_supported(int L, int spin, int C) {

@@ -37,6 +37,7 @@ struct RecArgs {
   double* Y;             // ring-side array (G layout) -- e2r result / r2e operand;  r2e writes X through Yh
   double* Yh;            // r2e result (H layout)
   int L, Lp, Tp, Rp, ncol, n_m, paired, spin, C;
+  int ncol_ring;         // doubles per row of the ring-side array Y (a narrow array of a few-chain plan: 2 C)
 };
 
 // ---- e2r operand: Hs[mi][el][col] = g_el ks_el sign (X + X2)[m_col][el][chain] --------------------------------------------
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(512) void k_rec_e2r(RecArgs a, const double2* __res
         if (chain >= a.C || (side == 1 && m == 0)) continue;
         const int mrow = (side ? -m : m) + L - 1;
         double2 v = sc[r] == 0 ? make_double2(ar[r][c], ai[r][c]) : make_double2(0.0, 0.0);
-        *reinterpret_cast<double2*>(a.Y + ((int64_t)mrow * a.Rp + t[r]) * a.ncol + 2 * chain) = v;
+        *reinterpret_cast<double2*>(a.Y + ((int64_t)mrow * a.Rp + t[r]) * a.ncol_ring + 2 * chain) = v;
       }
     }
   }
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(512) void k_rec_r2e(RecArgs a, const double2* __res
         double2 v = make_double2(0.0, 0.0);
         if (chain < a.C && !(side == 1 && m == 0)) {
           const int mrow = (side ? -m : m) + L - 1;
-          v = *reinterpret_cast<const double2*>(a.Y + ((int64_t)mrow * a.Rp + t[r]) * a.ncol + 2 * chain);
+          v = *reinterpret_cast<const double2*>(a.Y + ((int64_t)mrow * a.Rp + t[r]) * a.ncol_ring + 2 * chain);
         }
         gr[r][c] = v.x;
         gi[r][c] = v.y;
@@ -453,7 +454,7 @@ bool rec_geometry(int L, int spin, int C, int* R_out, int* NW_out, size_t* lds_o
   }
 }
 
-int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out) {
+int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out, int ncol_ring) {
   std::unique_ptr<RecTables, void (*)(RecTables*)> guard(new RecTables(), rec_tables_destroy);
   RecTables* T = guard.get();
   T->L = L;
@@ -464,6 +465,7 @@ int rec_tables_create(int L, int spin, int C, int Rp, int ncol, RecTables** out)
   T->Tp = round_up(L, 64);
   T->Rp = Rp;
   T->ncol = ncol;
+  T->ncol_ring = ncol_ring > 0 ? ncol_ring : ncol;
   T->C = C;
   T->NC = C * (T->paired ? 2 : 1);
   if (T->NC != 1 && T->NC != 2 && T->NC != 4) {
@@ -600,6 +602,7 @@ static RecArgs make_args(const RecTables& T, int C) {
   a.Tp = T.Tp;
   a.Rp = T.Rp;
   a.ncol = T.ncol;
+  a.ncol_ring = T.ncol_ring;
   a.n_m = T.n_m;
   a.paired = T.paired ? 1 : 0;
   a.spin = T.spin;
