@@ -489,6 +489,11 @@ struct pxm_wav_plan_s {
   // eight chain slots -- both its producers and its consumers take the row stride as an argument
   double* d_g2n = nullptr;
   int ncol_g2 = 0;
+  // ... and of the harmonic side of the one-chain weak-lensing path: class buffers A / B and H_L as [m][l][2 C] arrays of
+  // their own (the plan's eight-slot class buffers stay with the generic synthesis / analysis paths)
+  double* d_hn = nullptr;
+  int64_t offHAn = 0, offHBn = 0, offHLn = 0;  // relative to ws (doubles)
+  int ncol_h = 0;
   TaskList wl_syn_fwd, wl_adj_fwdadj;  // packed per-scale lists of the weak-lensing path reading / writing the twin array
   std::vector<int> el_lo_s, sup_lo_s;  // per scale: rows / contraction steps skipped, first degree of the support
   ShtTables* T2 = nullptr;
@@ -522,17 +527,25 @@ static void wav_hold(pxm_wav_plan_s* p, ShtTables* T) {
 // the four per-scale ring stages as GemmSide descriptors (which: 0 synthesis forward, 1 its adjoint, 2 analysis inverse,
 // 3 its adjoint); g_base != null replaces the scale's ring array (twin array of the weak-lensing path: a separate allocation,
 // so its offset from the workspace base can have either sign)
-static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const int64_t* g_base, int g_ncol = 0) {
+struct SideOverride {  // arrays of the weak-lensing path that replace the plan's (offsets relative to ws; ncol 0 = the plan's)
+  const int64_t* g = nullptr;  // ring array of this scale
+  int g_ncol = 0;
+  bool h = false;              // narrow harmonic side: class buffers / H_L of pxm_wav_plan_s::offHAn ...
+};
+static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const SideOverride& ov = SideOverride()) {
   const int L = p->L, b = p->bl[s], Rb = round_up(b, 16);
-  const int64_t G = g_base ? *g_base : p->offG[s];
+  const int64_t G = ov.g ? *ov.g : p->offG[s];
   GemmSide g;
-  // (row stride of the ring array when it is replaced: the ring side is x for the forward kinds, y for the adjoint ones)
-  if (g_base && g_ncol) { if (which == 0 || which == 3) g.x_ncol = g_ncol; else g.y_ncol = g_ncol; }
+  // (row strides of replaced arrays: the ring side is x for the forward kinds, y for the adjoint ones; the harmonic side the other)
+  const bool ring_is_x = which == 0 || which == 3;
+  if (ov.g && ov.g_ncol) (ring_is_x ? g.x_ncol : g.y_ncol) = ov.g_ncol;
+  if (ov.h) (ring_is_x ? g.y_ncol : g.x_ncol) = p->ncol_h;
   g.el_lo = p->el_lo_s[s];
   g.fuse = GemmFuse();
   g.kscale = nullptr;
   const int cls = (s == 0) ? 1 : ((s - 1) & 1);
-  const int64_t hcls = cls ? p->offHB : p->offHA;
+  const int64_t hcls = ov.h ? (cls ? p->offHBn : p->offHAn) : (cls ? p->offHB : p->offHA);
+  const int64_t hl = ov.h ? p->offHLn : p->offHL;
   switch (which) {
     case 0:  // synthesis: G_s --A_s--> c_s kappa_s(l) * (...) written straight into the class buffer in L layout
       g.x_base = G; g.x_L = b; g.x_Rp = Rb;
@@ -541,11 +554,11 @@ static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const int64_
       else { g.y_base = p->offH[s]; g.y_L = b; g.y_Rp = Rb; g.fuse = GemmFuse(); }
       break;
     case 1:  // synthesis adjoint: H_L (scaled by c_s kappa_s per el) --A_s^T--> G_s
-      g.x_base = p->offHL; g.x_L = L; g.x_Rp = p->Rp; g.y_base = G; g.y_L = b; g.y_Rp = Rb;
+      g.x_base = hl; g.x_L = L; g.x_Rp = p->Rp; g.y_base = G; g.y_L = b; g.y_Rp = Rb;
       g.kscale = p->d_kc_syn + (size_t)s * p->Rp;
       break;
     case 2:  // analysis: H_L (scaled by c_a kappa_s) --B_s--> G_s
-      g.x_base = p->offHL; g.x_L = L; g.x_Rp = p->Rp; g.y_base = G; g.y_L = b; g.y_Rp = Rb;
+      g.x_base = hl; g.x_L = L; g.x_Rp = p->Rp; g.y_base = G; g.y_L = b; g.y_Rp = Rb;
       g.kscale = p->d_kc_ana + (size_t)s * p->Rp;
       break;
     default:  // analysis adjoint: G_s --B_s^T--> class buffer (or H_s)
@@ -561,14 +574,21 @@ static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const int64_
 // packed per-scale lists (sht_gemm.hip: k_sht_gemm_pk) of stage `which` for every scale; scales of equal bandlimit stream their
 // table in one pass.  twin_s >= 0: scales twin_s / twin_s + 1 read / write chain slots 0 / 1 of the array at g_twin.
 static void wav_packed_lists(const pxm_wav_plan_s* p, int which, int kind, int twin_s, int64_t g_twin, std::vector<GemmTask>& out,
-                             std::vector<char>* shared, int twin_ncol = 0) {
+                             std::vector<char>* shared, int twin_ncol = 0, bool narrow_h = false) {
   if (shared) shared->assign(p->nsc, 0);
   for (int s = 0; s < p->nsc; ++s) {
     const bool pair = s + 1 < p->nsc && p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s];
     const int64_t ga = g_twin, gb = g_twin + 2;
-    const GemmSide a = wav_side(p, s, which, s == twin_s ? &ga : nullptr, twin_ncol);
+    SideOverride oa, ob;
+    oa.h = ob.h = narrow_h;
+    if (s == twin_s) {
+      oa.g = &ga;
+      ob.g = &gb;
+      oa.g_ncol = ob.g_ncol = twin_ncol;
+    }
+    const GemmSide a = wav_side(p, s, which, oa);
     if (pair) {
-      const GemmSide b = wav_side(p, s + 1, which, s == twin_s ? &gb : nullptr, twin_ncol);
+      const GemmSide b = wav_side(p, s + 1, which, ob);
       append_gemm_tasks_packed(*p->T[s], kind, p->ncol, a, &b, p->offS, p->ws, out);
       if (shared) (*shared)[s + 1] = 1;
       ++s;
@@ -680,7 +700,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   // the four per-scale stages as GemmSide descriptors
   p->el_lo_s = el_lo;
   p->sup_lo_s = sup_lo;
-  auto side = [&](int s, int which) { return wav_side(p, s, which, nullptr); };
+  auto side = [&](int s, int which) { return wav_side(p, s, which); };
   const int kinds[4] = {TAB_FWD, TAB_FWD_ADJ, TAB_INV, TAB_INV_ADJ};
   std::vector<GemmTask>* lists[4] = {&v_syn_fwd, &v_adj_fwdadj, &v_ana_inv, &v_anadj_invadj};
   for (int s = 0; s < p->nsc; ++s) {
@@ -792,6 +812,7 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   rec_tables_destroy(p->rec2);
   deferred_free(p->d_twin);
   deferred_free(p->d_g2n);
+  deferred_free(p->d_hn);
   free_tasks(&p->wl_syn_fwd);
   free_tasks(&p->wl_adj_fwdadj);
   delete p;
@@ -1430,15 +1451,30 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
     if ((rc = dev_alloc(&p->d_wlk, k.size() * sizeof(double), "weak-lensing harmonic kernel k_l [Rp]"))) return rc;
     if ((rc = dev_upload(p->d_wlk, k.data(), k.size() * sizeof(double)))) return rc;
   }
+  // one chain, two top scales of equal bandlimit outside the DFT group (L = 512, B = 2: scales 8 and 9): twin ring array
+  int twin_cand = -1;
+  if (p->twin_s < 0 && p->pk == 2 && p->Cmax == 1 && !getenv("PXM_NO_TWIN"))
+    for (int s = 0; s + 1 < p->nsc && twin_cand < 0; ++s)
+      if (p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s] && !wav_in_group(p, s) && !wav_in_group(p, s + 1)) twin_cand = s;
+  const bool narrow = !getenv("PXM_NO_NARROW");
   if (!p->T2 && !p->rec2 && rec_wanted(p->L, 2, p->Cmax)) {
     // few chains: Wigner rows of the two spin-2 contractions by recursion (no 2 x 8 L^3-byte tables, no table build)
-    p->ncol_g2 = getenv("PXM_NO_NARROW") ? p->ncol : 2 * p->Cmax;
+    p->ncol_g2 = narrow ? 2 * p->Cmax : p->ncol;
     if (p->ncol_g2 != p->ncol) {
       const size_t nb = (size_t)(2 * p->L - 1) * p->Rp * p->ncol_g2 * sizeof(double);
       if ((rc = dev_alloc(&p->d_g2n, nb, "narrow spin-2 ring array"))) return rc;
       if ((rc = dev_zero(p->d_g2n, nb))) return rc;
     }
-    if ((rc = rec_tables_create(p->L, 2, p->Cmax, p->Rp, p->ncol, &p->rec2, p->ncol_g2))) { p->rec2 = nullptr; return rc; }
+    if (narrow && twin_cand >= 0) {  // narrow harmonic side (the weak-lensing lists of the twin path are this path's own)
+      p->ncol_h = 2 * p->Cmax;
+      const int64_t sz = (int64_t)(2 * p->L - 1) * p->Rp * p->ncol_h + p->ncol;  // (+ slack for the 16-column address model)
+      if ((rc = dev_alloc(&p->d_hn, (size_t)(3 * sz) * sizeof(double), "narrow class buffers and H_L of the weak-lensing path"))) return rc;
+      if ((rc = dev_zero(p->d_hn, (size_t)(3 * sz) * sizeof(double)))) return rc;
+      p->offHAn = p->d_hn - p->ws;
+      p->offHBn = p->offHAn + sz;
+      p->offHLn = p->offHAn + 2 * sz;
+    }
+    if ((rc = rec_tables_create(p->L, 2, p->Cmax, p->Rp, p->ncol_h ? p->ncol_h : p->ncol, &p->rec2, p->ncol_g2))) { p->rec2 = nullptr; return rc; }
   }
   if (!p->T2 && !p->rec2) {
     if ((rc = get_tables(p->L, 2, (1u << TAB_INV) | (1u << TAB_INV_ADJ), &p->T2))) { p->T2 = nullptr; return rc; }
@@ -1454,26 +1490,22 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
     append_gemm_tasks(*p->T2, TAB_INV_ADJ, p->ncol, p->offG2, p->L, p->Rp, p->offHL, p->L, p->Rp, nullptr, p->offS, p->ws, v, 0, rs);
     if ((rc = upload_tasks(v, false, &p->wl_invadj, {p->L}, p->ncol, p->ws, "weak-lensing spin-2 inverse-adjoint"))) return rc;
   }
-  // one chain, two top scales of equal bandlimit outside the DFT group (L = 512, B = 2: scales 8 and 9): twin ring array
-  if (p->twin_s < 0 && p->pk == 2 && p->Cmax == 1 && !getenv("PXM_NO_TWIN")) {
-    for (int s = 0; s + 1 < p->nsc; ++s)
-      if (p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s] && !wav_in_group(p, s) && !wav_in_group(p, s + 1)) {
-        // narrow: 4 doubles per row (the two slots); PXM_NO_NARROW=1: the plan's eight-slot lines
-        p->ncol_t = getenv("PXM_NO_NARROW") ? p->ncol : 4;
-        // (+ one row: the address model of the GEMM stage counts a row's width from a slab's first column, and slot 1 starts at 2)
-        const int64_t n = (int64_t)(2 * p->bl[s] - 1) * round_up(p->bl[s], 16) * p->ncol_t + p->ncol_t;
-        if ((rc = dev_alloc(&p->d_twin, (size_t)n * sizeof(double), "twin ring array of the two top scales"))) return rc;
-        if ((rc = dev_zero(p->d_twin, (size_t)n * sizeof(double)))) return rc;
-        p->offGT = p->d_twin - p->ws;
-        std::vector<GemmTask> vf, va;
-        std::vector<char> shared;
-        wav_packed_lists(p, 0, TAB_FWD, s, p->offGT, vf, &shared, p->ncol_t);
-        wav_packed_lists(p, 1, TAB_FWD_ADJ, s, p->offGT, va, nullptr, p->ncol_t);
-        if ((rc = upload_tasks(vf, true, &p->wl_syn_fwd, p->bl, p->ncol, p->ws, "weak-lensing synthesis forward (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
-        if ((rc = upload_tasks(va, true, &p->wl_adj_fwdadj, p->bl, p->ncol, p->ws, "weak-lensing forward-adjoint (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
-        p->twin_s = s;
-        break;
-      }
+  if (twin_cand >= 0) {
+    const int s = twin_cand;
+    // narrow: 4 doubles per row (the two slots); PXM_NO_NARROW=1: the plan's eight-slot lines
+    p->ncol_t = narrow ? 4 : p->ncol;
+    // (+ one row: the address model of the GEMM stage counts a row's width from a slab's first column, and slot 1 starts at 2)
+    const int64_t n = (int64_t)(2 * p->bl[s] - 1) * round_up(p->bl[s], 16) * p->ncol_t + p->ncol_t;
+    if ((rc = dev_alloc(&p->d_twin, (size_t)n * sizeof(double), "twin ring array of the two top scales"))) return rc;
+    if ((rc = dev_zero(p->d_twin, (size_t)n * sizeof(double)))) return rc;
+    p->offGT = p->d_twin - p->ws;
+    std::vector<GemmTask> vf, va;
+    std::vector<char> shared;
+    wav_packed_lists(p, 0, TAB_FWD, s, p->offGT, vf, &shared, p->ncol_t, p->ncol_h != 0);
+    wav_packed_lists(p, 1, TAB_FWD_ADJ, s, p->offGT, va, nullptr, p->ncol_t, p->ncol_h != 0);
+    if ((rc = upload_tasks(vf, true, &p->wl_syn_fwd, p->bl, p->ncol, p->ws, "weak-lensing synthesis forward (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
+    if ((rc = upload_tasks(va, true, &p->wl_adj_fwdadj, p->bl, p->ncol, p->ws, "weak-lensing forward-adjoint (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
+    p->twin_s = s;
   }
   p->wl_gidx = pix2data;
   p->wl_gw = weight;
@@ -1496,7 +1528,8 @@ int pxm_wav_wl_forward(pxm_wav_plan_t p, const void* X, void* gamma, int C, pxm_
   if ((rc = run_tasks(twin ? p->wl_syn_fwd : p->syn_fwd, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof))) return rc;  // f_lm (class buffers)
   double* const g2 = p->d_g2n ? p->d_g2n : p->ws + p->offG2;  // (narrow only with the recursion stage: set together)
   const int g2n = p->d_g2n ? p->ncol_g2 : p->ncol;
-  if (p->rec2) rc = rec_launch_e2r(*p->rec2, p->ws + p->offHA, p->ws + p->offHB, p->d_wlk, g2, C, st, &p->prof);
+  const int64_t hA = p->ncol_h ? p->offHAn : p->offHA, hB = p->ncol_h ? p->offHBn : p->offHB;  // (narrow: Cmax == 1, twin lists)
+  if (p->rec2) rc = rec_launch_e2r(*p->rec2, p->ws + hA, p->ws + hB, p->d_wlk, g2, C, st, &p->prof);
   else rc = run_tasks(p->wl_inv, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);                  // rings of the shear
   if (rc) return rc;
   PxOut out;
@@ -1529,7 +1562,7 @@ int pxm_wav_wl_adjoint(pxm_wav_plan_t p, const void* gamma, const void* data, co
   double* const g2 = p->d_g2n ? p->d_g2n : p->ws + p->offG2;
   const int g2n = p->d_g2n ? p->ncol_g2 : p->ncol;
   if ((rc = launch_px2ring(p->dftL, in, g2, g2n, C, st))) return rc;
-  if (p->rec2) rc = rec_launch_r2e(*p->rec2, g2, p->d_wlk, p->ws + p->offHL, C, st, &p->prof);
+  if (p->rec2) rc = rec_launch_r2e(*p->rec2, g2, p->d_wlk, p->ws + (p->ncol_h ? p->offHLn : p->offHL), C, st, &p->prof);
   else rc = run_tasks(p->wl_invadj, p->ws, p->ws, p->ncol, C, st, GemmAffine(), &p->prof);               // k_l B2^T -> H_L
   if (rc) return rc;
   const bool twin = p->twin_s >= 0 && C == 1;
