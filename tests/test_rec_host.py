@@ -45,3 +45,31 @@ def test_recursion_symmetries_and_seed_scale():
     # L = 512, m = 511: only el = 511, values ~ sin^511(theta): 1e-136 on mid-latitude rings, below 1e-300 near the poles
     B, R = _tables(512, 2, 511)
     assert np.abs(B - R).max() < 2 ** -447 and R[0, 511] == 0.0 and abs(R[255, 511]) > 0.1  # (values below 2^-448 are dropped)
+
+
+def test_recursion_kernels_isa_has_no_unguarded_dpp_read_after_valu_write():
+    """gfx950: a VGPR written by a VALU instruction must not be read as a DPP source within two wait states.  The compiler
+    guards its own DPP instructions but cannot see inside the inline assembly of the recursion kernels (`v_fmac_f64_dpp` /
+    `v_mov_b64_dpp ... row_newbcast`); `dpp_fence` is what keeps the register rotation of the look-ahead away from them (a
+    version without it returned 5e17 in one instantiation).  Static check of the compiled ISA of every instantiation."""
+    import importlib.util
+    import os
+    import shutil
+
+    from conftest import ROOT
+
+    if not shutil.which("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    spec = importlib.util.spec_from_file_location("check_dpp_hazard", os.path.join(ROOT, "scripts", "dev", "check_dpp_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import subprocess
+    import tempfile
+
+    d = tempfile.mkdtemp(prefix="pxm_dpp_")
+    src = os.path.join(ROOT, "pxmcmc_amd", "csrc", "sht_rec.hip")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-c", src, "-o", os.path.join(d, "o.o"),
+                    "--save-temps=obj"], check=True, cwd=os.path.dirname(src), capture_output=True)
+    worst = mod.check(os.path.join(d, "sht_rec-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    shutil.rmtree(d, ignore_errors=True)
+    assert worst >= 2, worst
