@@ -494,6 +494,17 @@ def test_weaklensing_wavelet_operator_fused_matches_composition_and_oracle(L, ma
     go = oop.calc_gradg(fo)
     assert np.abs(f_fused[0] - fo).max() < 1e-10 * np.abs(fo).max()
     assert np.abs(g_fused[0] - go).max() < 1e-9 * np.abs(go).max()
+    # the ONE-chain plan of the same problem (BASELINE configs[4] per GPU): packed two-column GEMM lists and, above the DFT
+    # group (L = 272), the recursion kernels for the spin-2 stage, the twin array of the two top scales and the narrow arrays
+    wl1 = WeakLensing(L, mask=mask, ngal=ngal, max_chains=1)
+    tr1 = SphericalWaveletTransform(L, B, J_min, max_chains=1)
+    op1 = ForwardOperator(data, sig_d, "synthesis", transform=tr1, measurement=wl1, nparams=tr1.ncoefs)
+    plan1 = op1._wl_plan()
+    assert plan1 is not None and (plan1.wl_uses_recursion() > 0) == (L >= 128)
+    f_one = op1.forward(X[0])
+    g_one = op1.calc_gradg(fo)
+    assert np.abs(f_one - fo).max() < 1e-10 * np.abs(fo).max()
+    assert np.abs(g_one - go).max() < 1e-9 * np.abs(go).max()
 
 
 # ---- (vi) the kernels BASELINE configs[4] really runs: the fused wavelet + weak-lensing operator at L = 512 -----------
