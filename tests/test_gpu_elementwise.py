@@ -166,9 +166,11 @@ def test_philox_stream_matches_oracle():
     assert np.array_equal(a[2:], b)
 
 
-def test_noise_stream_moments_and_tails_over_1e8_draws():
-    """The production noise runs Box-Muller on the f32 transcendental units (csrc/philox.h: deviates ~1e-6 relative;
-    the reference draws fp64 randn, pxmcmc/mcmc.py:193).  Bound on what that can do to the chain: over 1.3e8 deviates
+@pytest.mark.parametrize("noise64", [False, True])
+def test_noise_stream_moments_and_tails_over_1e8_draws(noise64):
+    """The noise stream runs Box-Muller either on the f32 transcendental units (csrc/philox.h: deviates ~1e-6 relative)
+    or in double precision by table look-ups (noise64, what bench.py's headline uses; the reference draws fp64 randn,
+    pxmcmc/mcmc.py:193).  Bound on what either can do to the chain: over 1.3e8 deviates
     of the real stream (16 chains x 64 iterations) the first four moments, the |z| > 4 and |z| > 5 tail rates and the
     lag-1 / cross-chain correlations match N(0,1) within 5 standard errors, and so does the complex stream."""
     import torch
@@ -180,7 +182,7 @@ def test_noise_stream_moments_and_tails_over_1e8_draws():
     assert N >= 1e8
     acc = torch.zeros(8, dtype=torch.float64, device="cuda")  # sums of z, z^2, z^3, z^4, [|z|>4], [|z|>5], lag-1, cross-chain
     for it in range(its):
-        z = ops.randn(n, C_=C, complex_=False, seed=2024, chain0=0, it=it)
+        z = ops.randn(n, C_=C, complex_=False, seed=2024, chain0=0, it=it, noise64=noise64)
         z2 = z * z
         acc += torch.stack([z.sum(), z2.sum(), (z2 * z).sum(), (z2 * z2).sum(), (z.abs() > 4).sum().double(),
                             (z.abs() > 5).sum().double(), (z[:, 1:] * z[:, :-1]).sum(), (z[0::2] * z[1::2]).sum()])
@@ -199,7 +201,7 @@ def test_noise_stream_moments_and_tails_over_1e8_draws():
     assert abs(a[6] / (C * its * (n - 1))) < 5 / np.sqrt(C * its * (n - 1))  # neighbouring elements of a chain
     assert abs(a[7] / (N / 2)) < 5 / np.sqrt(N / 2)                          # the two deviates of a chain pair
     # complex stream (params.complex): real and imaginary parts of an element come from one Box-Muller pair
-    zc = ops.randn(1 << 22, C_=4, complex_=True, seed=7, chain0=3, it=5)
+    zc = ops.randn(1 << 22, C_=4, complex_=True, seed=7, chain0=3, it=5, noise64=noise64)
     Nc = zc.numel()
     assert abs(float(zc.real.mean())) < 5 / np.sqrt(Nc) and abs(float(zc.imag.mean())) < 5 / np.sqrt(Nc)
     assert abs(float((zc.real ** 2).mean()) - 1) < 5 * np.sqrt(2 / Nc) and abs(float((zc.imag ** 2).mean()) - 1) < 5 * np.sqrt(2 / Nc)
