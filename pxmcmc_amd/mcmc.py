@@ -12,10 +12,11 @@ Extensions (all optional, defaults reproduce the reference's one-chain behaviour
 * ``chain_offset`` -- global index of this process's first chain (multi-GPU sharding);
 * ``use_graph``    -- replay the fused iteration from a captured HIP graph (default on);
 * ``ring_shortcut`` -- with a scalar ``sig_d`` apply the residual on the ring transforms (default on);
-* ``noise_bits``   -- 32 (default) or 64: arithmetic of the Box-Muller step of the device Philox stream.  32 runs it
-  on the f32 transcendental units (deviates ~1e-6 relative, exact fp64 exponent: tail to 8.5 sigma); 64 evaluates log /
-  sqrt / sincos in double precision as the reference's ``np.random.randn`` does (pxmcmc/mcmc.py:193), ~7 % slower at the
-  benchmark size.  Same Philox counters and uniforms either way: the two streams agree to ~1e-6;
+* ``noise_bits``   -- 64 (default) or 32: arithmetic of the Box-Muller step of the device Philox stream.  64 evaluates
+  log / sqrt / sincos in double precision (table look-ups + short polynomials, csrc/philox.h) as the reference's
+  ``np.random.randn`` does (pxmcmc/mcmc.py:193); 32 runs it on the f32 transcendental units (deviates ~1e-6 relative,
+  exact fp64 exponent: tail to 8.5 sigma), ~2 % faster at the benchmark size.  Same Philox counters and uniforms either
+  way: the two streams agree to ~1e-6;
 * ``real_pairs``   -- with REAL data, a real start point and ``params.complex == False`` the reference's
   complex128 state has a zero imaginary part (every operator of the path maps real fields to real
   fields); the fused wavelet path then carries two real chains per complex slot -- chain 2c in the real
@@ -93,7 +94,7 @@ class PxMCMC:
     """
 
     def __init__(self, forward, prior, mcmcparams=PxMCMCParams(), nchains=1, rng="philox", seed=0, chain_offset=0,
-                 use_graph=True, ring_shortcut=True, real_pairs=True, noise_bits=32):
+                 use_graph=True, ring_shortcut=True, real_pairs=True, noise_bits=64):
         self.forward = forward
         self.prior = prior
         for attr in mcmcparams.__dict__.keys():

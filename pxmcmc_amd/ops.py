@@ -733,7 +733,8 @@ def tables_trim():
 
 
 def noise_bits():
-    """32: the DEFAULT precision of the Box-Muller step of the device noise stream; every noise-drawing call takes
+    """32: the precision of the Box-Muller step of the device noise stream WITHOUT the flag (the samplers of mcmc.py pass
+    the flag by default: ``noise_bits=64``); every noise-drawing call takes
     ``noise64=True`` for the double-precision evaluation (PXM_NOISE_F64, include/pxmcmc_amd.h)"""
     return int(lib.pxm_noise_bits())
 

@@ -139,7 +139,8 @@ def test_fused_step_fp64_noise_equals_injected_oracle_stream(L, pairs):
 
 def test_sampler_noise_bits_64_graph_equals_eager_and_tracks_default():
     """MYULA(noise_bits=64): HIP-graph replay == eager stepping (bit for bit), and the chain stays within the f32 units'
-    accuracy of the default stream over a few iterations; PxMALA and the generic engine take the flag too."""
+    accuracy of the f32-unit stream over a few iterations; PxMALA and the generic engine take the flag too; 64 is the
+    samplers' default (the reference draws fp64 randn)"""
     from pxmcmc_amd.forward import SphericalWaveletTransformOperator
     from pxmcmc_amd.mcmc import MYULA, PxMALA, PxMCMCParams
     from pxmcmc_amd.prior import S2_Wavelets_L1
@@ -152,7 +153,7 @@ def test_sampler_noise_bits_64_graph_equals_eager_and_tracks_default():
     reg = S2_Wavelets_L1("synthesis", None, None, lmda, L=L, B=B, J_min=J_min)
     p = PxMCMCParams(lmda=lmda, delta=delta, nsamples=2, nburn=3, ngap=2, verbosity=0)
     runs = {}
-    for key, kw in (("g64", dict(noise_bits=64)), ("e64", dict(noise_bits=64, use_graph=False)), ("g32", dict())):
+    for key, kw in (("g64", dict(noise_bits=64)), ("e64", dict(noise_bits=64, use_graph=False)), ("g32", dict(noise_bits=32))):
         s = MYULA(op, reg, p, nchains=C, seed=5, **kw)
         _quiet(s.run, start_point=np.zeros(op.nparams))
         runs[key] = (s.chain.copy(), s.used_graph)
@@ -168,13 +169,14 @@ def test_sampler_noise_bits_64_graph_equals_eager_and_tracks_default():
 
     rega = L1("analysis", opa.transform.inverse, opa.transform.inverse_adjoint, lmda)  # pxmcmc/prior.py:52-53
     a64 = MYULA(opa, rega, p, nchains=2, seed=5, noise_bits=64)
-    a32 = MYULA(opa, rega, p, nchains=2, seed=5)
+    a32 = MYULA(opa, rega, p, nchains=2, seed=5, noise_bits=32)
     _quiet(a64.run, start_point=np.zeros(opa.nparams))
     _quiet(a32.run, start_point=np.zeros(opa.nparams))
     d = np.abs(a64.chain - a32.chain).max() / np.sqrt(2 * delta)
     assert 0 < d < 1e-4, d
     q = PxMCMCParams(lmda=lmda, delta=delta, nsamples=2, nburn=1, ngap=1, verbosity=0)
-    m64 = PxMALA(op, reg, q, nchains=2, seed=8, noise_bits=64)
+    m64 = PxMALA(op, reg, q, nchains=2, seed=8)
+    assert m64.noise_bits == 64 and a64.noise_bits == 64  # the default
     _quiet(m64.run, start_point=np.zeros(op.nparams))
     assert np.isfinite(m64.chain).all()
 
