@@ -418,8 +418,8 @@ def test_full_size_step_properties_L256():
     assert np.abs(((Xn - det).imag).cpu().numpy()).max() < 1e-9 * np.sqrt(2 * delta)
     assert np.abs(w[0] - w[1]).max() > 1 and abs(np.corrcoef(w[0], w[1])[0, 1]) < 0.02
     # ... and that noise is the documented Philox stream of each chain
-    ref = ops.randn(op.nparams, C, seed=3, chain0=0, it=17).cpu().numpy()
-    assert np.abs(w - ref).max() < 1e-6
+    ref = ops.randn(op.nparams, C, seed=3, chain0=0, it=17, noise64=s2.noise64).cpu().numpy()
+    assert s2.noise64 and np.abs(w - ref).max() < 1e-6  # (w is recovered by a subtraction at the scale of X: ~1e-8)
 
 
 def test_philox_myula_stationary_moments_toy():
