@@ -321,12 +321,22 @@ int pxm_pxmala_accept(const double* logalpha_terms, const double* u, uint64_t se
  *                        logtrans_out[c] = calc_logtransition(X, X', proxf, gradg) as (re, im);
  *                        prior_out[c] = sum |w X'| (w = prior_weights [n] or NULL) -- ONE pass over the state.
  *                        iter_dev: optional caller-owned device counter added to iter (HIP-graph replay).
- *                        scratch: 4 * pxm_reduce_scratch_doubles(C) doubles.
+ *                        scratch: 4 * pxm_reduce_scratch_doubles(C) doubles.  logtrans_out == prior_out == NULL: the
+ *                        totals are DEFERRED -- the per-slice sums stay in `scratch` for pxm_pxmala_finish.
  *   pxm_pxmala_accept2 : logalpha = Re(logtrans_pc + logpi' - logtrans_cp - logpi), logpi' = -mu prior' - L2';
  *                        accept iff log(u) < logalpha (u injected [C] or the Philox uniform of (seed, chain, iteration));
  *                        accepted chains take (logpi', L2', prior') into their state scalars (logpi_c, L2_c as (re, im),
  *                        prior_c); delta_dev adapted when tune (:277-279) with the iteration number iter + *iter_dev;
  *                        acc_trace / delta_trace: optional [chunk][C] ring buffers written at row iteration % chunk.
+ *   pxm_pxmala_finish  : everything between the proposal's gradient and the conditional copy in TWO launches instead of
+ *                        seven: (i) ONE grid with the slices of the reverse transition sum of
+ *                        calc_logtransition(X', X, proxf', gradg') [n, dtype] and of L2' = vdot(d, invcov d),
+ *                        d = data - preds' [n_data, data_dtype; invcov as for pxm_reduce_l2]; (ii) ONE workgroup that
+ *                        totals those and the deferred sums of pxm_pxmala_propose (`propose_scratch`: that call's scratch) in
+ *                        the order of the separate reductions, stores logtrans_pc / logtrans_cp / L2' as (re, im) [C] and
+ *                        prior' [C] for observers, and runs the test of pxm_pxmala_accept2.  bump_counter: optional
+ *                        device counter advanced by one AFTER every chain has read iter_dev (replaces pxm_counter_add
+ *                        in a captured iteration).  scratch: 2 * pxm_reduce_scratch_doubles(C) doubles.
  *   pxm_select_copy_many : up to 4 arrays per call, dst_a[c] = src_a[c] for accepted chains.
  *   pxm_counter_add    : *counter += inc on the stream (after every reader of the iteration). */
 int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, const double* T, double T_scalar,
@@ -339,6 +349,13 @@ int pxm_pxmala_accept2(const double* logtrans_pc, const double* logtrans_cp, con
                        uint64_t chain0, uint64_t iter, const uint64_t* iter_dev, int32_t* accept_out, double* delta_dev,
                        int tune, double lmda, int32_t* acc_trace, double* delta_trace, int chunk, int C,
                        pxm_stream_t stream);
+int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_prop, const void* gradg_prop, int64_t n,
+                      int dtype, const void* preds_prop, const void* data, const void* invcov, int invcov_complex,
+                      int64_t n_data, int data_dtype, const double* propose_scratch, double mu, double lmda, double* logpi_c,
+                      double* L2_c, double* prior_c, const double* u, uint64_t seed, uint64_t chain0, uint64_t iter,
+                      const uint64_t* iter_dev, int32_t* accept_out, double* delta_dev, int tune, int32_t* acc_trace,
+                      double* delta_trace, int chunk, double* logtrans_pc_out, double* logtrans_cp_out, double* prior_p_out,
+                      double* L2_p_out, double* scratch, uint64_t* bump_counter, int C, pxm_stream_t stream);
 int pxm_select_copy_many(const int32_t* flag, int narrays, const void* const* src, void* const* dst, const int64_t* n,
                          const int* esize, int C, pxm_stream_t stream);
 int pxm_counter_add(uint64_t* counter_dev, uint64_t inc, pxm_stream_t stream);

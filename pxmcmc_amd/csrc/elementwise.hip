@@ -162,12 +162,14 @@ __global__ void k_l1_partial(const double* __restrict__ X, const double* __restr
 }
 
 // L2 = vdot(d, invcov d) = sum conj(d) * (invcov * d), d = data - preds   (pxmcmc/mcmc.py:78-79)
+// (bx of nb: the slice this workgroup sums -- the kernels below and the merged tail kernel of PxMALA share the bodies, so a
+// slice's sum does not depend on which launch computed it)
 template <bool CPLX, bool ICPLX>
-__global__ void k_l2_partial(const double* __restrict__ preds, const double* __restrict__ data,
-                             const double* __restrict__ invcov, double* __restrict__ part, int64_t n) {
-  const int c = blockIdx.y;
+__device__ __forceinline__ void l2_partial_body(const double* __restrict__ preds, const double* __restrict__ data,
+                                                const double* __restrict__ invcov, double* __restrict__ part, int64_t n,
+                                                int c, int bx, int nb) {
   double2 acc{0.0, 0.0};
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = bx * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)nb * blockDim.x) {
     if (CPLX) {
       const double2 d = csub(reinterpret_cast<const double2*>(data)[i], reinterpret_cast<const double2*>(preds)[(int64_t)c * n + i]);
       double2 wd;
@@ -182,7 +184,13 @@ __global__ void k_l2_partial(const double* __restrict__ preds, const double* __r
     }
   }
   double2 tot = block_sum2(acc);
-  if (threadIdx.x == 0) reinterpret_cast<double2*>(part)[(int64_t)c * gridDim.x + blockIdx.x] = tot;
+  if (threadIdx.x == 0) reinterpret_cast<double2*>(part)[(int64_t)c * nb + bx] = tot;
+}
+
+template <bool CPLX, bool ICPLX>
+__global__ void k_l2_partial(const double* __restrict__ preds, const double* __restrict__ data,
+                             const double* __restrict__ invcov, double* __restrict__ part, int64_t n) {
+  l2_partial_body<CPLX, ICPLX>(preds, data, invcov, part, n, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
 // vdot(a, b) = sum conj(a) * b per chain (logpi's L2 with a full inverse covariance: b = invcov @ a)
@@ -206,15 +214,13 @@ __global__ void k_vdot_partial(const double* __restrict__ A, const double* __res
 
 // S = sum (X2 - X1 - (d/2) g)^2 with g = -((X1 - proxf)/l) - gradg; complex squares, no abs (literal)
 template <bool CPLX>
-__global__ void k_logtrans_partial(const double* __restrict__ X1, const double* __restrict__ X2,
-                                   const double* __restrict__ P, const double* __restrict__ G,
-                                   const double* __restrict__ delta_dev, double delta, double lmda,
-                                   double* __restrict__ part, int64_t n) {
-  const int c = blockIdx.y;
-  const double d = delta_dev ? delta_dev[c] : delta;
+__device__ __forceinline__ void logtrans_partial_body(const double* __restrict__ X1, const double* __restrict__ X2,
+                                                      const double* __restrict__ P, const double* __restrict__ G, double d,
+                                                      double lmda, double* __restrict__ part, int64_t n, int c, int bx,
+                                                      int nb) {
   const int64_t base = (int64_t)c * n;
   double2 acc{0.0, 0.0};
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t i = bx * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)nb * blockDim.x) {
     if (CPLX) {
       const double2 x1 = reinterpret_cast<const double2*>(X1)[base + i], x2 = reinterpret_cast<const double2*>(X2)[base + i];
       const double2 p = reinterpret_cast<const double2*>(P)[base + i], g = reinterpret_cast<const double2*>(G)[base + i];
@@ -229,7 +235,31 @@ __global__ void k_logtrans_partial(const double* __restrict__ X1, const double* 
     }
   }
   double2 tot = block_sum2(acc);
-  if (threadIdx.x == 0) reinterpret_cast<double2*>(part)[(int64_t)c * gridDim.x + blockIdx.x] = tot;
+  if (threadIdx.x == 0) reinterpret_cast<double2*>(part)[(int64_t)c * nb + bx] = tot;
+}
+
+template <bool CPLX>
+__global__ void k_logtrans_partial(const double* __restrict__ X1, const double* __restrict__ X2,
+                                   const double* __restrict__ P, const double* __restrict__ G,
+                                   const double* __restrict__ delta_dev, double delta, double lmda,
+                                   double* __restrict__ part, int64_t n) {
+  const int c = blockIdx.y;
+  logtrans_partial_body<CPLX>(X1, X2, P, G, delta_dev ? delta_dev[c] : delta, lmda, part, n, c, blockIdx.x, gridDim.x);
+}
+
+// PxMALA, after the forward model and the gradient of the proposal: the reverse transition sum S(X', X) and the L2 of the
+// proposal's predictions in ONE grid -- workgroups [0, nb_lt) are the slices of the transition sum, [nb_lt, nb_lt + nb_l2)
+// those of the L2 (two short latency-bound launches otherwise)
+template <bool CPLX, bool DCPLX, bool ICPLX>
+__global__ void k_pxmala_tail_partial(const double* __restrict__ X1, const double* __restrict__ X2,
+                                      const double* __restrict__ P, const double* __restrict__ G,
+                                      const double* __restrict__ delta_dev, double lmda, double* __restrict__ part_lt,
+                                      int64_t n, int nb_lt, const double* __restrict__ preds,
+                                      const double* __restrict__ data, const double* __restrict__ invcov,
+                                      double* __restrict__ part_l2, int64_t nd, int nb_l2) {
+  const int c = blockIdx.y;
+  if ((int)blockIdx.x < nb_lt) logtrans_partial_body<CPLX>(X1, X2, P, G, delta_dev[c], lmda, part_lt, n, c, blockIdx.x, nb_lt);
+  else l2_partial_body<DCPLX, ICPLX>(preds, data, invcov, part_l2, nd, c, blockIdx.x - nb_lt, nb_l2);
 }
 
 // mode 0: out[c] = sum of partials; mode 1 (logtransition): out[c] = -(d/2) * S^2 (complex)
@@ -329,38 +359,100 @@ __global__ void k_pxmala_propose_final(const double* __restrict__ part, double* 
   }
 }
 
-// Metropolis test, state bookkeeping, delta adaptation and traces of one PxMALA iteration, one thread per chain
+// Metropolis test, state bookkeeping, delta adaptation and traces of one PxMALA iteration for chain c
 // (pxmcmc/mcmc.py:244-260,277-279).  logpi' = -mu prior' - L2' (mcmc.py:81); only real parts enter logalpha.
-__global__ void k_pxmala_accept2(const double2* __restrict__ lt_pc, const double2* __restrict__ lt_cp,
-                                 const double* __restrict__ prior_p, const double2* __restrict__ L2_p, double mu,
-                                 double2* __restrict__ logpi_c, double2* __restrict__ L2_c, double* __restrict__ prior_c,
-                                 const double* __restrict__ u, uint64_t seed, uint64_t chain0, uint64_t iter,
-                                 const uint64_t* __restrict__ iter_dev, int32_t* __restrict__ accept,
-                                 double* __restrict__ delta_dev, int tune, double lmda, int32_t* __restrict__ acc_trace,
-                                 double* __restrict__ delta_trace, int chunk, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const uint64_t it = iter + (iter_dev ? *iter_dev : 0);
-  const double2 lpp{-mu * prior_p[c] - L2_p[c].x, -L2_p[c].y};
-  const double logalpha = lt_pc[c].x + lpp.x - lt_cp[c].x - logpi_c[c].x;
-  const double uu = u ? u[c] : philox_uniform(seed, chain0 + c, it);
+struct AcceptArgs {
+  double mu, lmda;
+  double2* logpi_c;
+  double2* L2_c;
+  double* prior_c;
+  const double* u;
+  uint64_t seed, chain0, iter;
+  const uint64_t* iter_dev;
+  int32_t* accept;
+  double* delta_dev;
+  int tune;
+  int32_t* acc_trace;
+  double* delta_trace;
+  int chunk, C;
+};
+__device__ __forceinline__ void accept_chain(const AcceptArgs& a, int c, double2 lt_pc, double2 lt_cp, double prior_p, double2 L2_p) {
+  const uint64_t it = a.iter + (a.iter_dev ? *a.iter_dev : 0);
+  const double2 lpp{-a.mu * prior_p - L2_p.x, -L2_p.y};
+  const double logalpha = lt_pc.x + lpp.x - lt_cp.x - a.logpi_c[c].x;
+  const double uu = a.u ? a.u[c] : philox_uniform(a.seed, a.chain0 + c, it);
   const int acc = log(uu) < logalpha ? 1 : 0;
-  accept[c] = acc;
+  a.accept[c] = acc;
   if (acc) {
-    logpi_c[c] = lpp;
-    L2_c[c] = L2_p[c];
-    prior_c[c] = prior_p[c];
+    a.logpi_c[c] = lpp;
+    a.L2_c[c] = L2_p;
+    a.prior_c[c] = prior_p;
   }
-  double d = delta_dev[c];
-  if (tune) {  // pxmcmc/mcmc.py:277-279
+  double d = a.delta_dev[c];
+  if (a.tune) {  // pxmcmc/mcmc.py:277-279
     d = d * (1 + (acc - 0.5) / pow((double)(it + 1), 0.75));
-    d = fmin(fmax(d, lmda * 1e-8), lmda / 2);
-    delta_dev[c] = d;
+    d = fmin(fmax(d, a.lmda * 1e-8), a.lmda / 2);
+    a.delta_dev[c] = d;
   }
-  if (acc_trace) {
-    const int64_t k = (int64_t)(it % (uint64_t)chunk);
-    acc_trace[k * C + c] = acc;
-    delta_trace[k * C + c] = d;
+  if (a.acc_trace) {
+    const int64_t k = (int64_t)(it % (uint64_t)a.chunk);
+    a.acc_trace[k * a.C + c] = acc;
+    a.delta_trace[k * a.C + c] = d;
+  }
+}
+
+__global__ void k_pxmala_accept2(const double2* __restrict__ lt_pc, const double2* __restrict__ lt_cp,
+                                 const double* __restrict__ prior_p, const double2* __restrict__ L2_p, AcceptArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  accept_chain(a, c, lt_pc[c], lt_cp[c], prior_p[c], L2_p[c]);
+}
+
+// The same test fed by the PARTIAL sums of the iteration (pxm_pxmala_propose with deferred totals, k_pxmala_tail_partial):
+// ONE workgroup, a wave per chain; the wave adds the slices in the order of k_reduce_final / k_pxmala_propose_final (so the
+// totals are the ones the separate kernels give), lane 0 decides.  The totals are also stored for observers.  `bump`: the
+// device-resident iteration counter of a captured iteration, advanced here after every chain has read it (one workgroup,
+// one barrier) -- the last reader of the counter in an iteration.
+__global__ __launch_bounds__(1024) void k_pxmala_accept3(const double* __restrict__ part_prop, int slices_prop,
+                                                         const double2* __restrict__ part_lt, int slices_lt,
+                                                         const double2* __restrict__ part_l2, int slices_l2,
+                                                         double2* __restrict__ lt_pc_out, double2* __restrict__ lt_cp_out,
+                                                         double* __restrict__ prior_p_out, double2* __restrict__ L2_p_out,
+                                                         AcceptArgs a, uint64_t* __restrict__ bump) {
+  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int c = threadIdx.x >> 6; c < a.C; c += nw) {
+    double2 s_cp{0.0, 0.0}, s_pc{0.0, 0.0}, l2{0.0, 0.0};
+    double pr = 0.0;
+    for (int sl = lane; sl < slices_prop; sl += 64) {
+      const double* o = part_prop + ((int64_t)c * slices_prop + sl) * 4;
+      s_cp = cadd(s_cp, double2{o[0], o[1]});
+      pr += o[2];
+    }
+    for (int sl = lane; sl < slices_lt; sl += 64) s_pc = cadd(s_pc, part_lt[(int64_t)c * slices_lt + sl]);
+    for (int sl = lane; sl < slices_l2; sl += 64) l2 = cadd(l2, part_l2[(int64_t)c * slices_l2 + sl]);
+    for (int off = 32; off > 0; off >>= 1) {
+      s_cp.x += __shfl_down(s_cp.x, off);
+      s_cp.y += __shfl_down(s_cp.y, off);
+      pr += __shfl_down(pr, off);
+      s_pc.x += __shfl_down(s_pc.x, off);
+      s_pc.y += __shfl_down(s_pc.y, off);
+      l2.x += __shfl_down(l2.x, off);
+      l2.y += __shfl_down(l2.y, off);
+    }
+    if (lane == 0) {
+      const double d = a.delta_dev[c];  // (before its adaptation below: the delta both transitions were proposed with)
+      const double2 q_cp = cmul(s_cp, s_cp), q_pc = cmul(s_pc, s_pc);
+      const double2 lt_cp{-(1.0 / 2 * d) * q_cp.x, -(1.0 / 2 * d) * q_cp.y}, lt_pc{-(1.0 / 2 * d) * q_pc.x, -(1.0 / 2 * d) * q_pc.y};
+      lt_cp_out[c] = lt_cp;
+      lt_pc_out[c] = lt_pc;
+      prior_p_out[c] = pr;
+      L2_p_out[c] = l2;
+      accept_chain(a, c, lt_pc, lt_cp, pr, l2);
+    }
+  }
+  if (bump) {
+    __syncthreads();
+    if (threadIdx.x == 0) *bump += 1;
   }
 }
 
@@ -636,8 +728,9 @@ int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, cons
                        void* X_prop, void* proxf_prop, double* logtrans_out, double* prior_out, double* scratch,
                        int64_t n, int C, int dtype, pxm_stream_t stream) {
   PXM_REQUIRE(n >= 1 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_pxmala_propose: bad n / C / dtype");
-  PXM_REQUIRE(X && proxf && gradg && delta_dev && X_prop && proxf_prop && logtrans_out && prior_out && scratch,
-              "pxm_pxmala_propose: null buffer");
+  PXM_REQUIRE(X && proxf && gradg && delta_dev && X_prop && proxf_prop && scratch, "pxm_pxmala_propose: null buffer");
+  PXM_REQUIRE((logtrans_out == nullptr) == (prior_out == nullptr),
+              "pxm_pxmala_propose: logtrans_out and prior_out are given together, or both null (totals deferred to pxm_pxmala_finish)");
   PXM_REQUIRE((noise_complex & ~(1 | PXM_NOISE_F64)) == 0, "pxm_pxmala_propose: noise_complex must be 0 or 1 (| PXM_NOISE_F64)");
   PXM_REQUIRE(dtype == 1 || !(noise_complex & 1), "pxm_pxmala_propose: complex noise needs a complex state");
   hipStream_t st = (hipStream_t)stream;
@@ -650,9 +743,22 @@ int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, cons
   else
     hipLaunchKernelGGL(k_pxmala_propose<false>, g, b, 0, st, (const double*)X, (const double*)proxf, (const double*)gradg, T,
                        T_scalar, prior_weights, delta_dev, lmda, ns, (double*)X_prop, (double*)proxf_prop, scratch, n);
-  hipLaunchKernelGGL(k_pxmala_propose_final, dim3(C), dim3(64), 0, st, scratch, logtrans_out, prior_out, RS, delta_dev);
+  if (logtrans_out)
+    hipLaunchKernelGGL(k_pxmala_propose_final, dim3(C), dim3(64), 0, st, scratch, logtrans_out, prior_out, RS, delta_dev);
   PXM_HIP(hipGetLastError());
   return 0;
+}
+
+static AcceptArgs make_accept_args(double mu, double lmda, double* logpi_c, double* L2_c, double* prior_c, const double* u,
+                                   uint64_t seed, uint64_t chain0, uint64_t iter, const uint64_t* iter_dev, int32_t* accept_out,
+                                   double* delta_dev, int tune, int32_t* acc_trace, double* delta_trace, int chunk, int C) {
+  AcceptArgs a;
+  a.mu = mu, a.lmda = lmda;
+  a.logpi_c = (double2*)logpi_c, a.L2_c = (double2*)L2_c, a.prior_c = prior_c;
+  a.u = u, a.seed = seed, a.chain0 = chain0, a.iter = iter, a.iter_dev = iter_dev;
+  a.accept = accept_out, a.delta_dev = delta_dev, a.tune = tune;
+  a.acc_trace = acc_trace, a.delta_trace = delta_trace, a.chunk = chunk, a.C = C;
+  return a;
 }
 
 int pxm_pxmala_accept2(const double* logtrans_pc, const double* logtrans_cp, const double* prior_p, const double* L2_p,
@@ -664,8 +770,54 @@ int pxm_pxmala_accept2(const double* logtrans_pc, const double* logtrans_cp, con
               "pxm_pxmala_accept2: null buffer");
   PXM_REQUIRE((acc_trace == nullptr) == (delta_trace == nullptr) && (!acc_trace || chunk >= 1), "pxm_pxmala_accept2: bad trace buffers");
   hipLaunchKernelGGL(k_pxmala_accept2, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double2*)logtrans_pc,
-                     (const double2*)logtrans_cp, prior_p, (const double2*)L2_p, mu, (double2*)logpi_c, (double2*)L2_c, prior_c, u,
-                     seed, chain0, iter, iter_dev, accept_out, delta_dev, tune, lmda, acc_trace, delta_trace, chunk, C);
+                     (const double2*)logtrans_cp, prior_p, (const double2*)L2_p,
+                     make_accept_args(mu, lmda, logpi_c, L2_c, prior_c, u, seed, chain0, iter, iter_dev, accept_out, delta_dev, tune,
+                                      acc_trace, delta_trace, chunk, C));
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_prop, const void* gradg_prop, int64_t n,
+                      int dtype, const void* preds_prop, const void* data, const void* invcov, int invcov_complex,
+                      int64_t n_data, int data_dtype, const double* propose_scratch, double mu, double lmda, double* logpi_c,
+                      double* L2_c, double* prior_c, const double* u, uint64_t seed, uint64_t chain0, uint64_t iter,
+                      const uint64_t* iter_dev, int32_t* accept_out, double* delta_dev, int tune, int32_t* acc_trace,
+                      double* delta_trace, int chunk, double* logtrans_pc_out, double* logtrans_cp_out, double* prior_p_out,
+                      double* L2_p_out, double* scratch, uint64_t* bump_counter, int C, pxm_stream_t stream) {
+  PXM_REQUIRE(n >= 1 && n_data >= 1 && C >= 1 && (dtype == 0 || dtype == 1) && (data_dtype == 0 || data_dtype == 1),
+              "pxm_pxmala_finish: bad n / n_data / C / dtype");
+  PXM_REQUIRE(X_prop && X_curr && proxf_prop && gradg_prop && preds_prop && data && invcov && propose_scratch && scratch,
+              "pxm_pxmala_finish: null buffer");
+  PXM_REQUIRE(data_dtype == 1 || !invcov_complex, "pxm_pxmala_finish: complex invcov needs complex data");
+  PXM_REQUIRE(logpi_c && L2_c && prior_c && accept_out && delta_dev && logtrans_pc_out && logtrans_cp_out && prior_p_out && L2_p_out,
+              "pxm_pxmala_finish: null state / output buffer");
+  PXM_REQUIRE((acc_trace == nullptr) == (delta_trace == nullptr) && (!acc_trace || chunk >= 1), "pxm_pxmala_finish: bad trace buffers");
+  hipStream_t st = (hipStream_t)stream;
+  const int RS = red_slices(n), RD = red_slices(n_data);
+  double *part_lt = scratch, *part_l2 = scratch + red_scratch_doubles(C);
+  const double *x1 = (const double*)X_prop, *x2 = (const double*)X_curr, *px = (const double*)proxf_prop, *g = (const double*)gradg_prop;
+  const double *pp = (const double*)preds_prop, *dd = (const double*)data, *ic = (const double*)invcov;
+  dim3 grid(RS + RD, C), blk(256);
+#define PXM_TAIL(CP, DC, IC_)                                                                                              \
+  hipLaunchKernelGGL((k_pxmala_tail_partial<CP, DC, IC_>), grid, blk, 0, st, x1, x2, px, g, delta_dev, lmda, part_lt, n, RS, pp, dd, \
+                     ic, part_l2, n_data, RD)
+  if (dtype) {
+    if (data_dtype && invcov_complex) PXM_TAIL(true, true, true);
+    else if (data_dtype) PXM_TAIL(true, true, false);
+    else PXM_TAIL(true, false, false);
+  } else {
+    if (data_dtype && invcov_complex) PXM_TAIL(false, true, true);
+    else if (data_dtype) PXM_TAIL(false, true, false);
+    else PXM_TAIL(false, false, false);
+  }
+#undef PXM_TAIL
+  const int nw = std::min(C, 16);
+  hipLaunchKernelGGL(k_pxmala_accept3, dim3(1), dim3(64 * nw), 0, st, propose_scratch, RS, (const double2*)part_lt, RS,
+                     (const double2*)part_l2, RD, (double2*)logtrans_pc_out, (double2*)logtrans_cp_out, prior_p_out,
+                     (double2*)L2_p_out,
+                     make_accept_args(mu, lmda, logpi_c, L2_c, prior_c, u, seed, chain0, iter, iter_dev, accept_out, delta_dev, tune,
+                                      acc_trace, delta_trace, chunk, C),
+                     bump_counter);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -684,7 +836,10 @@ int pxm_select_copy_many(const int32_t* flag, int narrays, const void* const* sr
     most = std::max(most, cs.nwords[a]);
   }
   if (most == 0) return 0;
+  // (workgroups of rejected chains leave at once: the launch then costs its dispatch, so the grid is kept to about one
+  // resident round -- 2048 workgroups per chain batch -- and every thread loops)
   dim3 g = ew_grid(most, C);
+  g.x = std::min<unsigned>(g.x, std::max(64u, 2048u / (unsigned)(C * narrays)));
   g.z = narrays;
   hipLaunchKernelGGL(k_select_copy_many, g, dim3(256), 0, (hipStream_t)stream, flag, cs);
   PXM_HIP(hipGetLastError());

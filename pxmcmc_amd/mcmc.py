@@ -662,6 +662,7 @@ class PxMALA(MYULA):
     """
 
     _CHUNK = 1024
+    fuse_tail = True  # totals + Metropolis test of an iteration in pxm_pxmala_finish (False: the separate calls, same numbers)
 
     def __init__(self, forward, prox, mcmcparams=PxMCMCParams(), tune_delta=True, track_transitions=False, max_iter=None,
                  **kwargs):
@@ -690,6 +691,24 @@ class PxMALA(MYULA):
             return ops.reduce_vdot(d, self.forward.invcov.matvec(d))
         invcov = self.forward.invcov.diag if hasattr(self.forward.invcov, "diag") else ops.as_device(self.forward.invcov.diagonal())
         return ops.reduce_l2(p.to(dt), data, invcov)
+
+    def _l2_inputs(self, preds):
+        """(preds, data, diagonal of invcov) as _l2_dev hands them to the reduction; None with a full inverse covariance"""
+        if hasattr(self.forward.invcov, "matvec"):
+            return None
+        p = ops.as_device(preds)
+        dt = self.forward._resid_dtype(p) if hasattr(self.forward, "_resid_dtype") else p.dtype
+        cache = getattr(self, "_l2_data", None)
+        if cache is None or cache[0] is not self.forward.data or cache[1].dtype != dt:
+            src = getattr(self.forward, "data_dev", None)
+            src = ops.as_device(self.forward.data) if src is None else src
+            self._l2_data = cache = (self.forward.data, src.reshape(-1).to(dt).contiguous())
+        ic = getattr(self, "_l2_invcov", None)
+        if ic is None or ic[0] is not self.forward.invcov:
+            inv = self.forward.invcov
+            diag = inv.diag if hasattr(inv, "diag") else ops.as_device(inv.diagonal())
+            self._l2_invcov = ic = (inv, ops.as_device(diag).reshape(-1).contiguous())
+        return p.to(dt), cache[1], ic[1]
 
     def run(self, start_point=None):
         """Run the algorithm (pxmcmc/mcmc.py:218-275); every chain carries its own delta and accept flag.
@@ -729,14 +748,25 @@ class PxMALA(MYULA):
         it_dev = torch.zeros(1, dtype=torch.int64, device=dev)  # device-resident iteration number (graph replay)
         host_rng = self.rng == "numpy"
 
-        def iteration(i_host, counter):
+        # stock prior + diagonal inverse covariance: the totals of the proposal pass are deferred and everything between
+        # the proposal's gradient and the conditional copy is two launches (pxm_pxmala_finish) instead of seven; the sums
+        # are added in the same order either way (``fuse_tail = False``: the separate calls, bit-identical)
+        fused_tail = bool(stock and self.fuse_tail and not hasattr(self.forward.invcov, "matvec"))
+        if fused_tail:
+            prop_scratch = ops.pxmala_propose_scratch(C, dev)
+            fin_scratch = torch.empty(2 * ops.reduce_scratch_doubles(C), dtype=torch.float64, device=dev)
+            lt_pc = torch.empty(C, dtype=torch.complex128, device=dev)
+            L2_p = torch.empty(C, dtype=torch.complex128, device=dev)
+
+        def iteration(i_host, counter, bump=None):
             """one PxMALA iteration; Philox / adaptation use iteration number i_host + *counter"""
             kw = dict(seed=self.seed, chain0=self.chain_offset, it=i_host)
             noise = self._host_noise(X_curr) if host_rng else None
             if stock:
                 ops.pxmala_propose(X_curr, proxf_curr, gradg_curr, T_dev, w_prior, delta_dev, self.lmda, X_prop, proxf_prop,
-                                   lt_cp, prior_p, noise=noise, noise_complex=bool(self.complex), iter_dev=counter,
-                                   noise64=self.noise64, **kw)
+                                   None if fused_tail else lt_cp, None if fused_tail else prior_p, noise=noise,
+                                   noise_complex=bool(self.complex), iter_dev=counter, noise64=self.noise64,
+                                   scratch=prop_scratch if fused_tail else None, **kw)
                 Xp, pxp, ltc, prp = X_prop, proxf_prop, lt_cp, prior_p
             else:  # user-supplied prior / chain_step: the reference's own sequence of calls (mcmc.py:231-242)
                 if type(self).chain_step is MYULA.chain_step:
@@ -752,6 +782,15 @@ class PxMALA(MYULA):
                 prp = prp.to(torch.float64).contiguous()
             pp = ops.as_device(self.forward.forward(Xp))
             gp = ops.as_device(self.forward.calc_gradg(pp), dt)
+            if fused_tail:
+                p_, data_, ic_ = self._l2_inputs(pp)
+                u = np.array([np.random.rand() for _ in range(C)]) if host_rng else None
+                ops.pxmala_finish(Xp, X_curr, pxp, gp.contiguous(), p_, data_, ic_, prop_scratch, self.mu, self.lmda, logpiXc,
+                                  L2Xc, priorXc, accept, delta_dev, self.tune_delta, lt_pc, lt_cp, prior_p, L2_p, fin_scratch,
+                                  u=u, iter_dev=counter, acc_trace=acc_buf, delta_trace=delta_buf, bump=bump, **kw)
+                self._last_transitions = (lt_cp, lt_pc)
+                ops.select_copy_many(accept, [(Xp, X_curr), (pp.to(curr_preds.dtype), curr_preds), (gp, gradg_curr), (pxp, proxf_curr)])
+                return
             L2p = self._l2_dev(pp)
             ltp = ops.logtransition(Xp, X_curr, pxp, gp, delta_dev, self.lmda)
             self._last_transitions = (ltc, ltp)  # q(X'|X), q(X|X') of this iteration (pxmcmc/mcmc.py:240-241)
@@ -777,8 +816,11 @@ class PxMALA(MYULA):
                     t.copy_(s_)
                 g = torch.cuda.CUDAGraph()
                 with ops.capture_scope(), torch.cuda.graph(g):
-                    iteration(0, it_dev)
-                    ops.counter_add(it_dev, 1)
+                    if fused_tail:
+                        iteration(0, it_dev, bump=it_dev)  # (the counter advances inside pxm_pxmala_finish)
+                    else:
+                        iteration(0, it_dev)
+                        ops.counter_add(it_dev, 1)
                 graph = g
             except Exception as exc:
                 graph = None

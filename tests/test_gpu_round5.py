@@ -333,3 +333,52 @@ def test_config5_one_chain_path_equals_the_two_chain_path_L512():
     for k in (0, 1):
         a, b = res[1][k], res[2][k]
         assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-11 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("C", [1, 3, 17])
+def test_pxmala_fused_tail_equals_separate_calls(C):
+    """pxm_pxmala_finish (deferred totals of the proposal pass + reverse transition sum and L2 in one grid + totals and
+    Metropolis test in one workgroup, the iteration counter advanced inside) against the separate calls it replaces
+    (pxm_pxmala_propose totals, pxm_reduce_l2, pxm_logtransition, pxm_pxmala_accept2, pxm_counter_add): the slices are
+    summed by the same bodies and added in the same order, so chains, traces and both transition values are IDENTICAL --
+    graph replay and eager stepping, real and complex states, 1 / 3 / 17 chains (17: more chains than waves)."""
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams
+    from pxmcmc_amd.measurements import Identity, WeakLensing
+    from pxmcmc_amd.prior import L1, S2_Wavelets_L1
+    from pxmcmc_amd.transforms import IdentityTransform, SphericalWaveletTransform
+
+    rng = np.random.default_rng(5)
+    problems = []
+    n = 5000
+    T = IdentityTransform()
+    problems.append((ForwardOperator(rng.normal(size=n), 0.3, "synthesis", T, Identity(n, n), n),
+                     L1("synthesis", T.forward, T.forward_adjoint, 2e-3), n, 4e-3, 2e-3))
+    L, B, J = 16, 2, 2
+    tr = SphericalWaveletTransform(L, B, J, max_chains=C)
+    mask = np.ones((L, 2 * L - 1), dtype=int)
+    mask[6:9, :] = 0
+    wl = WeakLensing(L, mask, ngal=rng.integers(5, 40, size=mask.shape), max_chains=C)
+    data = rng.normal(size=int(mask.sum())) + 1j * rng.normal(size=int(mask.sum()))
+    op = ForwardOperator(data, 1 / wl.inv_cov, "synthesis", transform=tr, measurement=wl, nparams=tr.ncoefs)
+    problems.append((op, S2_Wavelets_L1("synthesis", tr.inverse, tr.inverse_adjoint, 1e-6, L=L, B=B, J_min=J), tr.ncoefs, 1e-6, 2e-6))
+    rejected = accepted = 0
+    for op, reg, nparams, lmda, delta in problems:
+        p = PxMCMCParams(lmda=lmda, delta=delta, nsamples=4, nburn=3, ngap=2, verbosity=0, track=["chain", "logposterior", "L2", "prior"])
+        runs = {}
+        for fuse in (True, False):
+            for graph in (True, False):
+                s = PxMALA(op, reg, p, tune_delta=True, nchains=C, seed=11, track_transitions=True, use_graph=graph, max_iter=60)
+                s.fuse_tail = fuse
+                _quiet(s.run, start_point=np.zeros(nparams))
+                assert s.used_graph == graph, s.graph_error
+                runs[fuse, graph] = (np.asarray(s.chain), np.asarray(s.acceptance_trace), np.asarray(s.deltas_trace),
+                                     np.asarray(s.logPi), np.asarray(s.L2s), np.asarray(s.priors),
+                                     np.asarray([t[0] for t in s.transitions_trace]), np.asarray([t[1] for t in s.transitions_trace]))
+        ref = runs[False, False]
+        accepted += ref[1].sum()
+        rejected += ref[1].size - ref[1].sum()
+        for key, got in runs.items():
+            for a, b in zip(got, ref):
+                np.testing.assert_array_equal(a, b, err_msg=str(key))
+    assert accepted > 0 and rejected > 0  # accepted and rejected proposals in the compared windows
