@@ -409,11 +409,11 @@ __global__ void k_pxmala_accept2(const double2* __restrict__ lt_pc, const double
 }
 
 // The same test fed by the PARTIAL sums of the iteration (pxm_pxmala_propose with deferred totals, k_pxmala_tail_partial):
-// ONE workgroup, a wave per chain; the wave adds the slices in the order of k_reduce_final / k_pxmala_propose_final (so the
+// ONE workgroup of up to four waves, a wave per chain (in turn); the wave adds the slices in the order of k_reduce_final / k_pxmala_propose_final (so the
 // totals are the ones the separate kernels give), lane 0 decides.  The totals are also stored for observers.  `bump`: the
 // device-resident iteration counter of a captured iteration, advanced here after every chain has read it (one workgroup,
 // one barrier) -- the last reader of the counter in an iteration.
-__global__ __launch_bounds__(1024) void k_pxmala_accept3(const double* __restrict__ part_prop, int slices_prop,
+__global__ __launch_bounds__(256) void k_pxmala_accept3(const double* __restrict__ part_prop, int slices_prop,
                                                          const double2* __restrict__ part_lt, int slices_lt,
                                                          const double2* __restrict__ part_l2, int slices_l2,
                                                          double2* __restrict__ lt_pc_out, double2* __restrict__ lt_cp_out,
@@ -735,7 +735,7 @@ int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, cons
   PXM_REQUIRE(dtype == 1 || !(noise_complex & 1), "pxm_pxmala_propose: complex noise needs a complex state");
   hipStream_t st = (hipStream_t)stream;
   const int RS = red_slices(n);
-  dim3 g(RS, C), b(256);
+  dim3 g(RS, C), b(512);  // (8 waves per slice: 25.5 us against 29.8 with 4 and 33.8 with 16 at n = 1.2 M complex, one chain)
   NoiseSrc ns = make_noise_src(noise, noise_complex, seed, chain0, iter, iter_dev);
   if (dtype)
     hipLaunchKernelGGL(k_pxmala_propose<true>, g, b, 0, st, (const double*)X, (const double*)proxf, (const double*)gradg, T,
@@ -811,7 +811,7 @@ int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_
     else PXM_TAIL(false, false, false);
   }
 #undef PXM_TAIL
-  const int nw = std::min(C, 16);
+  const int nw = std::min(C, 4);
   hipLaunchKernelGGL(k_pxmala_accept3, dim3(1), dim3(64 * nw), 0, st, propose_scratch, RS, (const double2*)part_lt, RS,
                      (const double2*)part_l2, RD, (double2*)logtrans_pc_out, (double2*)logtrans_cp_out, prior_p_out,
                      (double2*)L2_p_out,
