@@ -779,7 +779,7 @@ struct Dft6Args {
 };
 
 #define PXM_D6_GEOMETRY                                                                      \
-  constexpr int lgR = 1, R = 2;                     /* chains per workgroup: compile-time */ \
+  constexpr int lgR = LGR, R = 1 << LGR;            /* chains per workgroup: compile-time */ \
   const int n = a.n;                                                                         \
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;                                \
   const int w = wave & 3, r = wave >> 2;            /* bin class of the wave, chain of the workgroup */ \
@@ -794,7 +794,7 @@ struct Dft6Args {
   const double2* pp1 = lds5 + (wave ^ 1) * D5_PLANE;                                         \
   const double2* pp2 = lds5 + (wave ^ 2) * D5_PLANE;                                         \
   const double2* tw = lds5 + 4 * R * D5_PLANE;                                               \
-  for (int i = threadIdx.x; i < D5_TW; i += 512) lds5[4 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : a.wt[i - 448];
+  for (int i = threadIdx.x; i < D5_TW; i += 256 * R) lds5[4 * R * D5_PLANE + i] = i < 448 ? a.tw1[64 + i] : a.wt[i - 448];
 #define PXM_D6_SLOT(K, CH) (((K) << lgR) + (((CH) + ((K) >> rsh)) & (R - 1)))
 
 // xl[p] = element lane + 64 p, xh[p] = element lane + 64 p + 512 of the ring (zeros past n) -> fo[ii][q]: the
@@ -842,11 +842,14 @@ __device__ __forceinline__ void d6_transform(double2 (&xl)[8], const double2 (&x
   }
 }
 
-__global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double* __restrict__ G, int ncol, int C) {
+// LGR: log2 of the chains per workgroup -- 1 (two chains, 8 waves) in general, 0 (4 waves) for a single chain, whose second
+// half-workgroup would transform zeros on the same SIMDs
+template <int LGR>
+__global__ __launch_bounds__(256 << LGR, 4) void k_px2ring6(Dft6Args a, PxIn in, double* __restrict__ G, int ncol, int C) {
   extern __shared__ double2 lds5[];
   if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
   const int bx = blockIdx.x, by = blockIdx.y;
-  if ((by << 1) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
+  if ((by << LGR) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
   PXM_D6_GEOMETRY
   // every wave fetches a quarter of the ring (its two p, both halves) and the four share it through the stage
   {  // batched loads of the wave's four elements (elements past the ring end re-read element 0 of the ring)
@@ -891,7 +894,7 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
     }
   d5_barrier();
   {
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (512 >> lgR) /* workgroups of 512 threads */;
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = 256 /* workgroups of 256 R threads */;
     const int mstride = a.Rp * Cp;
     double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;
 #if PXM_D5_ABLATE & 8
@@ -911,14 +914,14 @@ __global__ __launch_bounds__(512, 4) void k_px2ring6(Dft6Args a, PxIn in, double
   }
 }
 
-template <bool N64>
-__global__ __launch_bounds__(512, 4) void k_ring2px6(Dft6Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
+template <bool N64, int LGR>
+__global__ __launch_bounds__(256 << LGR, 4) void k_ring2px6(Dft6Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
   extern __shared__ double2 lds5[];
   const int bx = blockIdx.x, by = blockIdx.y;
-  if ((by << 1) >= C) return;
+  if ((by << LGR) >= C) return;
   PXM_D6_GEOMETRY
   {  // the ring of the workgroup's chains -> stage (conjugated: inverse DFT by conjugation)
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = (512 >> lgR) /* workgroups of 512 threads */;
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> lgR, kstep = 256 /* workgroups of 256 R threads */;
     const int mstride = a.Rp * Cp;
     const double2* Gc = reinterpret_cast<const double2*>(G) + c0 + rr;
     const bool cv = c0 + rr < Cp;
@@ -1359,30 +1362,47 @@ static Dft6Args dft6_args(const DftPlan& p) {
   auto c = [](const double* x) { return reinterpret_cast<const double2*>(x); };
   return Dft6Args{p.L, p.n, p.Rp, 1, c(t.cA), c(t.cB), c(t.dA), c(t.dB), c(t.tw1), c(t.wt), c(t.bQ)};
 }
-static constexpr int D6_R = 2;  // chains per workgroup: 8 waves, 2 workgroups per CU (4 waves per SIMD)
-static size_t dft6_lds() { return (size_t)4 * D6_R * D5_PLANE * 16 + (size_t)D5_TW * 16; }  // (>= the stage: n R 16 B)
+// chains per workgroup: 2 (8 waves, 2 workgroups per CU: 4 waves per SIMD); 1 for a single chain
+static size_t dft6_lds(int R) { return (size_t)4 * R * D5_PLANE * 16 + (size_t)D5_TW * 16; }  // (>= the stage: n R 16 B)
 static int dft6_attr() {
   static bool done = false;
   if (!done) {
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring6), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px6<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px6<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring6<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px6<false, 0>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px6<true, 0>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px6<false, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px6<true, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     done = true;
   }
   return 0;
 }
+static int dft6_chains_per_wg(int C) {
+  static const int forced = getenv("PXM_D6_R") ? atoi(getenv("PXM_D6_R")) : 0;  // A/B: 1 | 2
+  return forced == 1 || forced == 2 ? forced : (C == 1 ? 1 : 2);
+}
 int dft6_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
   if (int rc = dft6_attr()) return rc;
-  dim3 grid(p.L, (ncol / 2 + D6_R - 1) / D6_R), block(256 * D6_R);
-  hipLaunchKernelGGL(k_px2ring6, grid, block, dft6_lds(), st, dft6_args(p), in, G, ncol, C);
+  const int R = dft6_chains_per_wg(C);
+  dim3 grid(p.L, (ncol / 2 + R - 1) / R), block(256 * R);
+  if (R == 1) hipLaunchKernelGGL(k_px2ring6<0>, grid, block, dft6_lds(R), st, dft6_args(p), in, G, ncol, C);
+  else hipLaunchKernelGGL(k_px2ring6<1>, grid, block, dft6_lds(R), st, dft6_args(p), in, G, ncol, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }
 int dft6_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st) {
   if (int rc = dft6_attr()) return rc;
-  dim3 grid(p.L, (C + D6_R - 1) / D6_R), block(256 * D6_R);
-  if (out.X && !out.noise && out.noise64) hipLaunchKernelGGL(k_ring2px6<true>, grid, block, dft6_lds(), st, dft6_args(p), G, ncol, out, C);
-  else hipLaunchKernelGGL(k_ring2px6<false>, grid, block, dft6_lds(), st, dft6_args(p), G, ncol, out, C);
+  const int R = dft6_chains_per_wg(C);
+  dim3 grid(p.L, (C + R - 1) / R), block(256 * R);
+  const bool n64 = out.X && !out.noise && out.noise64;
+  const Dft6Args a = dft6_args(p);
+  if (R == 1) {
+    if (n64) hipLaunchKernelGGL((k_ring2px6<true, 0>), grid, block, dft6_lds(R), st, a, G, ncol, out, C);
+    else hipLaunchKernelGGL((k_ring2px6<false, 0>), grid, block, dft6_lds(R), st, a, G, ncol, out, C);
+  } else {
+    if (n64) hipLaunchKernelGGL((k_ring2px6<true, 1>), grid, block, dft6_lds(R), st, a, G, ncol, out, C);
+    else hipLaunchKernelGGL((k_ring2px6<false, 1>), grid, block, dft6_lds(R), st, a, G, ncol, out, C);
+  }
   PXM_HIP(hipGetLastError());
   return 0;
 }
