@@ -33,7 +33,8 @@
 #include <cstdlib>
 #include <vector>
 
-// timing-only ablations for DESIGN.md (wrong results): 1 no Philox, 2 no table loads, 4 no LDS transposes
+// timing-only ablations for DESIGN.md (wrong results): 1 no Philox, 2 no table loads, 4 no LDS transposes, 8 no ring stores
+// (px2ring6), 16 no input loads (dft6 kernels), 32 no pixel stores (ring2px6)
 #ifndef PXM_D5_ABLATE
 #define PXM_D5_ABLATE 0
 #endif
@@ -808,7 +809,7 @@ __device__ __forceinline__ void d6_transform(double2 (&xl)[8], const double2 (&x
   const double2* __restrict__ dA = a.dA + w * 512 + lane;
   const double2* __restrict__ dB = a.dB + w * 512 + lane;
 #pragma unroll
-  for (int p = 0; p < 8; ++p) xl[p] = cadd(cmul(xl[p], cA[64 * p]), cmul(xh[p], cB[64 * p]));
+  for (int p = 0; p < 8; ++p) xl[p] = cadd(cmul(xl[p], D5_TAB(cA[64 * p])), cmul(xh[p], D5_TAB(cB[64 * p])));
   d5_conv<8>(xl, plane, lane, q, tw, a.bQ + w * 512);
   // ---- pair exchange 1 (w <-> w ^ 1): keep p in [4 wa, 4 wa + 4), send the shares of the other four
   double2 su[4], sv[4];
@@ -816,10 +817,10 @@ __device__ __forceinline__ void d6_transform(double2 (&xl)[8], const double2 (&x
   for (int i = 0; i < 4; ++i) {
     const double2 yk = d5_sel(wa, xl[4 + i], xl[i]), ys = d5_sel(wa, xl[i], xl[4 + i]);
     const int pk = 64 * (4 * wa + i), ps = 64 * (4 * (1 - wa) + i);
-    su[i] = cmul(yk, dA[pk]);
-    sv[i] = cmul(yk, dB[pk]);
-    plane[64 * i + lane] = cmul(ys, dA[ps]);
-    plane[256 + 64 * i + lane] = cmul(ys, dB[ps]);
+    su[i] = cmul(yk, D5_TAB(dA[pk]));
+    sv[i] = cmul(yk, D5_TAB(dB[pk]));
+    plane[64 * i + lane] = cmul(ys, D5_TAB(dA[ps]));
+    plane[256 + 64 * i + lane] = cmul(ys, D5_TAB(dB[ps]));
   }
   d5_barrier();
 #pragma unroll
@@ -842,13 +843,24 @@ __device__ __forceinline__ void d6_transform(double2 (&xl)[8], const double2 (&x
   }
 }
 
+// Workgroup -> ring.  On the narrow ring arrays (2 or 4 doubles per (m, ring) entry) eight or four neighbouring rings share a
+// 128-B line, and a workgroup reads / writes ONE ring of every order: with ring = block id the eight XCDs (block id mod 8 under
+// the round-robin placement) each fetch every line of the array -- 8 x the bytes, 8 us of the 24-us launch at L = 512 -- and
+// write it in 16-B pieces from eight L2s.  Here the eight rings of a line go to eight workgroups of ONE XCD that are dispatched
+// back to back (block ids 8 q + x, q = 8 j .. 8 j + 7): the line is fetched once and its stores merge in that L2.
+__device__ __forceinline__ int d6_ring_of_block(int b, int nb) {
+  if (b >= (nb & ~63)) return b;
+  const int x = b & 7, q = b >> 3;
+  return ((((q >> 3) << 3) + x) << 3) + (q & 7);
+}
+
 // LGR: log2 of the chains per workgroup -- 1 (two chains, 8 waves) in general, 0 (4 waves) for a single chain, whose second
 // half-workgroup would transform zeros on the same SIMDs
 template <int LGR>
 __global__ __launch_bounds__(256 << LGR, 4) void k_px2ring6(Dft6Args a, PxIn in, double* __restrict__ G, int ncol, int C) {
   extern __shared__ double2 lds5[];
   if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
-  const int bx = blockIdx.x, by = blockIdx.y;
+  const int bx = d6_ring_of_block(blockIdx.x, gridDim.x), by = blockIdx.y;
   if ((by << LGR) >= C) return;  // no live chain in this group: its slots are zero-filled by the last live group
   PXM_D6_GEOMETRY
   // every wave fetches a quarter of the ring (its two p, both halves) and the four share it through the stage
@@ -862,11 +874,15 @@ __global__ __launch_bounds__(256 << LGR, 4) void k_px2ring6(Dft6Args a, PxIn in,
       ok[u] = ch < C && j < n;
       ev[u] = in.ring0 + (int64_t)t * n + (j < n ? j : 0);
     }
+#if PXM_D5_ABLATE & 16
+    for (int u = 0; u < 4; ++u) v[u] = double2{1e-3 * lane, 1e-3 * u};
+#else
     if (ch < C) px_in_load_n<4>(in, ch, ev, ok, v);
     else {
 #pragma unroll
       for (int u = 0; u < 4; ++u) v[u] = double2{0.0, 0.0};
     }
+#endif
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = lane + 64 * (2 * w + (u >> 1)) + 512 * (u & 1);
@@ -917,7 +933,7 @@ __global__ __launch_bounds__(256 << LGR, 4) void k_px2ring6(Dft6Args a, PxIn in,
 template <bool N64, int LGR>
 __global__ __launch_bounds__(256 << LGR, 4) void k_ring2px6(Dft6Args a, const double* __restrict__ G, int ncol, PxOut out, int C) {
   extern __shared__ double2 lds5[];
-  const int bx = blockIdx.x, by = blockIdx.y;
+  const int bx = d6_ring_of_block(blockIdx.x, gridDim.x), by = blockIdx.y;
   if ((by << LGR) >= C) return;
   PXM_D6_GEOMETRY
   {  // the ring of the workgroup's chains -> stage (conjugated: inverse DFT by conjugation)
@@ -932,7 +948,11 @@ __global__ __launch_bounds__(256 << LGR, 4) void k_ring2px6(Dft6Args a, const do
       for (int u = 0; u < NB; ++u) {
         const int k = kb + u * kstep;
         v[u] = double2{0.0, 0.0};
+#if PXM_D5_ABLATE & 16
+        v[u] = double2{1e-3 * k, 1e-3 * u};
+#else
         if (cv && k < n) v[u] = Gc[((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + t * Cp];
+#endif
       }
 #pragma unroll
       for (int u = 0; u < NB; ++u) {
@@ -995,7 +1015,11 @@ __global__ __launch_bounds__(256 << LGR, 4) void k_ring2px6(Dft6Args a, const do
     int64_t ev[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) ev[u] = e0 + eo[u];
+#if PXM_D5_ABLATE & 32
+    if (yv[0].x + yv[1].x + yv[2].x + yv[3].x == 1.2345e300) px_out_store_n<4>(out, ch, ev, yv, ok);
+#else
     px_out_store_n<4>(out, ch, ev, yv, ok);
+#endif
   }
 }
 
