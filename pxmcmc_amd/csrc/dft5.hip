@@ -87,6 +87,7 @@ struct Dft5Group {
   int64_t ring0;  // offset of its coefficient block inside a chain (complex elements)
   int r0;
   int b0, nbx, nby;  // first block of the scale in the grid, its blocks along rings / chain groups
+  int xs;            // ring sets (workgroups along the rings) per 128-B line of the ring array: > 1 on narrow arrays
   int64_t tbase;     // the scale's table allocation as an offset (doubles) from the workspace base ...
   int toff[7];       // ... and cE, cO, dO, tw1, wt, bE, bO inside it (doubles)
 };
@@ -686,7 +687,13 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px5(Dft5Args a, doubl
   const Dft5Group g = ents[e];                                           \
   const int local = blockIdx.x - g.b0;                                   \
   const int rest = local >> 3;                                           \
-  const int by = rest % g.nby, bx = (rest / g.nby) * 8 + (local & 7);    \
+  const int by = rest % g.nby;                                           \
+  int bx = (rest / g.nby) * 8 + (local & 7);                             \
+  /* narrow ring arrays: the xs ring sets that share a 128-B line go to workgroups of ONE XCD (d6_ring_of_block) */ \
+  if (g.xs > 1 && bx < (g.nbx & ~(8 * g.xs - 1))) {                      \
+    const int q = rest / g.nby;                                          \
+    bx = g.xs * (8 * (q / g.xs) + (local & 7)) + q % g.xs;               \
+  }                                                                      \
   if (bx >= g.nbx) return;                                               \
   double* G = ws + g.g_off;                                              \
   Dft5Args a = g.a;                                                      \
@@ -1205,6 +1212,10 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
     const int rings = p.TR5 * (8 / g.r0);
     g.nbx = (p.L + rings - 1) / rings;
     g.nby = (ncol / 2 + p.R5 - 1) / p.R5;
+    {
+      const int per_line = 16 / ncol;  // rings per 128-B line: 8 for one complex slot per entry, 4 for two, < 2 otherwise
+      g.xs = (g.nby == 1 && per_line > rings && per_line % rings == 0) ? per_line / rings : 1;
+    }
     g.b0 = b0;
     b0 += round_up(g.nbx, 8) * g.nby;  // (padded so that every scale starts on an XCD-label boundary)
     lds = std::max(lds, p.lds5);

@@ -494,6 +494,12 @@ struct pxm_wav_plan_s {
   double* d_hn = nullptr;
   int64_t offHAn = 0, offHBn = 0, offHLn = 0;  // relative to ws (doubles)
   int ncol_h = 0;
+  // ... and of the scales INSIDE the DFT group on that path: ring arrays of 2 Cmax doubles per (m, ring) entry in one
+  // allocation, their own group descriptors (offGn[s] relative to ws; non-members keep offG[s])
+  double* d_gn = nullptr;
+  std::vector<int64_t> offGn;
+  int ncol_gn = 0;
+  DftGroupList dft_group_n;
   TaskList wl_syn_fwd, wl_adj_fwdadj;  // packed per-scale lists of the weak-lensing path reading / writing the twin array
   std::vector<int> el_lo_s, sup_lo_s;  // per scale: rows / contraction steps skipped, first degree of the support
   ShtTables* T2 = nullptr;
@@ -574,7 +580,7 @@ static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const SideOv
 // packed per-scale lists (sht_gemm.hip: k_sht_gemm_pk) of stage `which` for every scale; scales of equal bandlimit stream their
 // table in one pass.  twin_s >= 0: scales twin_s / twin_s + 1 read / write chain slots 0 / 1 of the array at g_twin.
 static void wav_packed_lists(const pxm_wav_plan_s* p, int which, int kind, int twin_s, int64_t g_twin, std::vector<GemmTask>& out,
-                             std::vector<char>* shared, int twin_ncol = 0, bool narrow_h = false) {
+                             std::vector<char>* shared, int twin_ncol = 0, bool narrow_h = false, bool narrow_g = false) {
   if (shared) shared->assign(p->nsc, 0);
   for (int s = 0; s < p->nsc; ++s) {
     const bool pair = s + 1 < p->nsc && p->bl[s + 1] == p->bl[s] && p->T[s + 1] == p->T[s];
@@ -585,6 +591,9 @@ static void wav_packed_lists(const pxm_wav_plan_s* p, int which, int kind, int t
       oa.g = &ga;
       ob.g = &gb;
       oa.g_ncol = ob.g_ncol = twin_ncol;
+    } else if (narrow_g) {  // narrow ring arrays of the DFT group's member scales
+      if (p->dft_group_n.member[s]) oa.g = &p->offGn[s], oa.g_ncol = p->ncol_gn;
+      if (pair && p->dft_group_n.member[s + 1]) ob.g = &p->offGn[s + 1], ob.g_ncol = p->ncol_gn;
     }
     const GemmSide a = wav_side(p, s, which, oa);
     if (pair) {
@@ -813,6 +822,8 @@ int pxm_wav_plan_destroy(pxm_wav_plan_t p) {
   deferred_free(p->d_twin);
   deferred_free(p->d_g2n);
   deferred_free(p->d_hn);
+  deferred_free(p->d_gn);
+  dft_group_destroy(&p->dft_group_n);
   free_tasks(&p->wl_syn_fwd);
   free_tasks(&p->wl_adj_fwdadj);
   delete p;
@@ -1021,7 +1032,8 @@ static int wav_blocks_to_rings(pxm_wav_plan_t p, const void* X, int C, hipStream
     in.f = (const double*)X;
     in.chain_stride = p->ncoefs;
     if (!bumped) in.bump = bump;
-    if ((rc = dft5_group_px2ring(p->dft_group, p->ws, p->ncol, in, C, wav_group_stream(p, st, used)))) return rc;
+    const bool ng = twin && p->dft_group_n.d;  // one-chain weak-lensing path: the member scales' narrow arrays
+    if ((rc = dft5_group_px2ring(ng ? p->dft_group_n : p->dft_group, p->ws, ng ? p->ncol_gn : p->ncol, in, C, wav_group_stream(p, st, used)))) return rc;
   }
   return wav_join(p, st, used);
 }
@@ -1047,7 +1059,8 @@ static int wav_rings_to_blocks(pxm_wav_plan_t p, PxOut proto, int C, hipStream_t
     if (rc) return rc;
   }
   if (grp) {
-    if ((rc = dft5_group_ring2px(p->dft_group, p->ws, p->ncol, proto, C, wav_group_stream(p, st, used)))) return rc;
+    const bool ng = twin && p->dft_group_n.d;
+    if ((rc = dft5_group_ring2px(ng ? p->dft_group_n : p->dft_group, p->ws, ng ? p->ncol_gn : p->ncol, proto, C, wav_group_stream(p, st, used)))) return rc;
   }
   return wav_join(p, st, used);
 }
@@ -1499,10 +1512,33 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
     if ((rc = dev_alloc(&p->d_twin, (size_t)n * sizeof(double), "twin ring array of the two top scales"))) return rc;
     if ((rc = dev_zero(p->d_twin, (size_t)n * sizeof(double)))) return rc;
     p->offGT = p->d_twin - p->ws;
+    bool narrow_g = false;
+    if (narrow && p->ncol_h && p->dft_group.d && p->dft_group.five && p->plain_group && !getenv("PXM_NO_NARROW_GROUP")) {
+      // the member scales of the DFT group on rows of 2 Cmax doubles as well: own arrays, own group descriptors
+      p->ncol_gn = 2 * p->Cmax;
+      p->offGn = p->offG;
+      int64_t tot = 0;
+      std::vector<int64_t> rel((size_t)p->nsc, 0);
+      for (int k = 0; k < p->nsc; ++k)
+        if (p->dft_group.member[k]) {
+          rel[k] = tot;
+          tot += ((int64_t)(2 * p->bl[k] - 1) * round_up(p->bl[k], 16) * p->ncol_gn + p->ncol + 15) / 16 * 16;  // (+ slack: 16-column address model)
+        }
+      if ((rc = dev_alloc(&p->d_gn, (size_t)tot * sizeof(double), "narrow ring arrays of the DFT group's scales"))) return rc;
+      if ((rc = dev_zero(p->d_gn, (size_t)tot * sizeof(double)))) return rc;
+      for (int k = 0; k < p->nsc; ++k)
+        if (p->dft_group.member[k]) p->offGn[k] = (p->d_gn - p->ws) + rel[k];
+      std::vector<const DftPlan*> dp;
+      for (int k = 0; k < p->nsc; ++k) dp.push_back(&p->dft[k]);
+      rc = dft5_group_create(dp, p->offGn, p->coef_off, p->ncol_gn, p->ws, &p->dft_group_n);
+      if (rc < 0) return rc;
+      narrow_g = rc == 0 && p->dft_group_n.member == p->dft_group.member;
+      if (!narrow_g) dft_group_destroy(&p->dft_group_n);
+    }
     std::vector<GemmTask> vf, va;
     std::vector<char> shared;
-    wav_packed_lists(p, 0, TAB_FWD, s, p->offGT, vf, &shared, p->ncol_t, p->ncol_h != 0);
-    wav_packed_lists(p, 1, TAB_FWD_ADJ, s, p->offGT, va, nullptr, p->ncol_t, p->ncol_h != 0);
+    wav_packed_lists(p, 0, TAB_FWD, s, p->offGT, vf, &shared, p->ncol_t, p->ncol_h != 0, narrow_g);
+    wav_packed_lists(p, 1, TAB_FWD_ADJ, s, p->offGT, va, nullptr, p->ncol_t, p->ncol_h != 0, narrow_g);
     if ((rc = upload_tasks(vf, true, &p->wl_syn_fwd, p->bl, p->ncol, p->ws, "weak-lensing synthesis forward (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
     if ((rc = upload_tasks(va, true, &p->wl_adj_fwdadj, p->bl, p->ncol, p->ws, "weak-lensing forward-adjoint (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
     p->twin_s = s;
