@@ -30,6 +30,18 @@ def test_fused_paths_equal_unfused_kernels_random_sizes():
     assert ntot == 25 and nfail == 0
 
 
+def test_one_chain_weaklensing_plan_equals_two_chain_plan_random_sizes_above_256():
+    """4 random (L in 257..339, B in {1.5, 2, 3}, J_min, random mask and galaxy counts): the one-chain weak-lensing plan --
+    recursion stage, packed lists, twin array where two top scales share a band-limit, narrow ring arrays incl. the DFT
+    group's scales with their XCD-aware ring order -- against the two-chain plan (eight-slot lines) of the same problem."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts", "parity"))
+    import fuzz_wl_narrow
+
+    ntot, nfail = fuzz_wl_narrow.main(ncase=4, seed=2)
+    assert ntot == 4 and nfail == 0
+
+
 @pytest.mark.parametrize("script", ["check_pxmala_chains.py", "check_complex_params.py", "check_many_chains.py"])
 def test_check_scripts(script):
     """check_pxmala_chains: a PxMALA batch (per-chain delta, accept flag, Philox uniforms) equals its chains run alone,
