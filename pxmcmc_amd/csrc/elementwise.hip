@@ -409,37 +409,54 @@ __global__ void k_pxmala_accept2(const double2* __restrict__ lt_pc, const double
 }
 
 // The same test fed by the PARTIAL sums of the iteration (pxm_pxmala_propose with deferred totals, k_pxmala_tail_partial):
-// ONE workgroup of up to four waves, a wave per chain (in turn); the wave adds the slices in the order of k_reduce_final / k_pxmala_propose_final (so the
-// totals are the ones the separate kernels give), lane 0 decides.  The totals are also stored for observers.  `bump`: the
-// device-resident iteration counter of a captured iteration, advanced here after every chain has read it (one workgroup,
-// one barrier) -- the last reader of the counter in an iteration.
-__global__ __launch_bounds__(256) void k_pxmala_accept3(const double* __restrict__ part_prop, int slices_prop,
+// ONE workgroup of 16 waves, three waves per chain (five chains in flight): one wave each for the slices of the forward
+// transition sum + prior, of the reverse transition sum and of the L2, added in the order of k_reduce_final /
+// k_pxmala_propose_final (so the totals are the ones the separate kernels give); the totals meet in LDS and lane 0 of the
+// chain's first wave decides.  The totals are also stored for observers.  `bump`: the device-resident iteration counter of a
+// captured iteration, advanced here after every chain has read it (one workgroup) -- the last reader of the counter in an
+// iteration.
+__global__ __launch_bounds__(1024) void k_pxmala_accept3(const double* __restrict__ part_prop, int slices_prop,
                                                          const double2* __restrict__ part_lt, int slices_lt,
                                                          const double2* __restrict__ part_l2, int slices_l2,
                                                          double2* __restrict__ lt_pc_out, double2* __restrict__ lt_cp_out,
                                                          double* __restrict__ prior_p_out, double2* __restrict__ L2_p_out,
                                                          AcceptArgs a, uint64_t* __restrict__ bump) {
-  const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
-  for (int c = threadIdx.x >> 6; c < a.C; c += nw) {
-    double2 s_cp{0.0, 0.0}, s_pc{0.0, 0.0}, l2{0.0, 0.0};
-    double pr = 0.0;
-    for (int sl = lane; sl < slices_prop; sl += 64) {
-      const double* o = part_prop + ((int64_t)c * slices_prop + sl) * 4;
-      s_cp = cadd(s_cp, double2{o[0], o[1]});
-      pr += o[2];
+  constexpr int CB = 5;              // chains per round
+  __shared__ double tot[CB][8];      // (S_cp.re, S_cp.im, prior, -, S_pc.re, S_pc.im, L2.re, L2.im)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = wave / 3, role = wave % 3;
+  for (int c0 = 0; c0 < a.C; c0 += CB) {
+    const int c = c0 + slot;
+    if (slot < CB && c < a.C) {
+      double2 v{0.0, 0.0};
+      double pr = 0.0;
+      if (role == 0) {
+        for (int sl = lane; sl < slices_prop; sl += 64) {
+          const double* o = part_prop + ((int64_t)c * slices_prop + sl) * 4;
+          v = cadd(v, double2{o[0], o[1]});
+          pr += o[2];
+        }
+      } else if (role == 1) {
+        for (int sl = lane; sl < slices_lt; sl += 64) v = cadd(v, part_lt[(int64_t)c * slices_lt + sl]);
+      } else {
+        for (int sl = lane; sl < slices_l2; sl += 64) v = cadd(v, part_l2[(int64_t)c * slices_l2 + sl]);
+      }
+      for (int off = 32; off > 0; off >>= 1) {
+        v.x += __shfl_down(v.x, off);
+        v.y += __shfl_down(v.y, off);
+        pr += __shfl_down(pr, off);
+      }
+      if (lane == 0) {
+        double* o = tot[slot] + (role == 0 ? 0 : (role == 1 ? 4 : 6));
+        o[0] = v.x;
+        o[1] = v.y;
+        if (role == 0) o[2] = pr;
+      }
     }
-    for (int sl = lane; sl < slices_lt; sl += 64) s_pc = cadd(s_pc, part_lt[(int64_t)c * slices_lt + sl]);
-    for (int sl = lane; sl < slices_l2; sl += 64) l2 = cadd(l2, part_l2[(int64_t)c * slices_l2 + sl]);
-    for (int off = 32; off > 0; off >>= 1) {
-      s_cp.x += __shfl_down(s_cp.x, off);
-      s_cp.y += __shfl_down(s_cp.y, off);
-      pr += __shfl_down(pr, off);
-      s_pc.x += __shfl_down(s_pc.x, off);
-      s_pc.y += __shfl_down(s_pc.y, off);
-      l2.x += __shfl_down(l2.x, off);
-      l2.y += __shfl_down(l2.y, off);
-    }
-    if (lane == 0) {
+    __syncthreads();
+    if (slot < CB && c < a.C && role == 0 && lane == 0) {
+      const double2 s_cp{tot[slot][0], tot[slot][1]}, s_pc{tot[slot][4], tot[slot][5]}, l2{tot[slot][6], tot[slot][7]};
+      const double pr = tot[slot][2];
       const double d = a.delta_dev[c];  // (before its adaptation below: the delta both transitions were proposed with)
       const double2 q_cp = cmul(s_cp, s_cp), q_pc = cmul(s_pc, s_pc);
       const double2 lt_cp{-(1.0 / 2 * d) * q_cp.x, -(1.0 / 2 * d) * q_cp.y}, lt_pc{-(1.0 / 2 * d) * q_pc.x, -(1.0 / 2 * d) * q_pc.y};
@@ -449,11 +466,9 @@ __global__ __launch_bounds__(256) void k_pxmala_accept3(const double* __restrict
       L2_p_out[c] = l2;
       accept_chain(a, c, lt_pc, lt_cp, pr, l2);
     }
-  }
-  if (bump) {
     __syncthreads();
-    if (threadIdx.x == 0) *bump += 1;
   }
+  if (bump && threadIdx.x == 0) *bump += 1;  // (behind the last barrier: every chain has read the counter)
 }
 
 struct CopySet {
@@ -811,8 +826,7 @@ int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_
     else PXM_TAIL(false, false, false);
   }
 #undef PXM_TAIL
-  const int nw = std::min(C, 4);
-  hipLaunchKernelGGL(k_pxmala_accept3, dim3(1), dim3(64 * nw), 0, st, propose_scratch, RS, (const double2*)part_lt, RS,
+  hipLaunchKernelGGL(k_pxmala_accept3, dim3(1), dim3(64 * std::min(16, 3 * C)), 0, st, propose_scratch, RS, (const double2*)part_lt, RS,
                      (const double2*)part_l2, RD, (double2*)logtrans_pc_out, (double2*)logtrans_cp_out, prior_p_out,
                      (double2*)L2_p_out,
                      make_accept_args(mu, lmda, logpi_c, L2_c, prior_c, u, seed, chain0, iter, iter_dev, accept_out, delta_dev, tune,
