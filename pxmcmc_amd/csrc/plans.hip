@@ -372,12 +372,14 @@ int64_t pxm_sht_table_bytes(pxm_sht_plan_t p, int op) {
 // =============================================================================================
 namespace pxm {
 
+constexpr int WAV_MAX_SCALES = 40;  // scaling function + wavelet scales of one plan (B = 1.2 at L = 512: 36)
+
 // H_L[m][el][col] = sum_i kc[i][el] * H_i[m][el][col]  over the scales whose band holds (el, m)
 struct CombineArgs {
   int nsc;
   int L, Rp, ncol;
-  int bl[16], Rp_i[16];
-  int64_t offH[16];
+  int bl[WAV_MAX_SCALES], Rp_i[WAV_MAX_SCALES];
+  int64_t offH[WAV_MAX_SCALES];
   const double* kc;  // [nsc][Rp] synthesis coefficients c_s * kappa
 };
 
@@ -629,7 +631,7 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   p->Rp = round_up(L, 16);
   p->bl = wav_bandlimits(L, B, J_min);
   p->nsc = (int)p->bl.size();
-  PXM_REQUIRE(p->nsc <= 16, "pxm_wav_plan_create: more than 15 wavelet scales are not supported");
+  PXM_REQUIRE(p->nsc <= WAV_MAX_SCALES, "pxm_wav_plan_create: more than 39 wavelet scales are not supported");
   int64_t off = 0;
   for (int b : p->bl) {
     p->coef_off.push_back(off);

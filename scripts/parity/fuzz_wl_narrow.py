@@ -26,6 +26,8 @@ def main(ncase=6, seed=0):
             bl = _multires_bandlimits(L, B, J)
         except ValueError:
             continue
+        if len(bl) > 40:  # (pxm_wav_plan_create: at most 39 wavelet scales)
+            continue
         ntot += 1
         mask = (rng.random((L, 2 * L - 1)) > 0.2).astype(int)
         mask[L // 2 - 3:L // 2 + 3, :] = 0

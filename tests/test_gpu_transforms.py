@@ -52,7 +52,8 @@ def test_sht_single_chain_1d_and_roundtrip():
     assert _rel(back, flm) < TOL
 
 
-@pytest.mark.parametrize("L,B,J_min,C", [(10, 2, 2, 1), (10, 2, 2, 5), (32, 1.5, 2, 2), (64, 2, 2, 16), (144, 2, 3, 3)])
+@pytest.mark.parametrize("L,B,J_min,C", [(10, 2, 2, 1), (10, 2, 2, 5), (32, 1.5, 2, 2), (64, 2, 2, 16), (144, 2, 3, 3),
+                                         (48, 1.25, 3, 2)])  # (the last: 17 scales, neighbours of equal band-limit)
 def test_wavelet_ops_match_oracle(L, B, J_min, C):
     from oracle import s2let
     from pxmcmc_amd import ops
