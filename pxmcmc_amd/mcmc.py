@@ -678,37 +678,36 @@ class PxMALA(MYULA):
 
     def _l2_dev(self, preds):
         """L2 = vdot(d, invcov @ d) of a [C, ndata] prediction batch -> complex128 [C] (pxmcmc/mcmc.py:78-79)"""
-        p = ops.as_device(preds)
+        inputs = self._l2_inputs(preds)
+        if inputs is not None:
+            return ops.reduce_l2(*inputs)
+        p = ops.as_device(preds)  # full inverse covariance: d = data - preds, then vdot(d, invcov @ d)
         dt = self.forward._resid_dtype(p) if hasattr(self.forward, "_resid_dtype") else p.dtype
-        cache = getattr(self, "_l2_data", None)
-        if cache is None or cache[0] is not self.forward.data or cache[1].dtype != dt:  # (no host copy per iteration)
-            src = getattr(self.forward, "data_dev", None)
-            src = ops.as_device(self.forward.data) if src is None else src
-            self._l2_data = cache = (self.forward.data, src.reshape(-1).to(dt).contiguous())
-        data = cache[1]
-        if hasattr(self.forward.invcov, "matvec"):
-            d = ops.residual_grad(p.to(dt), data, self.forward.invcov.ones)
-            return ops.reduce_vdot(d, self.forward.invcov.matvec(d))
-        invcov = self.forward.invcov.diag if hasattr(self.forward.invcov, "diag") else ops.as_device(self.forward.invcov.diagonal())
-        return ops.reduce_l2(p.to(dt), data, invcov)
+        data = self._l2_data_dev(dt)
+        d = ops.residual_grad(p.to(dt), data, self.forward.invcov.ones)
+        return ops.reduce_vdot(d, self.forward.invcov.matvec(d))
 
-    def _l2_inputs(self, preds):
-        """(preds, data, diagonal of invcov) as _l2_dev hands them to the reduction; None with a full inverse covariance"""
-        if hasattr(self.forward.invcov, "matvec"):
-            return None
-        p = ops.as_device(preds)
-        dt = self.forward._resid_dtype(p) if hasattr(self.forward, "_resid_dtype") else p.dtype
+    def _l2_data_dev(self, dt):
+        """the data vector on the device in the residual's dtype (cached: no host copy per iteration)"""
         cache = getattr(self, "_l2_data", None)
         if cache is None or cache[0] is not self.forward.data or cache[1].dtype != dt:
             src = getattr(self.forward, "data_dev", None)
             src = ops.as_device(self.forward.data) if src is None else src
             self._l2_data = cache = (self.forward.data, src.reshape(-1).to(dt).contiguous())
+        return cache[1]
+
+    def _l2_inputs(self, preds):
+        """(preds, data, diagonal of invcov) as the L2 reduction takes them; None with a full inverse covariance"""
+        if hasattr(self.forward.invcov, "matvec"):
+            return None
+        p = ops.as_device(preds)
+        dt = self.forward._resid_dtype(p) if hasattr(self.forward, "_resid_dtype") else p.dtype
         ic = getattr(self, "_l2_invcov", None)
         if ic is None or ic[0] is not self.forward.invcov:
             inv = self.forward.invcov
             diag = inv.diag if hasattr(inv, "diag") else ops.as_device(inv.diagonal())
             self._l2_invcov = ic = (inv, ops.as_device(diag).reshape(-1).contiguous())
-        return p.to(dt), cache[1], ic[1]
+        return p.to(dt), self._l2_data_dev(dt), ic[1]
 
     def run(self, start_point=None):
         """Run the algorithm (pxmcmc/mcmc.py:218-275); every chain carries its own delta and accept flag.
