@@ -323,6 +323,9 @@ int pxm_pxmala_accept(const double* logalpha_terms, const double* u, uint64_t se
  *                        iter_dev: optional caller-owned device counter added to iter (HIP-graph replay).
  *                        scratch: 4 * pxm_reduce_scratch_doubles(C) doubles.  logtrans_out == prior_out == NULL: the
  *                        totals are DEFERRED -- the per-slice sums stay in `scratch` for pxm_pxmala_finish.
+ *                        proxf == proxf_prop == NULL: the prox arrays are neither read nor written -- proxf = soft(X, T)
+ *                        (the stock L1 prox, pxmcmc/prior.py:49-50) is formed in the kernel, and pxm_pxmala_finish forms
+ *                        soft(X', T) the same way: 40 % fewer bytes in the pass and one array less in the conditional copy.
  *   pxm_pxmala_accept2 : logalpha = Re(logtrans_pc + logpi' - logtrans_cp - logpi), logpi' = -mu prior' - L2';
  *                        accept iff log(u) < logalpha (u injected [C] or the Philox uniform of (seed, chain, iteration));
  *                        accepted chains take (logpi', L2', prior') into their state scalars (logpi_c, L2_c as (re, im),
@@ -330,7 +333,8 @@ int pxm_pxmala_accept(const double* logalpha_terms, const double* u, uint64_t se
  *                        acc_trace / delta_trace: optional [chunk][C] ring buffers written at row iteration % chunk.
  *   pxm_pxmala_finish  : everything between the proposal's gradient and the conditional copy in TWO launches instead of
  *                        seven: (i) ONE grid with the slices of the reverse transition sum of
- *                        calc_logtransition(X', X, proxf', gradg') [n, dtype] and of L2' = vdot(d, invcov d),
+ *                        calc_logtransition(X', X, proxf', gradg') [n, dtype; proxf_prop == NULL: proxf' = soft(X', T)
+ *                        with T [n] or T_scalar] and of L2' = vdot(d, invcov d),
  *                        d = data - preds' [n_data, data_dtype; invcov as for pxm_reduce_l2]; (ii) ONE workgroup that
  *                        totals those and the deferred sums of pxm_pxmala_propose (`propose_scratch`: that call's scratch) in
  *                        the order of the separate reductions, stores logtrans_pc / logtrans_cp / L2' as (re, im) [C] and
@@ -349,8 +353,8 @@ int pxm_pxmala_accept2(const double* logtrans_pc, const double* logtrans_cp, con
                        uint64_t chain0, uint64_t iter, const uint64_t* iter_dev, int32_t* accept_out, double* delta_dev,
                        int tune, double lmda, int32_t* acc_trace, double* delta_trace, int chunk, int C,
                        pxm_stream_t stream);
-int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_prop, const void* gradg_prop, int64_t n,
-                      int dtype, const void* preds_prop, const void* data, const void* invcov, int invcov_complex,
+int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_prop, const double* T, double T_scalar,
+                      const void* gradg_prop, int64_t n, int dtype, const void* preds_prop, const void* data, const void* invcov, int invcov_complex,
                       int64_t n_data, int data_dtype, const double* propose_scratch, double mu, double lmda, double* logpi_c,
                       double* L2_c, double* prior_c, const double* u, uint64_t seed, uint64_t chain0, uint64_t iter,
                       const uint64_t* iter_dev, int32_t* accept_out, double* delta_dev, int tune, int32_t* acc_trace,

@@ -123,8 +123,9 @@ SIGNATURES = {
     ),
     "pxm_pxmala_finish": (
         c_int,
-        [c_vp, c_vp, c_vp, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp,
-         c_u64, c_u64, c_u64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_vp],
+        [c_vp, c_vp, c_vp, c_vp, c_dbl, c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_int, c_i64, c_int, c_vp, c_dbl, c_dbl, c_vp, c_vp,
+         c_vp, c_vp, c_u64, c_u64, c_u64, c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int,
+         c_vp],
     ),
     "pxm_select_copy_many": (c_int, [c_vp, c_int, c_vp, c_vp, c_vp, c_vp, c_int, c_vp]),
     "pxm_counter_add": (c_int, [c_vp, c_u64, c_vp]),

@@ -213,24 +213,28 @@ __global__ void k_vdot_partial(const double* __restrict__ A, const double* __res
 }
 
 // S = sum (X2 - X1 - (d/2) g)^2 with g = -((X1 - proxf)/l) - gradg; complex squares, no abs (literal)
+// (P == nullptr: proxf = soft(X1, T) is formed here instead of being read -- the stock L1 prox, prior.py:49-50)
 template <bool CPLX>
 __device__ __forceinline__ void logtrans_partial_body(const double* __restrict__ X1, const double* __restrict__ X2,
                                                       const double* __restrict__ P, const double* __restrict__ G, double d,
                                                       double lmda, double* __restrict__ part, int64_t n, int c, int bx,
-                                                      int nb) {
+                                                      int nb, const double* __restrict__ T = nullptr, double Ts = 0.0) {
   const int64_t base = (int64_t)c * n;
   double2 acc{0.0, 0.0};
   for (int64_t i = bx * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)nb * blockDim.x) {
     if (CPLX) {
       const double2 x1 = reinterpret_cast<const double2*>(X1)[base + i], x2 = reinterpret_cast<const double2*>(X2)[base + i];
-      const double2 p = reinterpret_cast<const double2*>(P)[base + i], g = reinterpret_cast<const double2*>(G)[base + i];
+      const double2 g = reinterpret_cast<const double2*>(G)[base + i];
+      const double2 p = P ? reinterpret_cast<const double2*>(P)[base + i] : soft_cplx(x1, T ? T[i] : Ts);
       const double2 gl{-((x1.x - p.x) / lmda) - g.x, -((x1.y - p.y) / lmda) - g.y};
       const double2 r{x2.x - x1.x - (d / 2) * gl.x, x2.y - x1.y - (d / 2) * gl.y};
       acc.x += r.x * r.x - r.y * r.y;
       acc.y += 2 * r.x * r.y;
     } else {
-      const double gl = -((X1[base + i] - P[base + i]) / lmda) - G[base + i];
-      const double r = X2[base + i] - X1[base + i] - (d / 2) * gl;
+      const double x1 = X1[base + i];
+      const double p = P ? P[base + i] : soft_real(x1, T ? T[i] : Ts);
+      const double gl = -((x1 - p) / lmda) - G[base + i];
+      const double r = X2[base + i] - x1 - (d / 2) * gl;
       acc.x += r * r;
     }
   }
@@ -256,9 +260,10 @@ __global__ void k_pxmala_tail_partial(const double* __restrict__ X1, const doubl
                                       const double* __restrict__ delta_dev, double lmda, double* __restrict__ part_lt,
                                       int64_t n, int nb_lt, const double* __restrict__ preds,
                                       const double* __restrict__ data, const double* __restrict__ invcov,
-                                      double* __restrict__ part_l2, int64_t nd, int nb_l2) {
+                                      double* __restrict__ part_l2, int64_t nd, int nb_l2, const double* __restrict__ T,
+                                      double Ts) {
   const int c = blockIdx.y;
-  if ((int)blockIdx.x < nb_lt) logtrans_partial_body<CPLX>(X1, X2, P, G, delta_dev[c], lmda, part_lt, n, c, blockIdx.x, nb_lt);
+  if ((int)blockIdx.x < nb_lt) logtrans_partial_body<CPLX>(X1, X2, P, G, delta_dev[c], lmda, part_lt, n, c, blockIdx.x, nb_lt, T, Ts);
   else l2_partial_body<DCPLX, ICPLX>(preds, data, invcov, part_l2, nd, c, blockIdx.x - nb_lt, nb_l2);
 }
 
@@ -303,21 +308,22 @@ __global__ void k_pxmala_propose(const double* __restrict__ X, const double* __r
     const double t = T ? T[i] : Ts;
     const double wa = wp ? fabs(wp[i]) : 1.0;
     if (CPLX) {
-      const double2 x = reinterpret_cast<const double2*>(X)[base + i], p = reinterpret_cast<const double2*>(P)[base + i];
+      const double2 x = reinterpret_cast<const double2*>(X)[base + i];
+      const double2 p = P ? reinterpret_cast<const double2*>(P)[base + i] : soft_cplx(x, t);
       const double2 g = reinterpret_cast<const double2*>(G)[base + i];
       const double2 xn = chain_step_cplx(x, p, g, w, d, lmda);
       reinterpret_cast<double2*>(Xp)[base + i] = xn;
-      reinterpret_cast<double2*>(Pp)[base + i] = soft_cplx(xn, t);
+      if (Pp) reinterpret_cast<double2*>(Pp)[base + i] = soft_cplx(xn, t);
       const double2 gl{-((x.x - p.x) / lmda) - g.x, -((x.y - p.y) / lmda) - g.y};
       const double2 r{xn.x - x.x - (d / 2) * gl.x, xn.y - x.y - (d / 2) * gl.y};
       acc.x += r.x * r.x - r.y * r.y;
       acc.y += 2 * r.x * r.y;
       accA += wa * sqrt(fma(xn.x, xn.x, xn.y * xn.y));
     } else {
-      const double x = X[base + i], p = P[base + i], g = G[base + i];
+      const double x = X[base + i], p = P ? P[base + i] : soft_real(x, t), g = G[base + i];
       const double xn = chain_step_real(x, p, g, w.x, d, lmda);
       Xp[base + i] = xn;
-      Pp[base + i] = soft_real(xn, t);
+      if (Pp) Pp[base + i] = soft_real(xn, t);
       const double gl = -((x - p) / lmda) - g;
       const double r = xn - x - (d / 2) * gl;
       acc.x += r * r;
@@ -743,7 +749,9 @@ int pxm_pxmala_propose(const void* X, const void* proxf, const void* gradg, cons
                        void* X_prop, void* proxf_prop, double* logtrans_out, double* prior_out, double* scratch,
                        int64_t n, int C, int dtype, pxm_stream_t stream) {
   PXM_REQUIRE(n >= 1 && C >= 1 && (dtype == 0 || dtype == 1), "pxm_pxmala_propose: bad n / C / dtype");
-  PXM_REQUIRE(X && proxf && gradg && delta_dev && X_prop && proxf_prop && scratch, "pxm_pxmala_propose: null buffer");
+  PXM_REQUIRE(X && gradg && delta_dev && X_prop && scratch, "pxm_pxmala_propose: null buffer");
+  PXM_REQUIRE((proxf == nullptr) == (proxf_prop == nullptr),
+              "pxm_pxmala_propose: proxf and proxf_prop are given together, or both null (prox = soft(., T) formed in the kernels)");
   PXM_REQUIRE((logtrans_out == nullptr) == (prior_out == nullptr),
               "pxm_pxmala_propose: logtrans_out and prior_out are given together, or both null (totals deferred to pxm_pxmala_finish)");
   PXM_REQUIRE((noise_complex & ~(1 | PXM_NOISE_F64)) == 0, "pxm_pxmala_propose: noise_complex must be 0 or 1 (| PXM_NOISE_F64)");
@@ -792,8 +800,8 @@ int pxm_pxmala_accept2(const double* logtrans_pc, const double* logtrans_cp, con
   return 0;
 }
 
-int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_prop, const void* gradg_prop, int64_t n,
-                      int dtype, const void* preds_prop, const void* data, const void* invcov, int invcov_complex,
+int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_prop, const double* T, double T_scalar,
+                      const void* gradg_prop, int64_t n, int dtype, const void* preds_prop, const void* data, const void* invcov, int invcov_complex,
                       int64_t n_data, int data_dtype, const double* propose_scratch, double mu, double lmda, double* logpi_c,
                       double* L2_c, double* prior_c, const double* u, uint64_t seed, uint64_t chain0, uint64_t iter,
                       const uint64_t* iter_dev, int32_t* accept_out, double* delta_dev, int tune, int32_t* acc_trace,
@@ -801,7 +809,7 @@ int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_
                       double* L2_p_out, double* scratch, uint64_t* bump_counter, int C, pxm_stream_t stream) {
   PXM_REQUIRE(n >= 1 && n_data >= 1 && C >= 1 && (dtype == 0 || dtype == 1) && (data_dtype == 0 || data_dtype == 1),
               "pxm_pxmala_finish: bad n / n_data / C / dtype");
-  PXM_REQUIRE(X_prop && X_curr && proxf_prop && gradg_prop && preds_prop && data && invcov && propose_scratch && scratch,
+  PXM_REQUIRE(X_prop && X_curr && gradg_prop && preds_prop && data && invcov && propose_scratch && scratch,
               "pxm_pxmala_finish: null buffer");
   PXM_REQUIRE(data_dtype == 1 || !invcov_complex, "pxm_pxmala_finish: complex invcov needs complex data");
   PXM_REQUIRE(logpi_c && L2_c && prior_c && accept_out && delta_dev && logtrans_pc_out && logtrans_cp_out && prior_p_out && L2_p_out,
@@ -815,7 +823,7 @@ int pxm_pxmala_finish(const void* X_prop, const void* X_curr, const void* proxf_
   dim3 grid(RS + RD, C), blk(256);
 #define PXM_TAIL(CP, DC, IC_)                                                                                              \
   hipLaunchKernelGGL((k_pxmala_tail_partial<CP, DC, IC_>), grid, blk, 0, st, x1, x2, px, g, delta_dev, lmda, part_lt, n, RS, pp, dd, \
-                     ic, part_l2, n_data, RD)
+                     ic, part_l2, n_data, RD, T, T_scalar)
   if (dtype) {
     if (data_dtype && invcov_complex) PXM_TAIL(true, true, true);
     else if (data_dtype) PXM_TAIL(true, true, false);

@@ -762,7 +762,9 @@ class PxMALA(MYULA):
             kw = dict(seed=self.seed, chain0=self.chain_offset, it=i_host)
             noise = self._host_noise(X_curr) if host_rng else None
             if stock:
-                ops.pxmala_propose(X_curr, proxf_curr, gradg_curr, T_dev, w_prior, delta_dev, self.lmda, X_prop, proxf_prop,
+                # (fused tail: no prox arrays at all -- soft(X, T) is formed where it is needed)
+                ops.pxmala_propose(X_curr, None if fused_tail else proxf_curr, gradg_curr, T_dev, w_prior, delta_dev, self.lmda,
+                                   X_prop, None if fused_tail else proxf_prop,
                                    None if fused_tail else lt_cp, None if fused_tail else prior_p, noise=noise,
                                    noise_complex=bool(self.complex), iter_dev=counter, noise64=self.noise64,
                                    scratch=prop_scratch if fused_tail else None, **kw)
@@ -784,11 +786,12 @@ class PxMALA(MYULA):
             if fused_tail:
                 p_, data_, ic_ = self._l2_inputs(pp)
                 u = np.array([np.random.rand() for _ in range(C)]) if host_rng else None
-                ops.pxmala_finish(Xp, X_curr, pxp, gp.contiguous(), p_, data_, ic_, prop_scratch, self.mu, self.lmda, logpiXc,
+                ops.pxmala_finish(Xp, X_curr, None, gp.contiguous(), p_, data_, ic_, prop_scratch, self.mu, self.lmda, logpiXc,
                                   L2Xc, priorXc, accept, delta_dev, self.tune_delta, lt_pc, lt_cp, prior_p, L2_p, fin_scratch,
-                                  u=u, iter_dev=counter, acc_trace=acc_buf, delta_trace=delta_buf, bump=bump, **kw)
+                                  u=u, iter_dev=counter, acc_trace=acc_buf, delta_trace=delta_buf, bump=bump,
+                                  T=T_dev if T_dev is not None else 0.0, **kw)
                 self._last_transitions = (lt_cp, lt_pc)
-                ops.select_copy_many(accept, [(Xp, X_curr), (pp.to(curr_preds.dtype), curr_preds), (gp, gradg_curr), (pxp, proxf_curr)])
+                ops.select_copy_many(accept, [(Xp, X_curr), (pp.to(curr_preds.dtype), curr_preds), (gp, gradg_curr)])
                 return
             L2p = self._l2_dev(pp)
             ltp = ops.logtransition(Xp, X_curr, pxp, gp, delta_dev, self.lmda)

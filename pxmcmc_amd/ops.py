@@ -291,7 +291,10 @@ def pxmala_propose(X, proxf, gradg, T, prior_weights, delta_dev, lmda, Xp, proxf
                    noise_complex=False, seed=0, chain0=0, it=0, iter_dev=None, noise64=False, scratch=None):
     """chain_step + soft + calc_logtransition(X, X') + prior(X') in one pass; writes into the given buffers
     (Xp, proxf_p [C, n]; lt_out complex128 [C]; prior_out float64 [C]).  lt_out = prior_out = None with a caller-owned
-    ``scratch`` (pxmala_propose_scratch): the totals are left to pxmala_finish."""
+    ``scratch`` (pxmala_propose_scratch): the totals are left to pxmala_finish.  proxf = proxf_p = None: the prox arrays
+    are neither read nor written (soft(X, T) is formed in the kernel)."""
+    if (proxf is None) != (proxf_p is None):
+        raise ValueError("pxmala_propose: proxf and proxf_p are given together or not at all")
     x, _ = _batched(X)
     Tv, Ts = _vecT(T, x.shape[1], x.device)
     w, wc = _noise_args(noise, x, noise_complex)
@@ -325,11 +328,15 @@ def pxmala_accept2(lt_pc, lt_cp, prior_p, L2_p, mu, logpi_c, L2_c, prior_c, acce
 
 def pxmala_finish(Xp, X, proxf_p, gradg_p, preds_p, data, invcov, propose_scratch, mu, lmda, logpi_c, L2_c, prior_c, accept,
                   delta_dev, tune, lt_pc_out, lt_cp_out, prior_p_out, L2_p_out, scratch, u=None, seed=0, chain0=0, it=0,
-                  iter_dev=None, acc_trace=None, delta_trace=None, bump=None):
+                  iter_dev=None, acc_trace=None, delta_trace=None, bump=None, T=None):
     """Reverse transition sum + L2 of the proposal in one grid, then totals (incl. the deferred ones of pxmala_propose) +
     Metropolis test + state scalars + delta adaptation + traces in one workgroup (pxmcmc/mcmc.py:239-260,277-279);
-    ``scratch``: 2 * pxm_reduce_scratch_doubles(C) doubles, caller-owned; ``bump``: device iteration counter to advance."""
+    ``scratch``: 2 * pxm_reduce_scratch_doubles(C) doubles, caller-owned; ``bump``: device iteration counter to advance;
+    ``proxf_p = None`` with the threshold ``T``: proxf' = soft(X', T) is formed in the kernel instead of being read."""
     xp, _ = _batched(Xp)
+    if proxf_p is None and T is None:
+        raise ValueError("pxmala_finish: without proxf_p the threshold T is needed")
+    Tv, Ts = _vecT(T, xp.shape[1], xp.device) if proxf_p is None else (None, 0.0)
     pp, _ = _batched(preds_p)
     nd = pp.shape[1]
     d = data.reshape(-1)
@@ -337,14 +344,14 @@ def pxmala_finish(Xp, X, proxf_p, gradg_p, preds_p, data, invcov, propose_scratc
     if d.dtype != pp.dtype or d.numel() != nd or ic.numel() != nd or (ic.is_complex() and not pp.is_complex()):
         raise ValueError("pxmala_finish: data / invcov do not match the predictions")
     for t in (X, proxf_p, gradg_p):
-        if t.shape != xp.shape or t.dtype != xp.dtype or not t.is_contiguous():
+        if t is not None and (t.shape != xp.shape or t.dtype != xp.dtype or not t.is_contiguous()):
             raise ValueError("pxmala_finish: state arrays must share shape, dtype and be contiguous")
     C_ = accept.shape[0]
     uu = None if u is None else as_device(u, _REAL).reshape(-1)
     chunk = 0 if acc_trace is None else acc_trace.shape[0]
     check(
         lib.pxm_pxmala_finish(
-            _p(xp), _p(X), _p(proxf_p), _p(gradg_p), xp.shape[1], _dt(xp), _p(pp), _p(d), _p(ic), int(ic.is_complex()), nd, _dt(pp),
+            _p(xp), _p(X), _p(proxf_p), _p(Tv), Ts, _p(gradg_p), xp.shape[1], _dt(xp), _p(pp), _p(d), _p(ic), int(ic.is_complex()), nd, _dt(pp),
             _p(propose_scratch), float(mu), float(lmda), _p(logpi_c), _p(L2_c), _p(prior_c), _p(uu), seed, chain0, int(it),
             _p(iter_dev), _p(accept), _p(delta_dev), int(bool(tune)), _p(acc_trace), _p(delta_trace), int(chunk), _p(lt_pc_out),
             _p(lt_cp_out), _p(prior_p_out), _p(L2_p_out), _p(scratch), _p(bump), C_, _stream(),
