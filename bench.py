@@ -485,7 +485,7 @@ def config5_leg(n_iter=150, nrep=10, pmc=None):
     finite = bool(torch.isfinite(s.X_curr.real).all())
     # the same loop with a step small enough to be accepted (the reference's parameters, experiments/weaklensing/main.py:110-119,
     # are rejected throughout the first iterations from a zero start): the conditional copy of the accepted state
-    # (pxm_select_copy_many, 78 MB) inside the clock
+    # (pxm_select_copy_many: X, predictions and gradient, 45 MB) inside the clock
     pa = PxMCMCParams(nsamples=1, nburn=10 ** 9, ngap=1, delta=1e-12, lmda=lmda, mu=MU, verbosity=0, track=[])
     sa = PxMALA(op, reg, pa, tune_delta=False, nchains=1, seed=3, max_iter=n_iter, noise_bits=64)
     with contextlib.redirect_stdout(io.StringIO()):
