@@ -382,3 +382,30 @@ def test_pxmala_fused_tail_equals_separate_calls(C):
             for a, b in zip(got, ref):
                 np.testing.assert_array_equal(a, b, err_msg=str(key))
     assert accepted > 0 and rejected > 0  # accepted and rejected proposals in the compared windows
+
+
+def test_pxmala_fused_tail_equals_separate_calls_at_the_slice_cap():
+    """The same identity at a state of 2.2 M elements: every reduction runs with RED_SLICES_MAX = 1024 slices (16 per lane in
+    the one-workgroup totals), the size class of BASELINE configs[4] (1.2 M complex coefficients)."""
+    from pxmcmc_amd.forward import ForwardOperator
+    from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams
+    from pxmcmc_amd.measurements import Identity
+    from pxmcmc_amd.prior import L1
+    from pxmcmc_amd.transforms import IdentityTransform
+
+    n, C = 2_200_000, 2
+    rng = np.random.default_rng(9)
+    T = IdentityTransform()
+    op = ForwardOperator(rng.normal(size=n), 0.3, "synthesis", T, Identity(n, n), n)
+    reg = L1("synthesis", T.forward, T.forward_adjoint, 2e-3)
+    p = PxMCMCParams(lmda=4e-3, delta=2e-3, nsamples=2, nburn=2, ngap=1, verbosity=0, track=["logposterior", "L2", "prior"])
+    runs = {}
+    for fuse in (True, False):
+        s = PxMALA(op, reg, p, tune_delta=True, nchains=C, seed=4, track_transitions=True, max_iter=8)
+        s.fuse_tail = fuse
+        _quiet(s.run, start_point=np.zeros(n))
+        runs[fuse] = (np.asarray(s.acceptance_trace), np.asarray(s.deltas_trace), np.asarray(s.logPi), np.asarray(s.L2s),
+                      np.asarray(s.priors), np.asarray([t[0] for t in s.transitions_trace]),
+                      np.asarray([t[1] for t in s.transitions_trace]), s.X_curr.cpu().numpy() if hasattr(s.X_curr, "cpu") else np.asarray(s.X_curr))
+    for a, b in zip(runs[True], runs[False]):
+        np.testing.assert_array_equal(a, b)
