@@ -322,14 +322,15 @@ def myula_run(fwd, prior, lmda, delta, mu, nsamples, nburn, ngap, X0, noise, cpl
 def pxmala_run(fwd, prior, lmda, delta, mu, nsamples, nburn, ngap, X0, noise, unif, tune=True, max_iter=None):
     """pxmcmc/mcmc.py:218-275 with injected normal ``noise(i)`` and uniform ``unif(i)`` draws.  ``max_iter`` (test
     aid, not in the reference) stops after that many iterations; ``lt_cp`` / ``lt_pc`` record both
-    calc_logtransition values of every iteration (:240-241)."""
+    calc_logtransition values of every iteration (:240-241), ``l2_prop`` / ``prior_prop`` / ``logalpha`` the proposal's
+    L2, prior (:242) and log acceptance ratio (:244)."""
     X = np.array(X0)
     preds = fwd.forward(X)
     gradg = fwd.calc_gradg(preds)
     px = prior.proxf(X)
     lpc, l2c, prc = logpi(X, preds, fwd.data, fwd.invcov, prior.prior, mu)
     acc, deltas = [], [delta]
-    lt_cp, lt_pc = [], []
+    lt_cp, lt_pc, l2_prop, prior_prop, logalphas = [], [], [], [], []
     out = dict(chain=[], logPi=[], L2s=[], priors=[], preds=[])
     i = j = 0
     while j < nsamples and (max_iter is None or i < max_iter):
@@ -343,6 +344,9 @@ def pxmala_run(fwd, prior, lmda, delta, mu, nsamples, nburn, ngap, X0, noise, un
         lt_pc.append(t_pc)
         lpp, l2p, prp = logpi(Xp, pp, fwd.data, fwd.invcov, prior.prior, mu)
         logalpha = t_pc + lpp - t_cp - lpc
+        l2_prop.append(l2p)
+        prior_prop.append(prp)
+        logalphas.append(logalpha)
         accept = np.log(unif(i)) < logalpha
         if accept:
             X, preds, gradg, px, lpc, l2c, prc = Xp, pp, gp, pxp, lpp, l2p, prp
@@ -361,5 +365,6 @@ def pxmala_run(fwd, prior, lmda, delta, mu, nsamples, nburn, ngap, X0, noise, un
     out = {k: np.array(v) for k, v in out.items()}
     out["acceptance_trace"], out["deltas_trace"] = np.array(acc), np.array(deltas)
     out["lt_cp"], out["lt_pc"] = np.array(lt_cp), np.array(lt_pc)
+    out["l2_prop"], out["prior_prop"], out["logalpha"] = np.array(l2_prop), np.array(prior_prop), np.array(logalphas)
     out["X"], out["niter"] = X, i
     return out

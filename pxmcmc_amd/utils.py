@@ -27,25 +27,19 @@ def flatten_mlm(wav_lm, scal_lm):
 
 
 def expand_mlm(mlm, nscales=None, nscalcoefs=None, flatten_wavs=False):
-    """pxmcmc/utils.py:25-52."""
-    if nscales is None and nscalcoefs is None:
-        raise ValueError("Set either 'nscales', or 'nscalcoefs'")
-    elif nscales is not None and nscalcoefs is not None:
-        raise ValueError("Give only one of 'nscales' or 'nscalcoefs'")
-    elif nscales is not None:
-        mlm = np.asarray(mlm)
-        v_len = mlm.size // (nscales + 1)
-        assert v_len > 0
-        scal_lm = mlm[:v_len]
-        wav_lm = np.zeros((v_len, nscales), dtype=complex)
-        for i in range(nscales):
-            wav_lm[:, i] = mlm[(i + 1) * v_len : (i + 2) * v_len]
-        if flatten_wavs:
-            wav_lm = np.concatenate([wav_lm[:, i] for i in range(nscales)])
-    else:
-        scal_lm = mlm[..., :nscalcoefs]
-        wav_lm = mlm[..., nscalcoefs:]
-    return wav_lm, scal_lm
+    """pxmcmc/utils.py:25-52: (wavelets, scaling) of a flat vector -- either ``nscales`` + 1 blocks of equal length
+    (wavelets as the columns of a complex [len, nscales] array, or concatenated) or a split after ``nscalcoefs``."""
+    if (nscales is None) == (nscalcoefs is None):
+        raise ValueError("Set either 'nscales', or 'nscalcoefs'" if nscales is None
+                         else "Give only one of 'nscales' or 'nscalcoefs'")
+    if nscalcoefs is not None:
+        return mlm[..., nscalcoefs:], mlm[..., :nscalcoefs]
+    mlm = np.asarray(mlm)
+    per_block = mlm.size // (nscales + 1)
+    assert per_block > 0
+    blocks = mlm[: (nscales + 1) * per_block].reshape(nscales + 1, per_block)
+    wavs = blocks[1:].astype(complex)
+    return (wavs.reshape(-1) if flatten_wavs else np.ascontiguousarray(wavs.T)), blocks[0]
 
 
 def soft(X, T=0.1):
@@ -83,31 +77,29 @@ def sample_positions(L):
 
 
 def mw_weights(m):
-    """pxmcmc/utils.py:249-259."""
-    if m == 1:
-        return 1j * np.pi / 2
-    elif m == -1:
-        return -1j * np.pi / 2
-    elif m % 2 == 0:
-        return 2.0 / (1.0 - m * m)
-    return 0
+    """pxmcmc/utils.py:249-259: w(m) = int_0^pi exp(i m theta) sin(theta) dtheta = (1 + (-1)^m) / (1 - m^2), and
+    +-i pi/2 at the removable points m = +-1."""
+    m = int(m)
+    if abs(m) == 1:
+        return 0.5j * np.pi * m
+    return (1.0 + (-1.0) ** m) / (1.0 - m * m)
 
 
 def weights_theta(L):
-    """pxmcmc/utils.py:262-267."""
-    wr = np.zeros(2 * L - 1, dtype=complex)
-    for i, m in enumerate(range(-(L - 1), L)):
-        wr[i] = mw_weights(m) * np.exp(-1j * m * np.pi / (2 * L - 1))
-    return (np.fft.fft(np.fft.ifftshift(wr)) * 2 * np.pi / (2 * L - 1) ** 2).real
+    """pxmcmc/utils.py:262-267: quadrature weights on the 2L-1 rings of the theta-extended MW grid.  The reference's
+    FFT of w(m) exp(-i m pi/(2L-1)) is the cosine series below at theta_t = pi (2t+1)/(2L-1), written out (the m = +-1
+    pair gives pi sin(theta), the odd rest vanishes)."""
+    n = 2 * L - 1
+    theta = np.pi * (2 * np.arange(n) + 1) / n
+    even = np.arange(2, L, 2)
+    series = np.pi * np.sin(theta) + 2.0 + (np.cos(np.outer(theta, even)) @ (4.0 / (1.0 - even * even)) if even.size else 0.0)
+    return series * (2 * np.pi / n ** 2)
 
 
 def mw_map_weights(L):
-    """pxmcmc/utils.py:270-283: exact MW quadrature weights, shape (L(2L-1),)."""
-    wr = weights_theta(L)
-    q = np.copy(wr[0:L])
-    for i, j in enumerate(range(2 * L - 2, L - 1, -1)):
-        q[i] = q[i] + wr[j]
-    return np.outer(q, np.ones(2 * L - 1)).flatten()
+    """pxmcmc/utils.py:270-283: exact MW quadrature weights, shape (L(2L-1),) -- the ring weights of the library
+    (`pxm_mw_ring_weights`: mirror rings of the extended grid folded onto the L sampled ones), constant along phi."""
+    return np.repeat(ops.mw_ring_weights(int(L)), 2 * int(L) - 1)
 
 
 def s2_integrate(f, L):

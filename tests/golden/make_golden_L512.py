@@ -1,0 +1,107 @@
+"""
+G15: the oracle at the FULL size of BASELINE configs[4] -- L = 512, B = 2, J_min = 2, weak-lensing measurement with a
+mask and galaxy counts -- run ONCE in the build container (minutes, ~12 GB of ring tables) on the seeded inputs of
+``g15_setup.build()``; the fixture keeps sub-sampled outputs (NSUB fixed entries each) and three whole-array
+functionals per output (l2 norm, sum, projection on a seeded probe vector), < 1 MB in all.
+
+Outputs, each citing what the reference calls there:
+  wavelet synthesis / synthesis-adjoint / analysis / analysis-adjoint   pxmcmc/transforms.py:101-154 -> pys2let [ext]
+  spin-0 and spin-2 inverse / forward / inverse_adjoint / forward_adjoint  pxmcmc/measurements.py:223-239 -> pyssht [ext]
+  WeakLensing.forward / adjoint with the mask and inv_cov                pxmcmc/measurements.py:209-304
+  ForwardOperator.forward / calc_gradg (wavelets o weak lensing)         pxmcmc/forward.py:36-72
+  S2_Wavelets_L1 threshold weights and prior                             pxmcmc/prior.py:67-84
+  PX_ITERS iterations of PxMALA.run with injected draws: acceptance, delta, both calc_logtransition values, L2 / prior /
+  log alpha of every proposal, the accepted states                        pxmcmc/mcmc.py:218-289
+
+The arithmetic is ``oracle/`` (the restated pyssht / pys2let algorithms: "parity unpinned" against the absent wheels, as
+its header says); what G15 adds is a DENSE comparison at the size the one-chain HIP plan (recursion + packed GEMM lists +
+twin / narrow arrays) exists for.
+
+    python tests/golden/make_golden_L512.py            # ~10 min, peak ~20 GB
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(OUT))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, OUT)
+
+import g15_setup as g15  # noqa: E402
+from oracle import pxmcmc_np as ref  # noqa: E402
+from oracle import ssht  # noqa: E402
+
+
+def main():
+    t0 = time.time()
+    L, B, J = g15.L, g15.B, g15.J_MIN
+    d = g15.build()
+    res = {"input_digest": g15.input_digest(d), "ndata": np.array(d["ndata"])}
+
+    def put(name, a):
+        a = np.asarray(a).reshape(-1)
+        idx = g15.sub_indices(name, a.size)
+        res[name + "_idx"] = idx.astype(np.int32)
+        res[name + "_val"] = a[idx]
+        res[name + "_fun"] = g15.functionals(a, d["probe"][a.size])
+        print(f"[{time.time() - t0:7.1f} s] {name:16s} n = {a.size:8d}  |.| = {res[name + '_fun'][0]:.6e}", flush=True)
+
+    T = ref.SphericalWaveletTransform(L, B, J)
+    assert T.ncoefs == g15.NCOEFS and list(T.w.bls) == g15.BLS
+    img = d["f"].reshape(L, 2 * L - 1)
+    for spin, flm in ((0, d["flm0"]), (2, d["flm2"])):
+        put(f"sht{spin}_inverse", ssht.inverse(flm, L, spin))
+        put(f"sht{spin}_forward", ssht.forward(img, L, spin))
+        put(f"sht{spin}_inverse_adjoint", ssht.inverse_adjoint(img, L, spin))
+        put(f"sht{spin}_forward_adjoint", ssht.forward_adjoint(flm, L, spin))
+    put("wav_inverse", T.inverse(d["X"]))                    # synthesis
+    put("wav_inverse_adjoint", T.inverse_adjoint(d["f"]))    # synthesis adjoint
+    put("wav_forward", T.forward(d["f"]))                    # analysis
+    put("wav_forward_adjoint", T.forward_adjoint(d["X"]))    # analysis adjoint
+    owl = ref.WeakLensing(L, mask=d["mask"], ngal=d["ngal"])
+    assert owl.ndata == d["ndata"]
+    put("wl_forward", owl.forward(d["f"]))
+    put("wl_adjoint", owl.adjoint(d["gam"]))
+    oop = ref.ForwardOperator(d["data"], 1 / owl.inv_cov, "synthesis", T, owl, T.ncoefs)
+    preds_X = oop.forward(d["X"])
+    put("op_forward", preds_X)
+    put("op_gradg", oop.calc_gradg(d["preds"]))
+    put("op_gradg_of_forward", oop.calc_gradg(preds_X))
+    oreg = ref.S2_Wavelets_L1("synthesis", None, None, g15.LMDA * g15.MU, L, B, J)
+    put("reg_T", oreg.T)
+    res["reg_prior_X"] = np.array(oreg.prior(d["X"]))
+    lp, l2, pr = ref.logpi(d["X"], preds_X, d["data"], oop.invcov, oreg.prior, g15.MU)
+    res["logpi_X"] = np.array([lp, l2, pr], dtype=complex)
+
+    # PxMALA: PX_ITERS iterations from X0 on injected draws; delta_0 = the first candidate whose trace holds accepted AND
+    # rejected proposals (the literal calc_logtransition is ~ delta^3 N^2 here, so the test is L2 / prior driven)
+    nz, un = g15.pxmala_draws(g15.PX_ITERS, g15.NCOEFS)
+    X0 = d["X0"].astype(complex)
+    chosen = None
+    for delta0 in (1e-11, 3e-12, 1e-12, 3e-13, 1e-13, 3e-14):
+        out = ref.pxmala_run(oop, oreg, g15.LMDA, delta0, g15.MU, 10 ** 6, 0, 1, X0, lambda i: nz[i], lambda i: un[i],
+                             tune=True, max_iter=g15.PX_ITERS)
+        acc = out["acceptance_trace"]
+        print(f"[{time.time() - t0:7.1f} s] pxmala delta0 = {delta0:g}: acceptance {list(acc)} logalpha {np.real(out['logalpha'])}",
+              flush=True)
+        if 0 < acc.sum() < len(acc):
+            chosen = delta0
+            break
+    assert chosen is not None, "no candidate delta_0 gave a mixed trace"
+    res["px_delta0"] = np.array(chosen)
+    for k in ("acceptance_trace", "deltas_trace", "lt_cp", "lt_pc", "l2_prop", "prior_prop", "logalpha", "logPi", "L2s", "priors"):
+        res["px_" + k] = np.asarray(out[k])
+    for n, x in enumerate(out["chain"]):  # accepted states (real parts, as the reference's tracking stores them)
+        put(f"px_chain{n}", x)
+    res["px_nsaved"] = np.array(len(out["chain"]))
+    put("px_X_final", out["X"])
+    path = os.path.join(OUT, "g15_L512.npz")
+    np.savez_compressed(path, **res)
+    print(f"wrote {path}: {os.path.getsize(path) / 1e6:.2f} MB in {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
