@@ -462,10 +462,65 @@ def rec_stage_flops(L, spin, ncols):
     return steps * L * (2 + 2 * ncols) * 2.0
 
 
-def config5_leg(n_iter=150, nrep=10, pmc=None):
+C5_TUNE_CAP, C5_WINDOW, C5_TIMED, C5_LAP = 6000, 200, 150, 50   # tuned PxMALA leg: iteration cap, acceptance window, timed stretch, lap
+C5_ACC_LO, C5_ACC_HI = 0.3, 0.7
+
+
+def tuned_iteration(acc, window=C5_WINDOW, lap=C5_LAP, timed=C5_TIMED, lo=C5_ACC_LO, hi=C5_ACC_HI):
+    """First iteration count n (a multiple of ``lap``, n >= window, n + timed <= len(acc)) at which the acceptance rate of
+    the last ``window`` iterations lies in [lo, hi]: the adaptation of pxmcmc/mcmc.py:277-279 has brought delta to its
+    working value.  Returns (n, window acceptance, True) or (len(acc) - timed rounded down to a lap, its window acceptance,
+    False) when the trace never gets there."""
+    acc = np.asarray(acc, dtype=float)
+    last = (len(acc) - timed) // lap * lap
+    for n in range((window + lap - 1) // lap * lap, last + 1, lap):
+        a = float(acc[n - window:n].mean())
+        if lo <= a <= hi:
+            return n, a, True
+    n = max(last, 0)
+    return n, float(acc[max(n - window, 0):n].mean()) if n else 0.0, False
+
+
+def config5_tuned(op, reg, tr, lmda, chain_offset=0, cap=C5_TUNE_CAP):
+    """The PxMALA chain of BASELINE configs[4] as a user runs it (experiments/weaklensing/main.py:110-147): delta_0 = 1e-6
+    from a zero start, ``tune_delta`` on (pxmcmc/mcmc.py:258-260, 277-279), ONE uninterrupted run of ``cap`` iterations with
+    a device synchronise + host time stamp every C5_LAP iterations.  delta_0 is rejected throughout until the adaptation has
+    shrunk it by ~6 decades (the data term moves by ~2 delta ||A||^2 per proposal); the timed stretch is the C5_TIMED iterations
+    that follow the first lap at which the acceptance over the last C5_WINDOW iterations is inside [0.3, 0.7]."""
     import torch
 
     from pxmcmc_amd.mcmc import PxMALA, PxMCMCParams
+
+    # (nburn beyond the run: no save candidates, i.e. no per-iteration host synchronisation; max_iter bounds the run --
+    # the reference's loop only ends on accepted samples)
+    p = PxMCMCParams(nsamples=1, nburn=10 ** 9, ngap=1, delta=C5_DELTA0, lmda=lmda, mu=MU, verbosity=0, track=[])
+    s = PxMALA(op, reg, p, tune_delta=True, nchains=1, seed=3, chain_offset=chain_offset, max_iter=cap, lap_every=C5_LAP,
+               noise_bits=64)
+    with contextlib.redirect_stdout(io.StringIO()):
+        s.run(start_point=np.zeros(tr.ncoefs))
+    assert s.niter == cap
+    acc = np.asarray(s.acceptance_trace, dtype=float)
+    deltas = np.asarray(s.deltas_trace, dtype=float)
+    laps = dict(s.laps)
+    n0, a0, ok = tuned_iteration(acc)
+    n1 = n0 + C5_TIMED
+    ms = (laps[n1] - (laps[n0] if n0 else 0.0)) / C5_TIMED * 1e3
+    first = laps[C5_TIMED] / C5_TIMED * 1e3
+    return {"ms_per_iteration": ms, "samples_per_s": 1e3 / ms, "tuned": ok, "iterations_before_timed_stretch": int(n0),
+            "window_acceptance_at_start": a0, "acceptance_in_timed_stretch": float(acc[n0:n1].mean()),
+            "acceptance_after_tuning": float(acc[n0:].mean()), "delta_at_start_of_stretch": float(deltas[n0]),
+            "delta_final": float(deltas[-1]), "delta_0": C5_DELTA0, "timed_iterations": C5_TIMED, "iterations_run": cap,
+            "first_iterations": {"iterations": C5_TIMED, "ms_per_iteration": first, "acceptance": float(acc[:C5_TIMED].mean()),
+                                 "what": "the first iterations of the same run: delta_0 = 1e-6 is rejected throughout, no "
+                                         "conditional copy of an accepted state in the clock"},
+            "hip_graph": bool(s.used_graph), "finite": bool(torch.isfinite(s.X_curr.real).all()),
+            "loop_ms_per_iteration_all": s.loop_seconds / cap * 1e3,
+            "clock": f"host time stamps after a device synchronise every {C5_LAP} iterations of one run "
+                     "(PxMALA(lap_every=...)); the stretch is the difference of two stamps"}
+
+
+def config5_leg(nrep=10, pmc=None, cap=C5_TUNE_CAP):
+    import torch
 
     t_setup = time.perf_counter()
     op, reg, tr, wl, lmda = config5_problem()
@@ -473,26 +528,7 @@ def config5_leg(n_iter=150, nrep=10, pmc=None):
     assert plan is not None
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
-    # (nburn beyond the run: no save candidates, i.e. no per-iteration host synchronisation; max_iter bounds the run --
-    # the reference's loop only ends on accepted samples)
-    p = PxMCMCParams(nsamples=1, nburn=10 ** 9, ngap=1, delta=C5_DELTA0, lmda=lmda, mu=MU, verbosity=0, track=[])
-    s = PxMALA(op, reg, p, tune_delta=True, nchains=1, seed=3, max_iter=n_iter, noise_bits=64)
-    with contextlib.redirect_stdout(io.StringIO()):
-        s.run(start_point=np.zeros(tr.ncoefs))
-    assert s.niter == n_iter
-    ms_iter = s.loop_seconds / n_iter * 1e3  # the iterations alone (PxMALA.run times its loop between two synchronisations)
-    acc, used_graph = float(np.mean(s.acceptance_trace)), bool(s.used_graph)
-    finite = bool(torch.isfinite(s.X_curr.real).all())
-    # the same loop with a step small enough to be accepted (the reference's parameters, experiments/weaklensing/main.py:110-119,
-    # are rejected throughout the first iterations from a zero start): the conditional copy of the accepted state
-    # (pxm_select_copy_many: X, predictions and gradient, 45 MB) inside the clock
-    pa = PxMCMCParams(nsamples=1, nburn=10 ** 9, ngap=1, delta=1e-12, lmda=lmda, mu=MU, verbosity=0, track=[])
-    sa = PxMALA(op, reg, pa, tune_delta=False, nchains=1, seed=3, max_iter=n_iter, noise_bits=64)
-    with contextlib.redirect_stdout(io.StringIO()):
-        sa.run(start_point=np.zeros(tr.ncoefs))
-    accepting = {"ms_per_iteration": sa.loop_seconds / n_iter * 1e3, "acceptance": float(np.mean(sa.acceptance_trace)),
-                 "delta": 1e-12, "tune_delta": False, "finite": bool(torch.isfinite(sa.X_curr.real).all()),
-                 "what": "the same iteration with a step that is accepted: the conditional copy of the accepted state runs in the clock"}
+    tuned = config5_tuned(op, reg, tr, lmda, cap=cap)
     plan.profile_enable(4 * nrep + 8)
     config5_operator_loop(op, nrep)
     rec = bool(plan.wl_uses_recursion())
@@ -511,17 +547,58 @@ def config5_leg(n_iter=150, nrep=10, pmc=None):
         else:
             c.update(kernel="k_sht_gemm_pk (packed column tile) / k_sht_gemm: per-scale spin-0 ring tables", bound="hbm")
     gemm_us = sum(c["avg_us"] * c["launches"] for c in classes) / nrep
-    return {"workload": f"PxMALA (tune_delta), wavelet synthesis L={C5_L} B={C5_B} J_min={C5_JMIN} (N=1221796) + weak-lensing shear "
-                        f"measurement with a mask ({wl.ndata} of {wl.npix} pixels kept) and ngal = {C5_NGAL:.0f}, 1 chain, fused operator, "
-                        "one-pass propose / accept kernels, HIP graph",
-            "iterations": n_iter, "ms_per_iteration": ms_iter, "samples_per_s": 1e3 / ms_iter,
-            "acceptance": acc, "hip_graph": used_graph, "finite": finite and accepting["finite"], "setup_s": t_setup,
-            "accepting_iterations": accepting,
-            "ring_stage_us_per_iteration": gemm_us, "gemm_launch_classes": classes,
-            "spin2_stage": "table-free recursion (csrc/sht_rec.hip)" if rec else "ring-table GEMM",
-            "note": "four ring stages per iteration: two spin-0 group launches on the 8 + 1 wavelet scales (packed column tile, the two "
-                    "512-band-limited scales in one pass over their table and one twin ring array) and two spin-2 stages (Wigner "
-                    "rows by three-term recursion on the vector pipe: no table, 25 MB instead of 1.09 GB per launch)"}
+    out = {"workload": f"PxMALA (tune_delta), wavelet synthesis L={C5_L} B={C5_B} J_min={C5_JMIN} (N=1221796) + weak-lensing shear "
+                       f"measurement with a mask ({wl.ndata} of {wl.npix} pixels kept) and ngal = {C5_NGAL:.0f}, 1 chain, fused operator, "
+                       "one-pass propose / accept kernels, HIP graph; timed in the TUNED state (acceptance of the last "
+                       f"{C5_WINDOW} iterations inside [{C5_ACC_LO}, {C5_ACC_HI}])",
+           "iterations": C5_TIMED}
+    out.update(tuned)
+    out.update({"acceptance": tuned["acceptance_in_timed_stretch"], "setup_s": t_setup,
+                "ring_stage_us_per_iteration": gemm_us, "gemm_launch_classes": classes,
+                "spin2_stage": "table-free recursion (csrc/sht_rec.hip)" if rec else "ring-table GEMM",
+                "note": "four ring stages per iteration: two spin-0 group launches on the 8 + 1 wavelet scales (packed column tile, the two "
+                        "512-band-limited scales in one pass over their table and one twin ring array) and two spin-2 stages (Wigner "
+                        "rows by three-term recursion on the vector pipe: no table, 25 MB instead of 1.09 GB per launch)"})
+    return out
+
+
+def config5_multirank_leg(rank, world, D, cap=C5_TUNE_CAP):
+    """BASELINE configs[4] as it is named: one PxMALA chain per GPU (the reference runs one chain per process,
+    experiments/weaklensing/main.py:110-147).  Every rank builds the same problem, runs ITS chain (Philox keyed by the global
+    chain id = rank) through ``config5_tuned`` on its own clock -- no torch.distributed call between the first and the last
+    time stamp of a rank -- and the per-rank figures are all-gathered afterwards."""
+    import torch
+
+    err = 0.0
+    res = {"ms_per_iteration": float("nan"), "acceptance_in_timed_stretch": float("nan"), "delta_at_start_of_stretch": float("nan"),
+           "iterations_before_timed_stretch": -1, "tuned": False, "finite": False}
+    try:
+        op, reg, tr, wl, lmda = config5_problem()
+        assert op._wl_plan() is not None
+        torch.cuda.synchronize()
+        res = config5_tuned(op, reg, tr, lmda, chain_offset=rank, cap=cap)
+    except Exception as exc:  # (the gather below must still be entered by every rank)
+        err = 1.0
+        print(f"bench.py rank {rank}: configs[4] leg failed: {exc!r}", file=sys.stderr)
+    ms = D.all_gather_float(res["ms_per_iteration"])
+    out = {"workload": f"PxMALA (tune_delta), wavelet synthesis L={C5_L} B={C5_B} J_min={C5_JMIN} + weak-lensing shear measurement "
+                       f"with a mask, ngal = {C5_NGAL:.0f}: ONE chain per GPU, {world} GPUs, chain id = rank, timed in the tuned state",
+           "per_rank_ms_per_iteration": ms,
+           "ms_per_iteration": max(ms),
+           "samples_per_s": world * 1e3 / max(ms),
+           "samples_per_s_sum_of_ranks": sum(1e3 / m for m in ms),
+           "per_rank_acceptance": D.all_gather_float(res["acceptance_in_timed_stretch"]),
+           "per_rank_delta": D.all_gather_float(res["delta_at_start_of_stretch"]),
+           "per_rank_iterations_before_timed_stretch": [int(v) for v in D.all_gather_float(float(res["iterations_before_timed_stretch"]))],
+           "per_rank_tuned": [bool(v) for v in D.all_gather_float(float(bool(res["tuned"])))],
+           "timed_iterations": C5_TIMED, "iterations_run": cap,
+           "ranks_seen": len(ms),
+           "finite": all(bool(v) for v in D.all_gather_float(float(bool(res["finite"])))),
+           "timing": "per rank: its own run, its own device synchronises and host time stamps; ms_per_iteration = max over "
+                     "ranks, samples_per_s = ranks / that (the chains advance side by side)"}
+    if sum(D.all_gather_float(err)) > 0:
+        out["error"] = "a rank's configs[4] leg raised (see stderr)"
+    return out
 
 
 PARITY_TOL = 1e-9  # full-size parity leg: max |X_hip - X_oracle| / max |X| after 3 iterations
@@ -565,7 +642,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--ramp", type=int, default=400, help="untimed iterations before the warm-up (clock ramp; declared in the JSON)")
+    ap.add_argument("--ramp", type=int, default=400, help="untimed iterations between the literal W + K run (value_no_ramp) and the headline regions (clock ramp; declared in the JSON)")
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of K steps back to back; value = the median region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=48)
     ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU leg (0 = min(usable cores, 32))")
@@ -578,6 +656,9 @@ def main():
                          "(pxmcmc/mcmc.py:193); 32 = the f32 transcendental units.  The other one is timed as the side leg")
     ap.add_argument("--no-noise-leg", "--no-f64-noise-leg", dest="no_noise_leg", action="store_true",
                     help="skip the second timing with the other Box-Muller precision (value_f32_noise)")
+    ap.add_argument("--config5-cap", type=int, default=C5_TUNE_CAP,
+                    help="iterations of the configs[4] PxMALA run (delta adapts from 1e-6; the timed stretch follows the first lap "
+                         "with the window acceptance inside [0.3, 0.7])")
     ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)  # internal: body of the side legs' rocprofv3 --pmc passes
     args = ap.parse_args()
     if args.pmc_child:
@@ -658,22 +739,31 @@ def main():
     eng = sampler._engine_start(X, preds, 0)
     barrier = D.barrier
 
-    # Clock ramp: the driver's default run times 20 steps = 3 ms, shorter than the time the GPU takes to reach its
-    # sustained clocks from idle; --ramp untimed iterations precede the W requested warm-up steps.  The JSON's
-    # top-level "warmup" is the TOTAL untimed count (ramp + W); config.warmup_requested / clock_ramp_steps split it.
-    untimed = args.ramp + args.warmup
-    sampler._engine_advance(untimed)
-    # Timed region: start barrier (device idle + ranks aligned), then each rank times ITS OWN K steps up to its own
-    # device synchronise -- no torch.distributed call lies between t0 and dt (nothing crosses ranks on the data path, so a
-    # collective inside a 3-ms clock would only measure the collective).  The stop-side barrier follows, outside the
-    # clock; the reported time is the MAX over ranks of the per-rank times.
-    barrier()
-    t0 = time.perf_counter()
-    sampler._engine_advance(args.steps)
-    torch.cuda.synchronize()
-    dt_rank = time.perf_counter() - t0
-    barrier()
-    dt = dt_rank
+    # Timed regions.  Each one: start barrier (device idle + ranks aligned), then each rank times ITS OWN K steps up to its
+    # own device synchronise -- no torch.distributed call lies between t0 and dt (nothing crosses ranks on the data path, so
+    # a collective inside a 3-ms clock would only measure the collective).  The stop-side barrier follows, outside the
+    # clock; a region's time is the MAX over ranks of the per-rank times.
+    def timed_region():
+        barrier()
+        t0 = time.perf_counter()
+        sampler._engine_advance(args.steps)
+        torch.cuda.synchronize()
+        dt_r = time.perf_counter() - t0
+        barrier()
+        return dt_r
+
+    # (i) what the command asked for, literally: W warm-up steps from a cold start, then K timed steps -> value_no_ramp.
+    sampler._engine_advance(args.warmup)
+    dt_no_ramp_rank = timed_region()
+    # (ii) Clock ramp: the driver's default run times 20 steps = 3 ms, shorter than the time the GPU takes to reach its
+    # sustained clocks from idle; --ramp further untimed iterations precede the regions the headline is taken from.
+    # "warmup" in the JSON is the W of the command line; config.untimed_steps_before_headline is everything that ran
+    # before the first headline region (W + K of region (i) + ramp).
+    sampler._engine_advance(args.ramp)
+    untimed = args.warmup + args.steps + args.ramp
+    # (iii) the timed region --repeats times back to back; value = MEDIAN region, min / max beside it
+    dt_ranks = [timed_region() for _ in range(max(args.repeats, 1))]
+    dt_rank = dt_ranks[0]
     # roofline leg: the same steps once more through the same engine, launched eagerly (no graph replay) so that
     # every k_sht_gemm launch can be bracketed by HIP events on its stream (events cannot be read back from
     # inside a graph replay)
@@ -710,8 +800,12 @@ def main():
     if not os.environ.get("PXM_BENCH_ABLATION"):  # (timing-only ablation builds of the library compute garbage)
         assert bool(torch.isfinite(X.real).all()) and bool(torch.isfinite(preds.real).all())
 
-    dt = D.max_over_ranks(dt_rank)
-    per_rank_ms = [v * 1e3 / args.steps for v in D.all_gather_float(dt_rank)]
+    region_dts = [D.max_over_ranks(v) for v in dt_ranks]          # per region: max over ranks
+    order = sorted(range(len(region_dts)), key=lambda k: region_dts[k])
+    k_med = order[(len(order) - 1) // 2]                           # median region (lower median for an even count)
+    dt = region_dts[k_med]
+    per_rank_ms = [v * 1e3 / args.steps for v in D.all_gather_float(dt_ranks[k_med])]
+    dt_no_ramp = D.max_over_ranks(dt_no_ramp_rank)
     # cost of one empty start/stop barrier of this process group (synchronise + dist.barrier + synchronise), after the
     # run: what the clock WOULD have contained had the stop barrier been inside it
     barrier()
@@ -785,11 +879,20 @@ def main():
         for name, fn in (("configs[1]", config2_leg), ("configs[4]", config5_leg)):
             t1 = time.perf_counter()
             try:
-                config_legs[name] = fn(pmc=(legs_pmc or {}).get(name))
+                kw = {"cap": args.config5_cap} if fn is config5_leg else {}
+                config_legs[name] = fn(pmc=(legs_pmc or {}).get(name), **kw)
             except Exception as exc:  # a side leg must never take the headline down with it
                 config_legs[name] = {"error": repr(exc)}
             config_legs[name]["leg_wall_s"] = time.perf_counter() - t1
             ops.tables_trim()
+
+    if world > 1 and not args.no_config_legs:
+        # BASELINE configs[4] "8 chains on 8 GPUs": every rank runs its own PxMALA chain after the headline
+        sampler._engine_stop()
+        t1 = time.perf_counter()
+        leg = config5_multirank_leg(rank, world, D, cap=args.config5_cap)
+        leg["leg_wall_s"] = time.perf_counter() - t1
+        config_legs = {"configs[4]": leg}
 
     if rank == 0:
         value = world * C * args.steps / dt
@@ -826,8 +929,17 @@ def main():
             "n_gpus": world,
             "ranks_seen": ranks_seen,
             "steps": args.steps,
-            "warmup": untimed,
+            "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            # the command as written -- W warm-up steps from a cold start, K timed steps, no clock ramp:
+            "value_no_ramp": world * C * args.steps / dt_no_ramp,
+            "ms_per_step_no_ramp": dt_no_ramp / args.steps * 1e3,
+            # the headline region repeated back to back; `value` / `ms_per_step` are the median region's
+            "repeats": {"n": len(region_dts), "ms_per_step": [v / args.steps * 1e3 for v in region_dts],
+                        "value_min": world * C * args.steps / max(region_dts), "value_max": world * C * args.steps / min(region_dts),
+                        "value_median": world * C * args.steps / dt,
+                        "what": "the K-step timed region (barrier, K steps, own device synchronise; max over ranks) run "
+                                "n times back to back after the clock ramp; value = the median region"},
             "per_rank_ms_per_step": per_rank_ms,
             "barrier_us": barrier_us,
             "timing": "per rank: start barrier, t0, K steps, own device synchronise, stop clock (no collective inside); "
@@ -852,6 +964,7 @@ def main():
                 "graph_iterations_per_replay": 2 * sampler._GRAPH_PAIRS if used_graph else 0,
                 "warmup_requested": args.warmup,
                 "clock_ramp_steps": args.ramp,
+                "untimed_steps_before_headline": untimed,
                 "noise_bits": args.noise_bits,
                 "noise": NOISE_NOTES[args.noise_bits],
             },

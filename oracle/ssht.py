@@ -144,7 +144,7 @@ def _quadrature_gram(L):
             X[u, n - 1 - u] = par
         q = X.T @ core @ X
         assert np.abs(q.imag).max() < 1e-12 * max(1.0, np.abs(q.real).max())
-        out[par] = q.real
+        out[par] = np.ascontiguousarray(q.real)  # (a strided view would take numpy's matmul off BLAS)
     return out
 
 

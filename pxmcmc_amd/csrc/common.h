@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -58,6 +59,14 @@ bool dev_range_ok(const void* lo, const void* hi, std::string* msg);
 int64_t ranges_checked();          // spans verified since the last reset (all plans of this process)
 void ranges_checked_add(int64_t n);
 void ranges_checked_reset();
+
+// hipFuncSetAttribute is per device: true the first time it is asked for the CURRENT device (one flag word per call site)
+inline bool first_on_this_device(std::atomic<uint64_t>& seen) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) d = 0;
+  const uint64_t bit = 1ull << (d & 63);
+  return !(seen.fetch_or(bit) & bit);
+}
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int round_down(int x, int m) { return x / m * m; }

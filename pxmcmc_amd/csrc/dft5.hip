@@ -1129,14 +1129,13 @@ static Dft5Args dft5_args(const DftPlan& p) {
 
 template <int R0>
 static int dft5_attr() {
-  static bool done = false;
-  if (!done) {
+  static std::atomic<uint64_t> seen{0};
+  if (first_on_this_device(seen)) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring5<R0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ring2px5<R0, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
   }
   return 0;
 }
@@ -1400,15 +1399,14 @@ static Dft6Args dft6_args(const DftPlan& p) {
 // chains per workgroup: 2 (8 waves, 2 workgroups per CU: 4 waves per SIMD); 1 for a single chain
 static size_t dft6_lds(int R) { return (size_t)4 * R * D5_PLANE * 16 + (size_t)D5_TW * 16; }  // (>= the stage: n R 16 B)
 static int dft6_attr() {
-  static bool done = false;
-  if (!done) {
+  static std::atomic<uint64_t> seen{0};
+  if (first_on_this_device(seen)) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring6<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_px2ring6<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px6<false, 0>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px6<true, 0>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px6<false, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px6<true, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
   }
   return 0;
 }

@@ -420,13 +420,14 @@ __global__ void k_pxmala_accept2(const double2* __restrict__ lt_pc, const double
 // k_pxmala_propose_final (so the totals are the ones the separate kernels give); the totals meet in LDS and lane 0 of the
 // chain's first wave decides.  The totals are also stored for observers.  `bump`: the device-resident iteration counter of a
 // captured iteration, advanced here after every chain has read it (one workgroup) -- the last reader of the counter in an
-// iteration.
+// iteration.  `bump` MAY ALIAS a.iter_dev (PxMALA's captured iteration passes the same counter as both): it is not
+// `__restrict__`, and the store sits behind the last barrier.
 __global__ __launch_bounds__(1024) void k_pxmala_accept3(const double* __restrict__ part_prop, int slices_prop,
                                                          const double2* __restrict__ part_lt, int slices_lt,
                                                          const double2* __restrict__ part_l2, int slices_l2,
                                                          double2* __restrict__ lt_pc_out, double2* __restrict__ lt_cp_out,
                                                          double* __restrict__ prior_p_out, double2* __restrict__ L2_p_out,
-                                                         AcceptArgs a, uint64_t* __restrict__ bump) {
+                                                         AcceptArgs a, uint64_t* bump) {
   constexpr int CB = 5;              // chains per round
   __shared__ double tot[CB][8];      // (S_cp.re, S_cp.im, prior, -, S_pc.re, S_pc.im, L2.re, L2.im)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -130,7 +130,9 @@ __device__ inline NormalPair box_muller_f64_poly(double u1, double u2) {
 __device__ inline NormalPair box_muller_f64_tab(double u1, double u2) {
   const int ex = __builtin_amdgcn_frexp_exp(u1);
   const double m = __builtin_amdgcn_frexp_mant(u1);  // [0.5, 1)
-  const int j = (int)__builtin_rint(m * 256.0);      // 128 .. 256
+  // 128 .. 256 for the stream's u1 in (0, 1]; clamped so that a caller-supplied u1 outside that range (0, NaN, inf through
+  // pxm_box_muller) reads a table entry and not the memory in front of the table
+  const int j = min(max((int)__builtin_rint(m * 256.0), NOISE_LOG_J0), 256);
   const double2 lt = *reinterpret_cast<const double2*>(&NOISE_LOG_TAB[j - NOISE_LOG_J0][0]);
   const double r = fma(m, lt.x, -1.0);
   double p = 1.0 / 7.0;

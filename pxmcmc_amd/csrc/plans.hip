@@ -484,6 +484,7 @@ struct pxm_wav_plan_s {
   // are one two-"chain" launch instead of two one-chain launches and the packed GEMM stages both from the same lines
   int pk = 0;                   // live columns per slab of the packed per-scale lists, 0 = unpacked (more than 2 chains)
   int twin_s = -1;              // the coarser scale of the pair, -1 = none
+  bool wl_failed = false;       // a pxm_wav_wl_attach gave up part-way: the weak-lensing entry points refuse the plan
   double* d_twin = nullptr;     // [2 bl - 1][Rp_bl][ncol_t]
   int64_t offGT = 0;            // d_twin relative to ws (doubles)
   int ncol_t = 0;               // doubles per row of the twin array: 4 (narrow: its two slots and nothing else) or ncol
@@ -581,7 +582,7 @@ static GemmSide wav_side(const pxm_wav_plan_s* p, int s, int which, const SideOv
 
 // packed per-scale lists (sht_gemm.hip: k_sht_gemm_pk) of stage `which` for every scale; scales of equal bandlimit stream their
 // table in one pass.  twin_s >= 0: scales twin_s / twin_s + 1 read / write chain slots 0 / 1 of the array at g_twin.
-static void wav_packed_lists(const pxm_wav_plan_s* p, int which, int kind, int twin_s, int64_t g_twin, std::vector<GemmTask>& out,
+static int wav_packed_lists(const pxm_wav_plan_s* p, int which, int kind, int twin_s, int64_t g_twin, std::vector<GemmTask>& out,
                              std::vector<char>* shared, int twin_ncol = 0, bool narrow_h = false, bool narrow_g = false) {
   if (shared) shared->assign(p->nsc, 0);
   for (int s = 0; s < p->nsc; ++s) {
@@ -600,6 +601,11 @@ static void wav_packed_lists(const pxm_wav_plan_s* p, int which, int kind, int t
     const GemmSide a = wav_side(p, s, which, oa);
     if (pair) {
       const GemmSide b = wav_side(p, s + 1, which, ob);
+      // a packed pair is ONE task with one pair of row strides (GemmTask::x_ncol / y_ncol, taken from side a): a pair of which
+      // only one scale sits on a narrow array must not be packed
+      PXM_REQUIRE((a.x_ncol ? a.x_ncol : p->ncol) == (b.x_ncol ? b.x_ncol : p->ncol) &&
+                      (a.y_ncol ? a.y_ncol : p->ncol) == (b.y_ncol ? b.y_ncol : p->ncol),
+                  "wav_packed_lists: the two scales of a packed pair have arrays of different row strides");
       append_gemm_tasks_packed(*p->T[s], kind, p->ncol, a, &b, p->offS, p->ws, out);
       if (shared) (*shared)[s + 1] = 1;
       ++s;
@@ -607,6 +613,7 @@ static void wav_packed_lists(const pxm_wav_plan_s* p, int which, int kind, int t
       append_gemm_tasks_packed(*p->T[s], kind, p->ncol, a, nullptr, p->offS, p->ws, out);
     }
   }
+  return 0;
 }
 
 extern "C" {
@@ -734,8 +741,8 @@ int pxm_wav_plan_create(int L, double B, int J_min, int max_chains, unsigned fla
   if (pk) {
     v_syn_fwd.clear();
     v_adj_fwdadj.clear();
-    wav_packed_lists(p, 0, TAB_FWD, -1, 0, v_syn_fwd, &shared);
-    wav_packed_lists(p, 1, TAB_FWD_ADJ, -1, 0, v_adj_fwdadj, nullptr);
+    if ((rc = wav_packed_lists(p, 0, TAB_FWD, -1, 0, v_syn_fwd, &shared))) return rc;
+    if ((rc = wav_packed_lists(p, 1, TAB_FWD_ADJ, -1, 0, v_adj_fwdadj, nullptr))) return rc;
   }
   p->pk = pk;
   if ((rc = upload_tasks(v_syn_fwd, true, &p->syn_fwd, p->bl, p->ncol, p->ws, "synthesis forward (all scales)", el_lo, false, pk, shared))) return rc;
@@ -1453,8 +1460,10 @@ int pxm_wav_ring_step(pxm_wav_plan_t p, const void* X, double w_re, double w_im,
 // harmonic kernel is applied to f_lm directly while the spin-2 inverse GEMM stages its operand.  The adjoint
 // collapses the same way (SHT0^-1 adjoint o SHT0 adjoint = identity).  Results equal the composed operators to
 // round-off; 4 ring GEMMs and 4 DFT stages per forward + adjoint pair instead of 8 and 8.
-int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* weight, int64_t ndata) {
-  PXM_REQUIRE(p, "pxm_wav_wl_attach: null plan");
+// (the resources of the weak-lensing path are committed to the plan one by one; if a later allocation / upload fails the
+// plan is left with e.g. the narrow harmonic side but no twin lists -- pxm_wav_wl_attach marks it `wl_failed` and every
+// weak-lensing entry point, a second attach included, refuses it: destroy the plan)
+static int wl_attach_impl(pxm_wav_plan_t p, const int32_t* pix2data, const double* weight, int64_t ndata) {
   PXM_REQUIRE(p->fused_combine, "pxm_wav_wl_attach: needs the fused wavelet combine (PXM_NO_FUSED_COMBINE is set)");
   PXM_REQUIRE(p->L >= 3, "pxm_wav_wl_attach: Bandlimit must be at least 3 for a spin-2 field");
   const int64_t P = (int64_t)p->L * (2 * p->L - 1);
@@ -1539,8 +1548,8 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
     }
     std::vector<GemmTask> vf, va;
     std::vector<char> shared;
-    wav_packed_lists(p, 0, TAB_FWD, s, p->offGT, vf, &shared, p->ncol_t, p->ncol_h != 0, narrow_g);
-    wav_packed_lists(p, 1, TAB_FWD_ADJ, s, p->offGT, va, nullptr, p->ncol_t, p->ncol_h != 0, narrow_g);
+    if ((rc = wav_packed_lists(p, 0, TAB_FWD, s, p->offGT, vf, &shared, p->ncol_t, p->ncol_h != 0, narrow_g))) return rc;
+    if ((rc = wav_packed_lists(p, 1, TAB_FWD_ADJ, s, p->offGT, va, nullptr, p->ncol_t, p->ncol_h != 0, narrow_g))) return rc;
     if ((rc = upload_tasks(vf, true, &p->wl_syn_fwd, p->bl, p->ncol, p->ws, "weak-lensing synthesis forward (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
     if ((rc = upload_tasks(va, true, &p->wl_adj_fwdadj, p->bl, p->ncol, p->ws, "weak-lensing forward-adjoint (twin scales)", p->el_lo_s, false, p->pk, shared))) return rc;
     p->twin_s = s;
@@ -1551,6 +1560,14 @@ int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* w
   return 0;
 }
 
+int pxm_wav_wl_attach(pxm_wav_plan_t p, const int32_t* pix2data, const double* weight, int64_t ndata) {
+  PXM_REQUIRE(p, "pxm_wav_wl_attach: null plan");
+  PXM_REQUIRE(!p->wl_failed, "pxm_wav_wl_attach: an earlier attach of this plan failed part-way; destroy the plan");
+  const int rc = wl_attach_impl(p, pix2data, weight, ndata);
+  if (rc) p->wl_failed = true;
+  return rc;
+}
+
 int pxm_wav_wl_uses_recursion(pxm_wav_plan_t p) {
   PXM_REQUIRE(p, "pxm_wav_wl_uses_recursion: null plan");
   return p->rec2 ? p->rec2->R * 16 + p->rec2->NC : 0;
@@ -1559,6 +1576,7 @@ int pxm_wav_wl_uses_recursion(pxm_wav_plan_t p) {
 int pxm_wav_wl_forward(pxm_wav_plan_t p, const void* X, void* gamma, int C, pxm_stream_t stream) {
   int rc = wav_check(p, X, gamma, C, "pxm_wav_wl_forward");
   if (rc) return rc;
+  PXM_REQUIRE(!p->wl_failed, "pxm_wav_wl_forward: pxm_wav_wl_attach of this plan failed part-way; destroy the plan");
   PXM_REQUIRE(p->T2 || p->rec2, "pxm_wav_wl_forward: call pxm_wav_wl_attach first");
   hipStream_t st = (hipStream_t)stream;
   const bool twin = p->twin_s >= 0 && C == 1;
@@ -1585,6 +1603,7 @@ int pxm_wav_wl_adjoint(pxm_wav_plan_t p, const void* gamma, const void* data, co
                        void* X_out, int C, pxm_stream_t stream) {
   int rc = wav_check(p, gamma, X_out, C, "pxm_wav_wl_adjoint");
   if (rc) return rc;
+  PXM_REQUIRE(!p->wl_failed, "pxm_wav_wl_adjoint: pxm_wav_wl_attach of this plan failed part-way; destroy the plan");
   PXM_REQUIRE(p->T2 || p->rec2, "pxm_wav_wl_adjoint: call pxm_wav_wl_attach first");
   PXM_REQUIRE((data == nullptr) == (invcov == nullptr), "pxm_wav_wl_adjoint: data and invcov come together");
   PXM_REQUIRE(p->wl_gidx || !p->wl_gw, "pxm_wav_wl_adjoint: a covariance weight needs the pixel -> data map");

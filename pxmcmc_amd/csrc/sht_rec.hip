@@ -632,10 +632,9 @@ static int launch_e2r_nc(const RecTables& T, const RecArgs& a, hipStream_t st, h
 
 template <int R, int NC>
 static int r2e_allow_lds() {  // (dynamic LDS beyond 64 KB has to be allowed per kernel, once)
-  static bool done = false;
-  if (!done) {
+  static std::atomic<uint64_t> seen{0};
+  if (first_on_this_device(seen)) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rec_r2e<R, NC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done = true;
   }
   return 0;
 }

@@ -249,8 +249,10 @@ class PxMCMC:
         """Fail loudly (PxmError) if a kernel reported an expired bounded wait since the last check -- called where the
         sampler synchronises with the device anyway: saved samples, progress prints, end of run (the reference raises
         on bad state, pxmcmc/mcmc.py:104-109; a silently corrupted chain is not an outcome)."""
+        # The status words are LEFT SET: with two samplers in one process each of them sees a latched fault whichever polls
+        # first (a fault is fatal for every chain that ran on the plan; ``plan.status(clear=True)`` is the explicit reset).
         for pl in self._device_plans():
-            pl.raise_on_fault()
+            pl.raise_on_fault(clear=False)
 
     # ---- noise ---------------------------------------------------------------------------
     def _host_noise(self, shape_like):
@@ -665,16 +667,23 @@ class PxMALA(MYULA):
     fuse_tail = True  # totals + Metropolis test of an iteration in pxm_pxmala_finish (False: the separate calls, same numbers)
 
     def __init__(self, forward, prox, mcmcparams=PxMCMCParams(), tune_delta=True, track_transitions=False, max_iter=None,
-                 **kwargs):
+                 lap_every=0, **kwargs):
         super().__init__(forward, prox, mcmcparams, **kwargs)
         self.tune_delta = tune_delta
+        # extension: every ``lap_every`` iterations the loop synchronises the device and appends (iterations done, seconds
+        # since the loop started) to ``laps`` -- the time of any stretch of a long run (e.g. after delta has settled)
+        # without a second run; 0 = never
+        self.lap_every = int(lap_every)
+        self.laps = []
         # extension: stop after this many iterations even if fewer than nsamples were saved (the reference's loop,
         # pxmcmc/mcmc.py:230, only ends on accepted samples: a chain that stops accepting never returns)
         self.max_iter = None if max_iter is None else int(max_iter)
         # extension: keep both calc_logtransition values of every iteration in ``transitions_trace`` (a list of
         # (q(X'|X), q(X|X')) complex128 [C] pairs; the static buffers of a graph replay are read after each replay)
+        # ... and (prior(X'), L2(X')) of every proposal (pxmcmc/mcmc.py:242) in ``proposals_trace``
         self.track_transitions = bool(track_transitions)
         self.transitions_trace = []
+        self.proposals_trace = []
 
     def _l2_dev(self, preds):
         """L2 = vdot(d, invcov @ d) of a [C, ndata] prediction batch -> complex128 [C] (pxmcmc/mcmc.py:78-79)"""
@@ -718,6 +727,7 @@ class PxMALA(MYULA):
         accepted states -- and, with the device Philox stream, is replayed from a captured HIP graph between
         observable events (save candidates, progress prints, trace flushes)."""
         self._prepare()
+        self.laps = []
         self._fused_wav = False  # PxMALA needs gradg and proxf of the proposal separately
         C = self.nchains
         dev = ops.device()
@@ -791,11 +801,13 @@ class PxMALA(MYULA):
                                   u=u, iter_dev=counter, acc_trace=acc_buf, delta_trace=delta_buf, bump=bump,
                                   T=T_dev if T_dev is not None else 0.0, **kw)
                 self._last_transitions = (lt_cp, lt_pc)
+                self._last_proposal = (prior_p, L2_p)
                 ops.select_copy_many(accept, [(Xp, X_curr), (pp.to(curr_preds.dtype), curr_preds), (gp, gradg_curr)])
                 return
             L2p = self._l2_dev(pp)
             ltp = ops.logtransition(Xp, X_curr, pxp, gp, delta_dev, self.lmda)
             self._last_transitions = (ltc, ltp)  # q(X'|X), q(X|X') of this iteration (pxmcmc/mcmc.py:240-241)
+            self._last_proposal = (prp, L2p)
             u = np.array([np.random.rand() for _ in range(C)]) if host_rng else None
             ops.pxmala_accept2(ltp, ltc, prp, L2p, self.mu, logpiXc, L2Xc, priorXc, accept, delta_dev, self.tune_delta,
                                self.lmda, u=u, iter_dev=counter, acc_trace=acc_buf, delta_trace=delta_buf, **kw)
@@ -843,6 +855,7 @@ class PxMALA(MYULA):
                 iteration(i, None)
             if self.track_transitions:  # observation only (synchronises): both calc_logtransition values per iteration
                 self.transitions_trace.append(tuple(t.cpu().numpy().copy() for t in self._last_transitions))
+                self.proposals_trace.append(tuple(t.cpu().numpy().copy() for t in self._last_proposal))
             k = i % self._CHUNK
             if k == self._CHUNK - 1:
                 acc_chunks.append(acc_buf.cpu().numpy().copy())
@@ -858,6 +871,9 @@ class PxMALA(MYULA):
                     self._tracking(j[chains] if C > 1 else int(j[0]), X_curr, curr_preds, logpiXc, L2Xc, priorXc,
                                    chains=chains if C > 1 else None)
                     j[chains] += 1
+            if self.lap_every > 0 and (i + 1) % self.lap_every == 0:
+                torch.cuda.synchronize()
+                self.laps.append((i + 1, time.perf_counter() - t_loop))
             if self.verbosity > 0 and (i + 1) % self.verbosity == 0:
                 pending = 0 if k == self._CHUNK - 1 else int(acc_buf[: k + 1, 0].sum().item())  # rows not yet flushed
                 rate = (n_acc + pending) / (i + 1)

@@ -7,6 +7,7 @@ float64 or complex128; outputs are fresh tensors (the reference never mutates in
 SURVEY.md section 8b).
 """
 import ctypes as C
+import threading
 import weakref
 
 import numpy as np
@@ -423,11 +424,19 @@ class CsrMatrix:
 
 # ---- transform plans -------------------------------------------------------------------
 _LIVE_PLANS = weakref.WeakSet()  # every ShtPlan / WavPlan with a live handle, whoever owns it (prior, user operator, ...)
+_LIVE_LOCK = threading.Lock()     # plans may be created on one thread while a sampler on another polls the registry
+
+
+def _register_plan(plan):
+    with _LIVE_LOCK:
+        _LIVE_PLANS.add(plan)
 
 
 def live_plans():
     """the plans of this process that still hold a device handle: what a sampler polls for expired bounded waits"""
-    return [pl for pl in list(_LIVE_PLANS) if getattr(pl, "_h", None)]
+    with _LIVE_LOCK:
+        plans = list(_LIVE_PLANS)
+    return [pl for pl in plans if getattr(pl, "_h", None)]
 
 
 class ShtPlan:
@@ -440,7 +449,7 @@ class ShtPlan:
         h = C.c_void_p()
         check(lib.pxm_sht_plan_create(self.L, self.spin, self.max_chains, 0, C.byref(h)))
         self._h = h
-        _LIVE_PLANS.add(self)
+        _register_plan(self)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -482,8 +491,8 @@ class ShtPlan:
         """bit mask of the bounded device waits of this plan that expired (0 = none); synchronises"""
         return int(check(lib.pxm_sht_status(self._h, int(bool(clear)), _stream())))
 
-    def raise_on_fault(self):
-        raise_on_status(self.status(clear=True), f"ShtPlan(L={self.L}, spin={self.spin})")
+    def raise_on_fault(self, clear=True):
+        raise_on_status(self.status(clear=clear), f"ShtPlan(L={self.L}, spin={self.spin})")
 
 
 class WavPlan:
@@ -499,7 +508,7 @@ class WavPlan:
         h = C.c_void_p()
         check(lib.pxm_wav_plan_create(self.L, self.B, self.J_min, self.max_chains, 0, C.byref(h)))
         self._h = h
-        _LIVE_PLANS.add(self)
+        _register_plan(self)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -655,9 +664,9 @@ class WavPlan:
         """bit mask of the bounded device waits of this plan that expired (0 = none; include/pxmcmc_amd.h); synchronises"""
         return int(check(lib.pxm_wav_status(self._h, int(bool(clear)), _stream())))
 
-    def raise_on_fault(self):
-        """raise PxmError if a kernel of this plan reported an expired wait since the last check (clears the word)"""
-        raise_on_status(self.status(clear=True), f"WavPlan(L={self.L})")
+    def raise_on_fault(self, clear=True):
+        """raise PxmError if a kernel of this plan reported an expired wait since the last check (``clear``: reset the word)"""
+        raise_on_status(self.status(clear=clear), f"WavPlan(L={self.L})")
 
     # ---- weak-lensing measurement fused with the synthesis (pxm_wav_wl_*) ----
     def wl_attach(self, pix2data, weight, ndata):

@@ -77,11 +77,12 @@ def main():
     res["logpi_X"] = np.array([lp, l2, pr], dtype=complex)
 
     # PxMALA: PX_ITERS iterations from X0 on injected draws; delta_0 = the first candidate whose trace holds accepted AND
-    # rejected proposals (the literal calc_logtransition is ~ delta^3 N^2 here, so the test is L2 / prior driven)
+    # rejected proposals (from this start a step of 1e-11 is accepted throughout -- the gradient step lowers L2 by ~1e5 per
+    # iteration -- and larger steps overshoot; the literal calc_logtransition is ~ delta^3 N^2)
     nz, un = g15.pxmala_draws(g15.PX_ITERS, g15.NCOEFS)
     X0 = d["X0"].astype(complex)
     chosen = None
-    for delta0 in (1e-11, 3e-12, 1e-12, 3e-13, 1e-13, 3e-14):
+    for delta0 in (1e-9, 3e-10, 3e-9, 1e-10, 1e-8, 1e-7):
         out = ref.pxmala_run(oop, oreg, g15.LMDA, delta0, g15.MU, 10 ** 6, 0, 1, X0, lambda i: nz[i], lambda i: un[i],
                              tune=True, max_iter=g15.PX_ITERS)
         acc = out["acceptance_trace"]

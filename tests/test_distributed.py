@@ -241,15 +241,27 @@ def test_bench_timed_region_holds_no_collective():
     no torch.distributed call (barrier, all-reduce, gather) between the two (the chains never cross ranks,
     experiments/earthtopography/main.py:31-36,169: one process per chain)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
-    i0 = src.index("t0 = time.perf_counter()\n    sampler._engine_advance(args.steps)")
-    i1 = src.index("dt_rank = time.perf_counter() - t0")
+    i0 = src.index("t0 = time.perf_counter()\n        sampler._engine_advance(args.steps)")
+    i1 = src.index("dt_r = time.perf_counter() - t0")
     region = [ln.split("#")[0] for ln in src[i0:i1].splitlines()]
     code = "\n".join(region)
-    for banned in ("barrier(", "dist.", "D.", "all_reduce", "max_over_ranks"):
+    banned_calls = ("barrier(", "dist.", "D.", "all_reduce", "max_over_ranks", "all_gather")
+    for banned in banned_calls:
         assert banned not in code, (banned, code)
     assert "torch.cuda.synchronize()" in code
     before = src[:i0].rstrip().splitlines()[-1].strip()
     assert before == "barrier()", before  # the start barrier is the last statement before the clock starts
+    # every timed region of the headline (the literal W + K run and the repeats) goes through that one function
+    assert src.count("sampler._engine_advance(args.steps)") == 1 and src.count("timed_region()") >= 3
+    # BASELINE configs[4] on N ranks: the body a rank times (one PxMALA run with lap stamps) holds no collective either;
+    # the all-gathers of config5_multirank_leg come after it has returned
+    j0, j1 = src.index("def config5_tuned("), src.index("def config5_leg(")
+    body = "\n".join(ln.split("#")[0] for ln in src[j0:j1].splitlines())
+    for banned in banned_calls:
+        assert banned not in body, banned
+    k0, k1 = src.index("def config5_multirank_leg("), src.index("PARITY_TOL =")
+    leg = src[k0:k1]
+    assert leg.index("config5_tuned(") < leg.index("D.all_gather_float(")
 
 
 @pytest.mark.gpu
@@ -263,13 +275,19 @@ def test_bench_gpus2_self_launch_rehearsal(nranks):
     env = dict(os.environ, PXM_BENCH_REHEARSE="1", OMP_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "6", "--warmup", "2", "--ramp", "10"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--steps", "6", "--warmup", "2", "--ramp", "10",
+           "--repeats", "3", "--config5-cap", "400"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-3000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == nranks and out["ranks_seen"] == nranks and out["steps"] == 6 and out["warmup"] == 12
+    assert out["n_gpus"] == nranks and out["ranks_seen"] == nranks and out["steps"] == 6 and out["warmup"] == 2
+    assert out["config"]["untimed_steps_before_headline"] == 2 + 6 + 10 and out["config"]["clock_ramp_steps"] == 10
+    # the headline qualifies itself: the literal W + K run without the ramp, and the timed region repeated (value = median)
+    rep = out["repeats"]
+    assert out["value_no_ramp"] > 0 and rep["n"] == 3 and len(rep["ms_per_step"]) == 3
+    assert rep["value_min"] <= out["value"] <= rep["value_max"] and sorted(rep["ms_per_step"])[1] == out["ms_per_step"]
     assert out["config"]["global_chains"] == 16 * nranks and out["value"] > 0 and out["scaling"] == "weak"
     assert "cpu_baseline" not in out  # the CPU legs run at N = 1 only
     # the clock of a rank stops at its own device synchronise (no collective inside): per-rank times are reported, the
@@ -279,7 +297,16 @@ def test_bench_gpus2_self_launch_rehearsal(nranks):
     assert abs(max(per_rank) - out["ms_per_step"]) <= 1e-9 * out["ms_per_step"]
     assert out["barrier_us"] > 0
     assert abs(out["value"] - 16 * nranks * 1e3 / out["ms_per_step"]) <= 1e-6 * out["value"]
-    assert out["noise_leg"] is None and out["value_f32_noise"] is None and out["configs"] is None  # side legs: N = 1 only
+    assert out["noise_leg"] is None and out["value_f32_noise"] is None  # these side legs: N = 1 only
+    # BASELINE configs[4] ("8 chains on 8 GPUs"): every rank ran its own PxMALA chain at L = 512 after the headline
+    assert list(out["configs"]) == ["configs[4]"]
+    c5 = out["configs"]["configs[4]"]
+    assert "error" not in c5 and c5["ranks_seen"] == nranks and c5["finite"] is True
+    assert len(c5["per_rank_ms_per_iteration"]) == nranks and all(t > 0 for t in c5["per_rank_ms_per_iteration"])
+    assert c5["ms_per_iteration"] == max(c5["per_rank_ms_per_iteration"])
+    assert abs(c5["samples_per_s"] - nranks * 1e3 / c5["ms_per_iteration"]) <= 1e-9 * c5["samples_per_s"]
+    assert len(c5["per_rank_acceptance"]) == nranks and len(c5["per_rank_delta"]) == nranks
+    assert c5["iterations_run"] == 400 and c5["per_rank_tuned"] == [False] * nranks  # (400 iterations: delta_0 still rejected)
     assert out["config"]["noise_bits"] == 64 and out["value_f64_noise"] == out["value"]  # headline = the fp64 noise stream
     assert out["legs_ok"] is True and out["leg_failures"] == []
 

@@ -68,6 +68,10 @@ def test_box_muller_edge_cases_both_precisions():
     assert (np.abs(z1 - want1) <= tol).all(), (np.abs(z1 - want1) / tol).max()
     assert np.abs(z0[U1 == 1.0]).max() < 1e-100 and np.abs(z1[U1 == 1.0]).max() < 1e-100
     assert abs(np.hypot(z0, z1)[U1 == tiny].max() - np.sqrt(-2 * np.log(tiny))) < 1e-13  # 8.6 sigma reachable
+    # outside the stream's range (0, 1] -- a caller of the test entry point can pass anything: the table index is clamped
+    # (round-5 advisor: j - 128 < 0 read in front of the table); the values are garbage by contract, the reads stay in range
+    for bad in (0.0, np.nan, np.inf, -1.0, 5e-324):
+        ops.box_muller(np.full(64, bad), np.linspace(0.0, 1.0, 64), noise64=True)
     f0, f1 = [_np(z) for z in ops.box_muller(U1, U2, noise64=False)]
     assert np.isfinite(f0).all() and np.isfinite(f1).all()
     tol = 3e-6 * np.maximum(rad, 1)
@@ -228,6 +232,11 @@ def test_pair_sync_expiry_is_reported_not_silent(monkeypatch):
         with pytest.raises(PxmError, match="wave-pair wait"):
             _quiet(s.run, start_point=np.zeros(op.nparams))
     assert good.status() == 0  # the word is per plan
+    # the samplers leave a latched word set (every sampler of the process must see it): the explicit reset
+    assert any(pl.status() for pl in ops.live_plans())
+    for pl in ops.live_plans():
+        pl.status(clear=True)
+    assert not any(pl.status() for pl in ops.live_plans())
 
 
 def test_dataflow_launch_is_really_taken(monkeypatch):

@@ -237,3 +237,23 @@ def test_address_range_check_refuses_short_buffers(spec, what, expect, monkeypat
     assert expect in msg, msg
     monkeypatch.delenv("PXM_RANGE_SELFTEST")
     assert lib.pxm_host_check_address_ranges(64, 2.0, 2, 0, 3, what) > 0  # and nothing of the failed plan lingers
+
+
+def test_bench_tuned_iteration_window_rule():
+    """bench.py's rule for "delta has been tuned" on a PxMALA acceptance trace (pxmcmc/mcmc.py:254-260): the first lap at
+    which the acceptance over the last 200 iterations is inside [0.3, 0.7], with room for the timed stretch behind it"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod_t", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    acc = np.zeros(3000)
+    acc[1000:] = np.tile([1, 0], 1000)                      # rejected throughout, then every second proposal accepted
+    n, a, ok = bench.tuned_iteration(acc, window=200, lap=50, timed=150)
+    assert ok and n == 1150 and abs(a - 0.375) < 1e-12       # 150 of the last 200 iterations at rate 0.5 -> 0.375 >= 0.3
+    n, a, ok = bench.tuned_iteration(np.zeros(1000), window=200, lap=50, timed=150)
+    assert not ok and n == 850 and a == 0.0                  # never tuned: the last stretch that fits, flagged
+    n, a, ok = bench.tuned_iteration(np.ones(400), window=200, lap=50, timed=150)
+    assert not ok and n == 250 and a == 1.0
+    n, a, ok = bench.tuned_iteration(np.tile([1, 0], 300), window=200, lap=50, timed=150)
+    assert ok and n == 200 and a == 0.5                      # tuned from the start: the first full window
