@@ -31,6 +31,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 // timing-only ablations for DESIGN.md (wrong results): 1 no Philox, 2 no table loads, 4 no LDS transposes, 8 no ring stores
@@ -90,6 +91,7 @@ struct Dft5Group {
   int xs;            // ring sets (workgroups along the rings) per 128-B line of the ring array: > 1 on narrow arrays
   int64_t tbase;     // the scale's table allocation as an offset (doubles) from the workspace base ...
   int toff[7];       // ... and cE, cO, dO, tw1, wt, bE, bO inside it (doubles)
+  int pfa_off;       // r0 == 9 (exact-length body, n = 511): the PFA table block inside the allocation (doubles)
 };
 
 // Workgroup barrier of these kernels: every exchange between waves goes through LDS, so only the LDS counter has to
@@ -657,6 +659,229 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
 #endif
 }
 
+
+// =============================================================================================================
+// Exact-length path for n = 511 (bandlimit 256): ONE wave per ring unit, Good-Thomas 7 x 73 + Rader over 8 x 9 (dft_pfa.h).
+// Workgroup = 8 waves = 2 rings x 4 chain slots; the rings are staged in LDS like above (64-B segments of the ring
+// arrays), every transpose of the transform is local to a wave.  Only the fused rings -> X' -> rings launch takes this
+// body (RING_OUT); PXM_DFT_PFA=0 at plan creation keeps the Bluestein unit for A/B runs and the variant tests.
+// =============================================================================================================
+}  // namespace pxm
+#include "dft_pfa.h"
+namespace pxm {
+
+struct PfaTabs {
+  const uint16_t* gat;   // [64][8]  byte offset (16 k) of element k = gat(lane, q8) of the S1 layout
+  const uint16_t* kidx;  // [80][8]  byte offset (16 k) of output k(instance, k1), rows 0..72
+  const double2* B2;     // [8][9]
+};
+
+#define PXM_PFA_SLOT(RING, K, CH) ((((RING)*PFA_N + (K)) << 2) + (CH))
+
+template <bool N64>
+__device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTabs& pt, double* __restrict__ G, int ncol,
+                                                 const PxOut& out, int C, int bx, int by, double2* lds5) {
+  if ((by << 2) >= C) return;
+  constexpr int n = PFA_N, R = 4, TRS = 2;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int r = wave & 3, trs = wave >> 2;  // chain slot and ring of the workgroup: one unit per wave
+  const int t = bx * TRS + trs;
+  const int c0 = by * R, ch = c0 + r;
+  const bool tv = t < a.L;
+  const int Cp = ncol >> 1;
+  double2* stage = lds5;
+  double2* plane = lds5 + wave * PFA_PLANE;
+  double2* B2l = lds5 + 8 * PFA_PLANE;
+  if (threadIdx.x < 72) B2l[threadIdx.x] = pt.B2[threadIdx.x];
+  // (the per-lane index tables -- byte offsets, 8 x u16 per row, L1-resident -- are re-read where they are used instead of
+  // living in 12 registers across the epilogue)
+  const int j1m = lane >> 3;
+  const int x0k = (73 * (j1m < 7 ? j1m : 6)) % n;  // element j2 = 0 of the lane's S2 ring role
+  const int mstride = a.Rp * Cp;                    // complex elements between consecutive m
+  {  // rings of the workgroup -> stage (conjugated: inverse DFT by conjugation); thread -> (chain rr, k)
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> 2, kstep = 128;
+    const double2* Gc = reinterpret_cast<const double2*>(G) + c0 + rr;
+    const bool cv = c0 + rr < Cp;
+#pragma nounroll
+    for (int kb = kq; kb < n; kb += 2 * kstep) {
+      double2 v[TRS][2];
+#pragma unroll
+      for (int ru = 0; ru < TRS; ++ru) {
+        const int tt = bx * TRS + ru;
+        const bool rv = cv && tt < a.L;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = kb + u * kstep;
+          v[ru][u] = double2{0.0, 0.0};
+          if (rv && k < n) v[ru][u] = Gc[((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + tt * Cp];
+        }
+      }
+#pragma unroll
+      for (int ru = 0; ru < TRS; ++ru)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int k = kb + u * kstep;
+          if (k < n) stage[PXM_PFA_SLOT(ru, k, rr)] = double2{v[ru][u].x, -v[ru][u].y};
+        }
+    }
+  }
+  d5_barrier();  // (also: the LDS copy of the filter spectrum is complete)
+  double2 z[8], o1[7], o2[7];
+  double2 x0;
+  {
+    const char* sb = reinterpret_cast<const char*>(stage + PXM_PFA_SLOT(trs, 0, r));
+    const uint4 gv = reinterpret_cast<const uint4*>(pt.gat)[lane];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) z[q] = *reinterpret_cast<const double2*>(sb + 4 * pfa_u16(gv, q));
+    x0 = *reinterpret_cast<const double2*>(sb + 64 * x0k);
+  }
+  d5_barrier();  // the stage is dead: the planes may be written
+  pfa511_core(z, x0, o1, o2, plane, B2l, lane);
+  // natural order in the plane: slot k = y[k]
+  {
+    char* pb_ = reinterpret_cast<char*>(plane);
+    const uint4 kv1 = reinterpret_cast<const uint4*>(pt.kidx)[lane];
+    const uint4 kv2 = reinterpret_cast<const uint4*>(pt.kidx)[64 + (lane < 9 ? lane : 8)];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) D5_PW(*reinterpret_cast<double2*>(pb_ + pfa_u16(kv1, k)), o1[k]);
+    if (lane < 9) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) D5_PW(*reinterpret_cast<double2*>(pb_ + pfa_u16(kv2, k)), o2[k]);
+    }
+    d5_wave_sync();
+  }
+  // The lane's eight elements lane + 64 p go through the epilogue FOUR at a time, from the plane and back into it (the
+  // natural-order plane is the input of the second transform's gather): never more than four elements in registers
+  // beside the epilogue's operands, as in the Bluestein body.
+  const bool act = ch < C && tv;
+  const int64_t e0 = out.ring0 + (int64_t)t * n + lane;  // the lane's first element; p advances by 64
+  const int64_t ce0 = (int64_t)ch * out.chain_stride + e0;
+  const bool last_ok = lane < 63;                        // element lane + 448 exists
+  const uint64_t it_eff = out.iter + (out.iter_dev ? *out.iter_dev : 0);
+  const int ch_s = __builtin_amdgcn_readfirstlane(ch);
+#pragma unroll
+  for (int g0 = 0; g0 < 8; g0 += 4) {
+    double2 x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) D5_PR(x[u], plane[lane + 64 * (g0 + u)]);  // (lane 63, p = 7: slot 511, never an element)
+    if (act && out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50); see ring2px_body5
+      double2 xs[4], wn[4], wph[4];
+      double Ts[4];
+      int64_t eo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // Philox + Box-Muller ahead of the operand loads
+        wph[u] = double2{0.0, 0.0};
+        if (!out.noise) wph[u] = px_noise_philox_t<N64>(out, ch_s, e0 + 64 * (g0 + u), it_eff);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) eo[u] = (g0 + u < 7 || last_ok) ? (int64_t)64 * (g0 + u) : -(int64_t)lane;  // (else: the ring's element 0)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xs[u] = reinterpret_cast<const double2*>(out.X)[ce0 + eo[u]];
+      if (out.T) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Ts[u] = out.T[e0 + eo[u]];
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Ts[u] = out.T_scalar;
+      }
+      if (out.noise) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wn[u] = px_noise_load(out, ch, e0 + eo[u]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wn[u] = double2{0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = g0 + u;
+        if (p == 7 && !last_ok) {
+          x[u] = double2{0.0, 0.0};
+          continue;
+        }
+        const double2 y{x[u].x, -x[u].y};
+        const double2 w = out.noise ? wn[u] : wph[u];
+        x[u] = px_update(out, xs[u], Ts[u], y, w);
+        reinterpret_cast<double2*>(out.f)[ce0 + 64 * p] = x[u];
+      }
+    } else if (act) {  // plain / gathered output and the residual that goes back to the rings
+      bool ok[4];
+      int64_t ev[4];
+      double2 yv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ok[u] = g0 + u < 7 || last_ok;
+        ev[u] = ok[u] ? e0 + 64 * (g0 + u) : out.ring0 + (int64_t)t * n;
+        yv[u] = double2{x[u].x, -x[u].y};
+      }
+      px_out_store_n<4>(out, ch, ev, yv, ok);
+      if (out.rdata) {
+        double2 rd[4], rc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rd[u] = reinterpret_cast<const double2*>(out.rdata)[ev[u]];
+        if (out.rinvcov_complex) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) rc[u] = reinterpret_cast<const double2*>(out.rinvcov)[ev[u]];
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) rc[u] = double2{out.rinvcov[ev[u]], 0.0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double2 d = csub(yv[u], rd[u]);
+          yv[u] = out.rinvcov_complex ? cmul(rc[u], d) : double2{rc[u].x * d.x, rc[u].x * d.y};
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = ok[u] ? yv[u] : double2{0.0, 0.0};
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = double2{0.0, 0.0};  // padding chains / rings: their rings are kept at zero
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) D5_PW(plane[lane + 64 * (g0 + u)], x[u]);
+  }
+  // ---- forward transform of the updated ring: natural order -> S1 layout through the plane
+  d5_wave_sync();
+  {
+    const char* pb_ = reinterpret_cast<const char*>(plane);
+    const uint4 gv = reinterpret_cast<const uint4*>(pt.gat)[lane];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) D5_PR(z[q], *reinterpret_cast<const double2*>(pb_ + pfa_u16(gv, q)));
+    D5_PR(x0, plane[x0k]);
+  }
+  d5_wave_sync();
+  pfa511_core(z, x0, o1, o2, plane, B2l, lane);
+  d5_barrier();  // every plane of the workgroup is dead: the stage may be written
+  {
+    char* sb = reinterpret_cast<char*>(stage + PXM_PFA_SLOT(trs, 0, r));
+    const uint4 kv1 = reinterpret_cast<const uint4*>(pt.kidx)[lane];
+    const uint4 kv2 = reinterpret_cast<const uint4*>(pt.kidx)[64 + (lane < 9 ? lane : 8)];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) *reinterpret_cast<double2*>(sb + 4 * pfa_u16(kv1, k)) = o1[k];
+    if (lane < 9) {
+#pragma unroll
+      for (int k = 0; k < 7; ++k) *reinterpret_cast<double2*>(sb + 4 * pfa_u16(kv2, k)) = o2[k];
+    }
+  }
+  d5_barrier();
+  {  // stage -> G rows of both rings
+    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> 2, kstep = 128;
+    double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;
+    if (c0 + rr < Cp) {
+#pragma nounroll
+      for (int trr = 0; trr < TRS; ++trr) {
+        const int tt = bx * TRS + trr;
+        if (tt >= a.L) break;
+        for (int k = kq; k < n; k += kstep) {
+          const int mi = (k < a.L) ? k + a.L - 1 : k - a.L;
+          Gc[mi * mstride + tt * Cp] = stage[PXM_PFA_SLOT(trr, k, rr)];
+        }
+      }
+    }
+  }
+}
+
 template <int R0>
 __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_px2ring5(Dft5Args a, PxIn in, double* __restrict__ G,
                                                                                  int ncol, int C) {
@@ -731,6 +956,15 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5G
     for (int i = threadIdx.x; i < n_zero; i += 512) zero_words[i] = 0;
   PXM_D5_GROUP_DECODE
   out.ring0 = g.ring0;
+  if constexpr (RING_OUT) {
+   if (g.r0 == 9) {  // exact-length unit (entries of the fused launch's own list only)
+    const double* pb = ws + g.tbase + g.pfa_off;
+    const PfaTabs pt{reinterpret_cast<const uint16_t*>(pb + PFA_TAB_GAT), reinterpret_cast<const uint16_t*>(pb + PFA_TAB_KIDX),
+                     reinterpret_cast<const double2*>(pb + PFA_TAB_B2)};
+    ring2px_body_pfa<N64>(a, pt, G, ncol, out, C, bx, by, lds5);
+    return;
+   }
+  }
   switch (g.r0) {
     case 8: ring2px_body5<8, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
     case 4: ring2px_body5<4, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
@@ -1093,6 +1327,40 @@ int dft5_make_tables(int n, Dft5Tables* t) {
     for (int k0 = 0; k0 < r0; ++k0)
       for (int lane = 0; lane < 64; ++lane) put(bhat[2 * ((lane >> 3) + 8 * (lane & 7) + 64 * k0) + w]);
   }
+  // n = 511: the tables of the exact-length unit (dft_pfa.h, scripts/dev/proto_pfa511.py) behind the Bluestein ones
+  size_t o_pfa = 0;
+  if (n == PFA_N && !(getenv("PXM_DFT_PFA") && atoi(getenv("PXM_DFT_PFA")) == 0)) {
+    o_pfa = h.size();
+    const int N2 = 73, g = 5;  // 5 generates (Z / 73)^*
+    auto powm = [&](long long b, int e) { long long r_ = 1; for (int i = 0; i < e; ++i) r_ = r_ * b % N2; return (int)r_; };
+    const int ginv = powm(g, 71);  // g^-1 = g^(phi - 1)
+    auto crt72 = [](int q8, int q9) { return (9 * q8 + 64 * q9) % 72; };
+    std::vector<uint16_t> idx((size_t)(64 + 80) * 8, 0);
+    for (int l = 0; l < 63; ++l)      // S1: lane (j1, q9), register q8 -> element (73 j1 + 7 g^-q) mod 511, q = CRT(q8, q9)
+      for (int q8 = 0; q8 < 8; ++q8) idx[(size_t)l * 8 + q8] = (uint16_t)(16 * ((73 * (l / 9) + 7 * powm(ginv, crt72(q8, l % 9))) % n));
+    // (lane 63 is idle in S1: its eight entries stay 0 -- element 0, a valid address)
+    for (int inst = 0; inst < 73; ++inst) {  // S4: instance p9 + 9 p8 holds k2 = g^CRT(p8, p9), instance 72 holds k2 = 0
+      const int k2 = inst < 72 ? powm(g, crt72(inst / 9, inst % 9)) : 0;
+      for (int k1 = 0; k1 < 7; ++k1) idx[(size_t)(64 + inst) * 8 + k1] = (uint16_t)(16 * ((365 * k1 + 147 * k2) % n));
+    }
+    const size_t nd = idx.size() * sizeof(uint16_t) / sizeof(double);
+    h.resize(h.size() + nd);
+    std::memcpy(h.data() + o_pfa, idx.data(), idx.size() * sizeof(uint16_t));
+    // B2[k8][k9] = (1 / 72) sum_(q8, q9) b[CRT(q8, q9)] W_8^(q8 k8) W_9^(q9 k9),  b[r] = W_73^(g^r)
+    for (int k8 = 0; k8 < 8; ++k8)
+      for (int k9 = 0; k9 < 9; ++k9) {
+        cld acc(0, 0);
+        for (int q8 = 0; q8 < 8; ++q8)
+          for (int q9 = 0; q9 < 9; ++q9)
+            acc += ang(2.0L * powm(g, crt72(q8, q9)), N2) * ang(2.0L * ((q8 * k8) % 8), 8) * ang(2.0L * ((q9 * k9) % 9), 9);
+        put(acc / 72.0L);
+      }
+    if (h.size() - o_pfa != (size_t)PFA_TAB_DOUBLES) {
+      set_error("dft5_make_tables: the PFA table block has an unexpected size");
+      return -1;
+    }
+  }
+  t->pfa_off = (int)o_pfa;
   if (int rc = dev_alloc(&t->d_all, h.size() * sizeof(double), "phi-DFT tables (8 points per lane)")) return rc;
   if (int rc = dev_upload(t->d_all, h.data(), h.size() * sizeof(double))) return rc;
   t->bytes = h.size() * sizeof(double);
@@ -1193,9 +1461,10 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
     if (plans[i]->use5) order.push_back((int)i);
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return plans[x]->L > plans[y]->L; });
   if (order.size() < 2) return 1;
-  std::vector<Dft5Group> v;
+  std::vector<Dft5Group> v, vf;
   out->member.assign(plans.size(), 0);
-  int b0 = 0;
+  int b0 = 0, b0f = 0;
+  bool any_pfa = false;
   size_t lds = 0;
   for (int s : order) {
     const DftPlan& p = *plans[s];
@@ -1215,12 +1484,26 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
       const int per_line = 16 / ncol;  // rings per 128-B line: 8 for one complex slot per entry, 4 for two, < 2 otherwise
       g.xs = (g.nby == 1 && per_line > rings && per_line % rings == 0) ? per_line / rings : 1;
     }
+    g.pfa_off = 0;
     g.b0 = b0;
     b0 += round_up(g.nbx, 8) * g.nby;  // (padded so that every scale starts on an XCD-label boundary)
     lds = std::max(lds, p.lds5);
     out->px_elems += (double)p.L * p.n;
     out->member[s] = 1;
     v.push_back(g);
+    // the fused launch's entry of the same scale: n = 511 takes the exact-length body (one wave per ring unit: two rings
+    // x four chain slots per workgroup, half the workgroups)
+    Dft5Group f = g;
+    if (p.t5.pfa_off && p.R5 == 4) {
+      any_pfa = true;
+      f.r0 = 9;
+      f.pfa_off = p.t5.pfa_off;
+      f.nbx = (p.L + 1) / 2;
+      f.xs = 1;
+    }
+    f.b0 = b0f;
+    b0f += round_up(f.nbx, 8) * f.nby;
+    vf.push_back(f);
   }
   if (v.size() < 2) {
     out->member.clear();
@@ -1254,6 +1537,14 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
         }
       }
       out->ring_end = std::max(out->ring_end, g.ring0 + (int64_t)g.a.L * g.a.n);
+      if (vf[i].r0 == 9) {  // the table block of the exact-length body
+        ++nchk;
+        const double* tb = ws_base + g.tbase + vf[i].pfa_off;
+        if (!dev_range_ok(tb, tb + PFA_TAB_DOUBLES, &why)) {
+          set_error("DFT group entry " + std::to_string(i) + ": PFA table block outside its buffer: " + why);
+          return -1;
+        }
+      }
     }
     ranges_checked_add(nchk);
   }
@@ -1265,6 +1556,15 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
   out->threads = 128 * plans[order[0]]->R5;
   if (int rc = dev_alloc(&out->d, v.size() * sizeof(Dft5Group), "DFT group entries")) return rc;
   if (int rc = dev_upload(out->d, v.data(), v.size() * sizeof(Dft5Group))) return rc;
+  if (any_pfa) {
+    // LDS of the exact-length body: 8 planes of PFA_PLANE slots (aliased by the stage of 2 rings x 511 x 4 slots) + the filter
+    // spectrum: 74 880 B, inside the 81 920 B of the Bluestein workgroups (two workgroups per CU either way)
+    static_assert((size_t)8 * PFA_PLANE * 16 + 72 * 16 <= (size_t)2 * D5_RMAX * D5_PLANE * 16 + (size_t)D5_TW * 16, "PFA workgroup LDS");
+    static_assert(2 * PFA_N * 4 <= 8 * PFA_PLANE, "the stage of two rings fits in the planes");
+    if (int rc = dev_alloc(&out->d_fused, vf.size() * sizeof(Dft5Group), "DFT group entries (fused launch)")) return rc;
+    if (int rc = dev_upload(out->d_fused, vf.data(), vf.size() * sizeof(Dft5Group))) return rc;
+    out->blocks_fused = b0f;
+  }
   static bool attr = false;
   if (!attr && !dry_run()) {
     PXM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>((k_ring2px_group5<true, false>)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1279,7 +1579,9 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
 
 void dft_group_destroy(DftGroupList* g) {
   if (g->d) deferred_free(g->d);
-  g->d = nullptr;
+  if (g->d_fused) deferred_free(g->d_fused);
+  g->d = g->d_fused = nullptr;
+  g->blocks_fused = 0;
   g->n = 0;
 }
 
@@ -1291,12 +1593,14 @@ int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& 
   const double bytes = g.px_elems * (2.0 * 16 * (ncol / 2) + 2.0 * 16 * C + (out.T ? 8.0 : 0.0));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (prof) prof->next(prof->dft, &ev0, &ev1, bytes, 0.0);
+  const Dft5Group* ents = reinterpret_cast<const Dft5Group*>(g.d_fused ? g.d_fused : g.d);
+  const int blocks = g.d_fused ? g.blocks_fused : g.blocks;
   if (out.X && !out.noise && out.noise64)
-    hipExtLaunchKernelGGL((k_ring2px_group5<true, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
-                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero);
+    hipExtLaunchKernelGGL((k_ring2px_group5<true, true>), dim3(blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
+                          ents, g.n, ws, ncol, out, C, zero_words, n_zero);
   else
-    hipExtLaunchKernelGGL((k_ring2px_group5<true, false>), dim3(g.blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
-                          reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, zero_words, n_zero);
+    hipExtLaunchKernelGGL((k_ring2px_group5<true, false>), dim3(blocks), dim3(g.threads), g.lds, st, ev0, ev1, 0,
+                          ents, g.n, ws, ncol, out, C, zero_words, n_zero);
   PXM_HIP(hipGetLastError());
   return 0;
 }

@@ -199,6 +199,7 @@ struct Dft5Tables {
   double* d_all = nullptr;
   size_t bytes = 0;
   int r0 = 0;  // Mh / 64
+  int pfa_off = 0;  // n = 511: the table block of the exact-length unit inside the allocation (doubles), 0 = none
   const double *cE = nullptr, *cO = nullptr, *dO = nullptr, *tw1 = nullptr, *wt = nullptr, *bE = nullptr, *bO = nullptr;
 };
 
@@ -274,6 +275,10 @@ struct PxOut {  // ring2px output: plain image, or the fused MYULA update of a c
 // grouped launches of a wavelet plan's member scales (dft5.hip): one grid for every scale
 struct DftGroupList {
   void* d = nullptr;  // device array of per-scale descriptors
+  // the fused rings -> X' -> rings launch's own descriptors when a member scale takes the exact-length body (n = 511:
+  // two rings per workgroup, other block counts); null = the list above
+  void* d_fused = nullptr;
+  int blocks_fused = 0;
   bool five = false;  // descriptors of the eight-points-per-lane kernel (dft5.hip)
   int threads = 512;  // ... and its workgroup size
   int n = 0, blocks = 0;
