@@ -92,6 +92,7 @@ struct Dft5Group {
   int64_t tbase;     // the scale's table allocation as an offset (doubles) from the workspace base ...
   int toff[7];       // ... and cE, cO, dO, tw1, wt, bE, bO inside it (doubles)
   int pfa_off;       // r0 == 9 (exact-length body, n = 511): the PFA table block inside the allocation (doubles)
+  int pfa_passes;    // ... and the ring pairs a workgroup of that body handles one after the other (1 or 2)
 };
 
 // Workgroup barrier of these kernels: every exchange between waves goes through LDS, so only the LDS counter has to
@@ -461,7 +462,7 @@ __device__ __forceinline__ void px2ring_body5(const Dft5Args& a, const PxIn& in,
 // again and its rings go back IN PLACE over G (rings of S X -> X' and the rings of X' in one kernel).
 #ifdef PXM_D5_TRACE
 __device__ unsigned long long* g_dft_trace = nullptr;
-#define PXM_D5_STAMP(K) d5_stamp[K] = wall_clock64();
+#define PXM_D5_STAMP(K) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); d5_stamp[K] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); }
 #else
 #define PXM_D5_STAMP(K)
 #endif
@@ -676,14 +677,27 @@ struct PfaTabs {
   const double2* B2;     // [8][9]
 };
 
-#define PXM_PFA_SLOT(RING, K, CH) ((((RING)*PFA_N + (K)) << 2) + (CH))
+// stage of the exact-length body: [ring][chain slot][k], rows of 514 slots.  The units gather / scatter pseudo-random k of ONE
+// chain slot: with the chain innermost (slot 4 k + r, as in the Bluestein bodies) a wave would touch 4 of the 16 bank groups
+// only (190 / 329 instead of ~94 / ~157 LDS cycles per gather / scatter, scripts/dev/proto_pfa511.py); 514 = 2 mod 8 keeps
+// the cooperative fill (thread -> (chain, k): 4 chains x 2 k per group of eight lanes) free of write conflicts.
+constexpr int PFA_STAGE_S = 514;
+#define PXM_PFA_SLOT(RING, K, CH) (((((RING) << 2) + (CH)) * PFA_STAGE_S) + (K))
 
 template <bool N64>
 __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTabs& pt, double* __restrict__ G, int ncol,
                                                  const PxOut& out, int C, int bx, int by, double2* lds5) {
   if ((by << 2) >= C) return;
+#ifdef PXM_D5_TRACE
+  unsigned long long d5_stamp[7] = {0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long d5_t0 = wall_clock64();
+#endif
   constexpr int n = PFA_N, R = 4, TRS = 2;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  // (the body may run twice per workgroup: the opaque copy keeps everything derived from the thread id INSIDE a pass -- hoisted
+  // out of the pass loop these values cost 20 spilled registers at the 128-VGPR budget)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = wave & 3, trs = wave >> 2;  // chain slot and ring of the workgroup: one unit per wave
   const int t = bx * TRS + trs;
   const int c0 = by * R, ch = c0 + r;
@@ -692,14 +706,22 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
   double2* stage = lds5;
   double2* plane = lds5 + wave * PFA_PLANE;
   double2* B2l = lds5 + 8 * PFA_PLANE;
-  if (threadIdx.x < 72) B2l[threadIdx.x] = pt.B2[threadIdx.x];
+  if (tid < 72) B2l[tid] = pt.B2[tid];
+  // fp64 noise: LDS copies of the two Box-Muller tables (129 + 256 entries behind the filter spectrum: 81 040 B per workgroup)
+  const double2* const logt = B2l + 72;
+  const double2* const sct = B2l + 72 + NOISE_LOG_N;
+#if !defined(PXM_NOISE_F64_POLY)
+  if (N64 && out.X && !out.noise && tid < NOISE_LOG_N + 256)  // (385 entries, 512 threads)
+    B2l[72 + tid] = tid < NOISE_LOG_N ? reinterpret_cast<const double2*>(&NOISE_LOG_TAB[0][0])[tid]
+                                      : reinterpret_cast<const double2*>(&NOISE_SINCOS_TAB[0][0])[tid - NOISE_LOG_N];
+#endif
   // (the per-lane index tables -- byte offsets, 8 x u16 per row, L1-resident -- are re-read where they are used instead of
   // living in 12 registers across the epilogue)
   const int j1m = lane >> 3;
   const int x0k = (73 * (j1m < 7 ? j1m : 6)) % n;  // element j2 = 0 of the lane's S2 ring role
   const int mstride = a.Rp * Cp;                    // complex elements between consecutive m
   {  // rings of the workgroup -> stage (conjugated: inverse DFT by conjugation); thread -> (chain rr, k)
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> 2, kstep = 128;
+    const int rr = tid & (R - 1), kq = tid >> 2, kstep = 128;
     const double2* Gc = reinterpret_cast<const double2*>(G) + c0 + rr;
     const bool cv = c0 + rr < Cp;
 #pragma nounroll
@@ -726,17 +748,20 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
     }
   }
   d5_barrier();  // (also: the LDS copy of the filter spectrum is complete)
+  PXM_D5_STAMP(0)  // rings staged
   double2 z[8], o1[7], o2[7];
   double2 x0;
   {
     const char* sb = reinterpret_cast<const char*>(stage + PXM_PFA_SLOT(trs, 0, r));
     const uint4 gv = reinterpret_cast<const uint4*>(pt.gat)[lane];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) z[q] = *reinterpret_cast<const double2*>(sb + 4 * pfa_u16(gv, q));
-    x0 = *reinterpret_cast<const double2*>(sb + 64 * x0k);
+    for (int q = 0; q < 8; ++q) z[q] = *reinterpret_cast<const double2*>(sb + pfa_u16(gv, q));
+    x0 = *reinterpret_cast<const double2*>(sb + 16 * x0k);
   }
   d5_barrier();  // the stage is dead: the planes may be written
+  PXM_D5_STAMP(1)  // unit gathered
   pfa511_core(z, x0, o1, o2, plane, B2l, lane);
+  PXM_D5_STAMP(2)  // inverse transform done
   // natural order in the plane: slot k = y[k]
   {
     char* pb_ = reinterpret_cast<char*>(plane);
@@ -768,12 +793,9 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
       double2 xs[4], wn[4], wph[4];
       double Ts[4];
       int64_t eo[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {  // Philox + Box-Muller ahead of the operand loads
-        wph[u] = double2{0.0, 0.0};
-        if (!out.noise) wph[u] = px_noise_philox_t<N64>(out, ch_s, e0 + 64 * (g0 + u), it_eff);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+      // operand loads FIRST, the noise of the four elements while they are in flight (this body holds four elements, not
+      // eight, beside the epilogue's operands: the fp64 Box-Muller fits between the loads and their use without spills --
+      // in ring2px_body5 that order cost 250 spilled registers)
 #pragma unroll
       for (int u = 0; u < 4; ++u) eo[u] = (g0 + u < 7 || last_ok) ? (int64_t)64 * (g0 + u) : -(int64_t)lane;  // (else: the ring's element 0)
 #pragma unroll
@@ -791,6 +813,20 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
       } else {
 #pragma unroll
         for (int u = 0; u < 4; ++u) wn[u] = double2{0.0, 0.0};
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        wph[u] = double2{0.0, 0.0};
+#if !(PXM_D5_ABLATE & 1)
+#if defined(PXM_NOISE_F64_POLY)
+        if (!out.noise) wph[u] = px_noise_philox_t<N64>(out, ch_s, e0 + 64 * (g0 + u), it_eff);
+#else
+        if (!out.noise) wph[u] = N64 ? px_noise_philox_tabs(out, ch_s, e0 + 64 * (g0 + u), it_eff, logt, sct)
+                                     : px_noise_philox_t<false>(out, ch_s, e0 + 64 * (g0 + u), it_eff);
+#endif
+#endif
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -840,6 +876,9 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) D5_PW(plane[lane + 64 * (g0 + u)], x[u]);
+#ifdef PXM_D5_TRACE
+    if (g0 == 0) PXM_D5_STAMP(3) else PXM_D5_STAMP(4)  // first / second half of the epilogue done
+#endif
   }
   // ---- forward transform of the updated ring: natural order -> S1 layout through the plane
   d5_wave_sync();
@@ -852,21 +891,23 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
   }
   d5_wave_sync();
   pfa511_core(z, x0, o1, o2, plane, B2l, lane);
+  PXM_D5_STAMP(5)  // forward transform done
   d5_barrier();  // every plane of the workgroup is dead: the stage may be written
   {
     char* sb = reinterpret_cast<char*>(stage + PXM_PFA_SLOT(trs, 0, r));
     const uint4 kv1 = reinterpret_cast<const uint4*>(pt.kidx)[lane];
     const uint4 kv2 = reinterpret_cast<const uint4*>(pt.kidx)[64 + (lane < 9 ? lane : 8)];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) *reinterpret_cast<double2*>(sb + 4 * pfa_u16(kv1, k)) = o1[k];
+    for (int k = 0; k < 7; ++k) *reinterpret_cast<double2*>(sb + pfa_u16(kv1, k)) = o1[k];
     if (lane < 9) {
 #pragma unroll
-      for (int k = 0; k < 7; ++k) *reinterpret_cast<double2*>(sb + 4 * pfa_u16(kv2, k)) = o2[k];
+      for (int k = 0; k < 7; ++k) *reinterpret_cast<double2*>(sb + pfa_u16(kv2, k)) = o2[k];
     }
   }
   d5_barrier();
+  PXM_D5_STAMP(6)  // results in the stage
   {  // stage -> G rows of both rings
-    const int rr = threadIdx.x & (R - 1), kq = threadIdx.x >> 2, kstep = 128;
+    const int rr = tid & (R - 1), kq = tid >> 2, kstep = 128;
     double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;
     if (c0 + rr < Cp) {
 #pragma nounroll
@@ -880,6 +921,16 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
       }
     }
   }
+#ifdef PXM_D5_TRACE
+  d5_barrier();
+  if (tid == 0 && g_dft_trace) {
+    const unsigned long long slot = atomicAdd(g_dft_trace + 1, 1ull);
+    unsigned long long* rr_ = g_dft_trace + 8 + 8 * 4096 + 8 * slot;
+    rr_[0] = 9;  // six phase stamps + the end (bx / by are not recorded for this body)
+    for (int k = 0; k < 6; ++k) rr_[1 + k] = d5_stamp[k] - d5_t0;
+    rr_[7] = wall_clock64() - d5_t0;
+  }
+#endif
 }
 
 template <int R0>
@@ -961,16 +1012,24 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5G
     const double* pb = ws + g.tbase + g.pfa_off;
     const PfaTabs pt{reinterpret_cast<const uint16_t*>(pb + PFA_TAB_GAT), reinterpret_cast<const uint16_t*>(pb + PFA_TAB_KIDX),
                      reinterpret_cast<const double2*>(pb + PFA_TAB_B2)};
-    ring2px_body_pfa<N64>(a, pt, G, ncol, out, C, bx, by, lds5);
-    return;
+    // (pfa_passes = 2: half as many workgroups, each taking two ring pairs in turn -- with one such workgroup per CU the
+    // latency-bound workgroups of the small scales are resident from the start instead of forming a second round)
+#pragma nounroll
+    for (int ps = 0; ps < g.pfa_passes; ++ps) {
+      if (ps) d5_barrier();  // the stage of the previous pair has been read by the ring stores
+      ring2px_body_pfa<N64>(a, pt, G, ncol, out, C, bx * g.pfa_passes + ps, by, lds5);
+    }
    }
   }
+#ifndef PXM_D5_ONLY_PFA  // (development aid: an assembly listing of the exact-length body alone)
   switch (g.r0) {
+    case 9: break;  // (done above)
     case 8: ring2px_body5<8, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
     case 4: ring2px_body5<4, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
     case 2: ring2px_body5<2, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
     default: ring2px_body5<1, RING_OUT, N64>(a, G, ncol, out, C, bx, by, lds5); break;
   }
+#endif
 #ifdef PXM_D5_TRACE
   if (threadIdx.x == 0 && g_dft_trace) {
     unsigned hw, xcc;
@@ -1485,6 +1544,7 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
       g.xs = (g.nby == 1 && per_line > rings && per_line % rings == 0) ? per_line / rings : 1;
     }
     g.pfa_off = 0;
+    g.pfa_passes = 1;
     g.b0 = b0;
     b0 += round_up(g.nbx, 8) * g.nby;  // (padded so that every scale starts on an XCD-label boundary)
     lds = std::max(lds, p.lds5);
@@ -1498,7 +1558,8 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
       any_pfa = true;
       f.r0 = 9;
       f.pfa_off = p.t5.pfa_off;
-      f.nbx = (p.L + 1) / 2;
+      f.pfa_passes = (getenv("PXM_PFA_PASSES") && atoi(getenv("PXM_PFA_PASSES")) == 1) ? 1 : 2;
+      f.nbx = ((p.L + 1) / 2 + f.pfa_passes - 1) / f.pfa_passes;
       f.xs = 1;
     }
     f.b0 = b0f;
@@ -1559,8 +1620,8 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
   if (any_pfa) {
     // LDS of the exact-length body: 8 planes of PFA_PLANE slots (aliased by the stage of 2 rings x 511 x 4 slots) + the filter
     // spectrum: 74 880 B, inside the 81 920 B of the Bluestein workgroups (two workgroups per CU either way)
-    static_assert((size_t)8 * PFA_PLANE * 16 + 72 * 16 <= (size_t)2 * D5_RMAX * D5_PLANE * 16 + (size_t)D5_TW * 16, "PFA workgroup LDS");
-    static_assert(2 * PFA_N * 4 <= 8 * PFA_PLANE, "the stage of two rings fits in the planes");
+    static_assert(((size_t)8 * PFA_PLANE + 72 + NOISE_LOG_N + 256) * 16 <= (size_t)2 * D5_RMAX * D5_PLANE * 16 + (size_t)D5_TW * 16, "PFA workgroup LDS");
+    static_assert(2 * 4 * PFA_STAGE_S <= 8 * PFA_PLANE, "the stage of two rings fits in the planes");
     if (int rc = dev_alloc(&out->d_fused, vf.size() * sizeof(Dft5Group), "DFT group entries (fused launch)")) return rc;
     if (int rc = dev_upload(out->d_fused, vf.data(), vf.size() * sizeof(Dft5Group))) return rc;
     out->blocks_fused = b0f;

@@ -127,13 +127,15 @@ __device__ inline NormalPair box_muller_f64_poly(double u1, double u2) {
 //   angle   2 pi u2 = 2 pi k / 256 + a, k = rint(256 u2), |a| <= pi / 256: table {cos, sin}(2 pi k / 256), sin a and
 //           cos a - 1 by four / three terms, angle addition with the small parts added last.
 // 1.2e-15 against a 40-digit evaluation over 2 x 10^4 uniforms incl. the edges (a = 0, 2^53 - 1, m at the range ends).
-__device__ inline NormalPair box_muller_f64_tab(double u1, double u2) {
+// (logt / sct: the two tables -- the global ones, or a kernel's LDS copies: a gather from global memory costs the epilogue of
+// the fused phi-DFT kernel ~700 cycles of latency per look-up, an LDS read ~100)
+__device__ inline NormalPair box_muller_f64_tab(double u1, double u2, const double2* logt, const double2* sct) {
   const int ex = __builtin_amdgcn_frexp_exp(u1);
   const double m = __builtin_amdgcn_frexp_mant(u1);  // [0.5, 1)
   // 128 .. 256 for the stream's u1 in (0, 1]; clamped so that a caller-supplied u1 outside that range (0, NaN, inf through
   // pxm_box_muller) reads a table entry and not the memory in front of the table
   const int j = min(max((int)__builtin_rint(m * 256.0), NOISE_LOG_J0), 256);
-  const double2 lt = *reinterpret_cast<const double2*>(&NOISE_LOG_TAB[j - NOISE_LOG_J0][0]);
+  const double2 lt = logt[j - NOISE_LOG_J0];
   const double r = fma(m, lt.x, -1.0);
   double p = 1.0 / 7.0;
   p = fma(p, r, -1.0 / 6.0);
@@ -156,7 +158,7 @@ __device__ inline NormalPair box_muller_f64_tab(double u1, double u2) {
   const double t = 256.0 * u2;
   const double k = __builtin_rint(t);
   const double a = (t - k) * 0.024543692606170259675;  // 2 pi / 256
-  const double2 cs = *reinterpret_cast<const double2*>(&NOISE_SINCOS_TAB[(int)k & 255][0]);
+  const double2 cs = sct[(int)k & 255];
   const double a2 = a * a;
   const double q = fma(fma(a2, -1.0 / 5040.0, 1.0 / 120.0), a2, -1.0 / 6.0);
   const double sa = fma(a * a2, q, a);                                                // sin a
@@ -164,6 +166,9 @@ __device__ inline NormalPair box_muller_f64_tab(double u1, double u2) {
   const double C = cs.x + fma(-cs.y, sa, cs.x * cm1);
   const double S = cs.y + fma(cs.x, sa, cs.y * cm1);
   return NormalPair{g * C, g * S};
+}
+__device__ inline NormalPair box_muller_f64_tab(double u1, double u2) {
+  return box_muller_f64_tab(u1, u2, reinterpret_cast<const double2*>(&NOISE_LOG_TAB[0][0]), reinterpret_cast<const double2*>(&NOISE_SINCOS_TAB[0][0]));
 }
 __device__ inline NormalPair box_muller_f64(double u1, double u2) {
 #ifdef PXM_NOISE_F64_POLY
@@ -188,6 +193,16 @@ __device__ inline NormalPair philox_normal_pair_t(uint64_t seed, uint64_t chain,
   const double u2 = ((double)b + 0.5) * 0x1.0p-53;
   if (F64) return box_muller_f64(u1, u2);
   return box_muller_fast(u1, u2);
+}
+// the fp64 form with the caller's copies of the Box-Muller tables (same deviates, bit for bit)
+__device__ inline NormalPair philox_normal_pair_tabs(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter, const double2* logt,
+                                                     const double2* sct) {
+  const uint64_t key = seed + chain * 0x9E3779B97F4A7C15ull;
+  uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)iter, (uint32_t)(iter >> 32)};
+  philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+  const uint64_t a = (((uint64_t)c[1] << 32) | c[0]) >> 11;
+  const uint64_t b = (((uint64_t)c[3] << 32) | c[2]) >> 11;
+  return box_muller_f64_tab(((double)a + 0.5) * 0x1.0p-53, ((double)b + 0.5) * 0x1.0p-53, logt, sct);
 }
 __device__ inline NormalPair philox_normal_pair(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter, bool f64 = false) {
   return f64 ? philox_normal_pair_t<true>(seed, chain, index, iter) : philox_normal_pair_t<false>(seed, chain, index, iter);

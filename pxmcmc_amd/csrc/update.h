@@ -175,6 +175,30 @@ __device__ __forceinline__ double2 px_noise_philox_t(const PxOut& o, int c, int6
   }
   return w;
 }
+// fp64 form reading the Box-Muller tables through the caller's pointers (LDS copies in the exact-length phi-DFT body)
+__device__ __forceinline__ double2 px_noise_philox_tabs(const PxOut& o, int c, int64_t e, uint64_t it, const double2* logt, const double2* sct) {
+  const bool pairs = o.mode == PXM_MODE_REAL_PAIRS, cplx = o.mode == PXM_MODE_CPLX_NOISE;
+  if (pairs && !(o.chain0 & 1)) {
+    const NormalPair q = philox_normal_pair_tabs(o.seed + PXM_PAIR_TWEAK, (o.chain0 >> 1) + c, (uint64_t)e, it, logt, sct);
+    return double2{q.z0, q.z1};
+  }
+  const int nk = pairs ? 2 : 1;
+  double2 w{0.0, 0.0};
+#pragma nounroll
+  for (int k = 0; k < nk; ++k) {
+    const uint64_t chain = o.chain0 + (pairs ? 2 * c + k : c);
+    const NormalPair q = cplx ? philox_normal_pair_tabs(o.seed, chain, (uint64_t)e, it, logt, sct)
+                              : philox_normal_pair_tabs(o.seed + PXM_PAIR_TWEAK, chain >> 1, (uint64_t)e, it, logt, sct);
+    const double v = (cplx || !(chain & 1)) ? q.z0 : q.z1;
+    if (k == 0) {
+      w.x = v;
+      w.y = cplx ? q.z1 : 0.0;
+    } else {
+      w.y = v;
+    }
+  }
+  return w;
+}
 // run-time form (kernels that are not instantiated per noise precision): one uniform branch
 __device__ __forceinline__ double2 px_noise_philox(const PxOut& o, int c, int64_t e, uint64_t it) {
   return o.noise64 ? px_noise_philox_t<true>(o, c, e, it) : px_noise_philox_t<false>(o, c, e, it);

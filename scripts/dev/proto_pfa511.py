@@ -366,3 +366,35 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def conflict_report():
+    """per-access LDS array cycles of the transposes (bank rules of MI355X_MICROARCH.md), incl. the kernel's stage gather / scatter"""
+    T = tables()
+    lane = T["lane"]
+    a63, a56, a9 = lane < 63, lane < 56, lane < 9
+    j1l, q9l, j1m, k8m = lane // 9, lane % 9, lane // 8, lane % 8
+    W = lambda slot, act=None: Lds._cycles(slot, np.ones(64, bool) if act is None else act, WRITE_GROUPS, 8)
+    R = lambda slot, act=None: Lds._cycles(slot, np.ones(64, bool) if act is None else act, READ_GROUPS, 16)
+    rows = []
+    rows.append(("T2 write  plane[j1*72 + k8*9 + q9]", [W(j1l * 72 + k * 9 + q9l, a63) for k in range(8)], 8))
+    rows.append(("T2 read   plane[j1*72 + k8*9 + q9]", [R(j1m * 72 + k8m * 9 + k, a56) for k in range(9)], 4))
+    rows.append(("T3 write", [W(j1m * 72 + k8m * 9 + k, a56) for k in range(9)], 8))
+    rows.append(("T3 read", [R(j1l * 72 + k * 9 + q9l, a63) for k in range(8)], 4))
+    rows.append(("T4 write  plane[(p9 + 9 p8)*7 + j1]", [W((q9l + 9 * k) * 7 + j1l, a63) for k in range(8)], 8))
+    rows.append(("T4 read   plane[inst*7 + j1]", [R(lane * 7 + k) for k in range(7)] + [R((64 + lane) * 7 + k, a9) for k in range(7)], 4))
+    kb1, kb2 = T["kb"][lane], T["kb"][np.minimum(64 + lane, 72)]
+    rows.append(("T5 write  plane[k] (natural)", [W((kb1 + 365 * k) % N) for k in range(7)] + [W((kb2 + 365 * k) % N, a9) for k in range(7)], 8))
+    rows.append(("T5 read / T0 write  plane[lane + 64 p]", [R(lane + 64 * p) for p in range(8)], 4))
+    rows.append(("T0 read   plane[gat]", [R(T["gat"][q]) for q in range(8)], 4))
+    for r in range(4):
+        rows.append((f"stage gather  stage[4 gat + {r}]", [R(4 * T["gat"][q] + r) for q in range(8)], 4))
+    rows.append(("stage scatter stage[4 k + r]", [W(4 * ((kb1 + 365 * k) % N)) for k in range(7)] + [W(4 * ((kb2 + 365 * k) % N), a9) for k in range(7)], 8))
+    print("LDS array cycles per instruction (ideal = conflict-free):")
+    for name, cyc, ideal in rows:
+        print(f"   {name:42s} {sum(cyc):4d} cycles over {len(cyc):2d} instructions (ideal {ideal * len(cyc):3d}): {cyc}")
+
+
+if __name__ == "__main__":
+    print()
+    conflict_report()

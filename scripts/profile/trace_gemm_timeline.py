@@ -72,6 +72,12 @@ if os.environ.get("TRACE") == "dft":  # grouped DFT kernel instead (-DPXM_D5_TRA
     print(f"  phases (us from workgroup start; median over {m} workgroups): r0: rings staged / inverse transform / update / forward transform / rings stored")
     for r0 in sorted(set(ph[:, 0].tolist())):
         q = ph[ph[:, 0] == r0]
+        if r0 == 9:  # exact-length body (csrc/dft_pfa.h): its own stamps
+            med = np.median(q[:, 1:8], axis=0) / 100.0
+            print("    r0=9 (exact length): rings staged / unit gathered / inverse transform / first half of the epilogue / second half / "
+                  "forward transform / rings stored:")
+            print("          " + " / ".join(f"{v:5.1f}" for v in med) + f"   ({len(q)} workgroup passes)")
+            continue
         med = np.median(q[:, 1:6], axis=0) / 100.0
         print(f"    r0={r0}: " + " / ".join(f"{v:5.1f}" for v in med) + f"   ({len(q)} workgroups)")
     sys.exit(0)
