@@ -95,6 +95,11 @@ int pxm_host_sht_tables(int L, int spin, int m, double* Binv, double* Afwd);
  * double precision on a per-ring scaled state; host emulation, operation for operation): what pyssht.inverse /
  * inverse_adjoint (pxmcmc/measurements.py:225,237) multiply by when a plan takes the recursion path */
 int pxm_host_rec_table(int L, int spin, int m, double* Brec);
+/* tables of the exact-length phi-DFT unit for ring length 511 = 7 x 73 (csrc/dft_pfa.h; the phi stage of
+ * pys2let.synthesis_wav2px / synthesis_adjoint_px2wav at bandlimit 256, pxmcmc/transforms.py:126,138): idx[(64 + 80) * 8]
+ * uint16 gather / scatter offsets, b2[8 * 9 * 2] the spectrum of Rader's filter; for the CPU test against
+ * scripts/dev/proto_pfa511.py */
+int pxm_host_pfa511_tables(uint16_t* idx, double* b2);
 
 /* ---- spin spherical-harmonic transforms on the MW grid ---------------------- */
 /* replaces pyssht.forward / inverse / inverse_adjoint / forward_adjoint

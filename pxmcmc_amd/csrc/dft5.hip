@@ -677,88 +677,114 @@ struct PfaTabs {
   const double2* B2;     // [8][9]
 };
 
-// stage of the exact-length body: [ring][chain slot][k], rows of 514 slots.  The units gather / scatter pseudo-random k of ONE
-// chain slot: with the chain innermost (slot 4 k + r, as in the Bluestein bodies) a wave would touch 4 of the 16 bank groups
-// only (190 / 329 instead of ~94 / ~157 LDS cycles per gather / scatter, scripts/dev/proto_pfa511.py); 514 = 2 mod 8 keeps
-// the cooperative fill (thread -> (chain, k): 4 chains x 2 k per group of eight lanes) free of write conflicts.
+// stage of the exact-length body: [chain slot][k] per ring, rows of 514 slots.  The units gather / scatter pseudo-random k of
+// ONE chain slot: with the chain innermost (slot 4 k + r, as in the Bluestein bodies) a wave would touch 4 of the 16 bank
+// groups only (190 / 329 instead of ~94 / ~157 LDS cycles per gather / scatter, scripts/dev/proto_pfa511.py); 514 = 2 mod 8
+// keeps the cooperative fill (thread -> (chain, k): 4 chains x 2 k per group of eight lanes) free of write conflicts.
 constexpr int PFA_STAGE_S = 514;
-#define PXM_PFA_SLOT(RING, K, CH) (((((RING) << 2) + (CH)) * PFA_STAGE_S) + (K))
+static_assert(4 * PFA_STAGE_S <= 4 * PFA_PLANE, "a ring group's stage fits in its four planes");
 
+// Synchronisation of the FOUR waves of a ring group (one ring, four chain slots) through an LDS counter, as d5_pair_sync does for
+// a wave pair: the two ring groups of a workgroup share nothing but the read-only tables, so each runs at its own pace -- a
+// workgroup barrier made every phase wait for the slowest of eight waves (7-10 us between a unit's last transform and the
+// end of its workgroup in the trace build).  Bounded spin; an expiry sets the plan's PXM_STATUS_PAIR_SYNC bit.
+__device__ __forceinline__ void pfa_group_sync(unsigned* cnt, unsigned target, int lane, const D5Sync& sy) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  unsigned spins = 0;
+  bool ready;
+  while (!(ready = __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= (int)target) &&
+         ++spins < sy.limit)
+    __builtin_amdgcn_s_sleep(1);
+  if (!ready && sy.err && lane == 0) __hip_atomic_fetch_or(sy.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("" ::: "memory");
+}
+
+// bxw: workgroup index along the rings; the workgroup takes the ring pairs bxw * passes + ps, ps < passes, one after the
+// other (passes = 2: half as many workgroups -- with one such workgroup per CU the latency-bound workgroups of the small
+// scales are resident from the start of the launch instead of forming a second round).
 template <bool N64>
 __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTabs& pt, double* __restrict__ G, int ncol,
-                                                 const PxOut& out, int C, int bx, int by, double2* lds5) {
+                                                 const PxOut& out, int C, int bxw, int by, int passes, double2* lds5) {
   if ((by << 2) >= C) return;
 #ifdef PXM_D5_TRACE
   unsigned long long d5_stamp[7] = {0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long d5_t0 = wall_clock64();
+  unsigned long long d5_t0 = wall_clock64();
 #endif
-  constexpr int n = PFA_N, R = 4, TRS = 2;
-  // (the body may run twice per workgroup: the opaque copy keeps everything derived from the thread id INSIDE a pass -- hoisted
-  // out of the pass loop these values cost 20 spilled registers at the 128-VGPR budget)
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int r = wave & 3, trs = wave >> 2;  // chain slot and ring of the workgroup: one unit per wave
-  const int t = bx * TRS + trs;
-  const int c0 = by * R, ch = c0 + r;
-  const bool tv = t < a.L;
-  const int Cp = ncol >> 1;
-  double2* stage = lds5;
-  double2* plane = lds5 + wave * PFA_PLANE;
-  double2* B2l = lds5 + 8 * PFA_PLANE;
-  if (tid < 72) B2l[tid] = pt.B2[tid];
-  // fp64 noise: LDS copies of the two Box-Muller tables (129 + 256 entries behind the filter spectrum: 81 040 B per workgroup)
-  const double2* const logt = B2l + 72;
-  const double2* const sct = B2l + 72 + NOISE_LOG_N;
-#if !defined(PXM_NOISE_F64_POLY)
-  if (N64 && out.X && !out.noise && tid < NOISE_LOG_N + 256)  // (385 entries, 512 threads)
-    B2l[72 + tid] = tid < NOISE_LOG_N ? reinterpret_cast<const double2*>(&NOISE_LOG_TAB[0][0])[tid]
-                                      : reinterpret_cast<const double2*>(&NOISE_SINCOS_TAB[0][0])[tid - NOISE_LOG_N];
-#endif
-  // (the per-lane index tables -- byte offsets, 8 x u16 per row, L1-resident -- are re-read where they are used instead of
-  // living in 12 registers across the epilogue)
-  const int j1m = lane >> 3;
-  const int x0k = (73 * (j1m < 7 ? j1m : 6)) % n;  // element j2 = 0 of the lane's S2 ring role
-  const int mstride = a.Rp * Cp;                    // complex elements between consecutive m
-  {  // rings of the workgroup -> stage (conjugated: inverse DFT by conjugation); thread -> (chain rr, k)
-    const int rr = tid & (R - 1), kq = tid >> 2, kstep = 128;
-    const double2* Gc = reinterpret_cast<const double2*>(G) + c0 + rr;
-    const bool cv = c0 + rr < Cp;
-#pragma nounroll
-    for (int kb = kq; kb < n; kb += 2 * kstep) {
-      double2 v[TRS][2];
-#pragma unroll
-      for (int ru = 0; ru < TRS; ++ru) {
-        const int tt = bx * TRS + ru;
-        const bool rv = cv && tt < a.L;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int k = kb + u * kstep;
-          v[ru][u] = double2{0.0, 0.0};
-          if (rv && k < n) v[ru][u] = Gc[((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + tt * Cp];
-        }
-      }
-#pragma unroll
-      for (int ru = 0; ru < TRS; ++ru)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int k = kb + u * kstep;
-          if (k < n) stage[PXM_PFA_SLOT(ru, k, rr)] = double2{v[ru][u].x, -v[ru][u].y};
-        }
-    }
+  constexpr int n = PFA_N, R = 4, S = PFA_STAGE_S;
+  // Everything derived from the thread id is formed from an OPAQUE copy of it, once in front of the pass loop and again at the top
+  // of every pass: hoisted out of the loop as invariants these values (lane roles, LDS and global bases) stay live through the
+  // whole pass and cost 65-90 spilled registers at the 128-VGPR budget.
+#define PXM_PFA_THREAD_SETUP                                                                                              \
+  int tid = threadIdx.x;                                                                                                  \
+  asm volatile("" : "+v"(tid));                                                                                           \
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;                                             \
+  const int r = wave & 3, grp = wave >> 2; /* chain slot of the unit; ring group (waves 0-3 / 4-7: one ring each per pass) */ \
+  const int c0 = by * R, ch = c0 + r;                                                                                     \
+  const int Cp = ncol >> 1;                                                                                               \
+  double2* stage = lds5 + grp * (4 * PFA_PLANE); /* the group's stage aliases the group's own four planes */              \
+  double2* plane = lds5 + wave * PFA_PLANE;                                                                               \
+  double2* B2l = lds5 + 8 * PFA_PLANE;                                                                                    \
+  const double2* const logt = B2l + 72;                                                                                   \
+  const double2* const sct = B2l + 72 + NOISE_LOG_N;                                                                      \
+  unsigned* const gcnt = reinterpret_cast<unsigned*>(B2l + 72 + NOISE_LOG_N + 256) + grp;                                 \
+  const int j1m = lane >> 3;                                                                                              \
+  const int x0k = (73 * (j1m < 7 ? j1m : 6)) % n; /* element j2 = 0 of the lane's S2 ring role */                         \
+  const int mstride = a.Rp * Cp;                  /* complex elements between consecutive m */                            \
+  /* ring <-> stage: thread of the group -> (chain rr, k = kq + 64 i), 64-B segments of the ring arrays */                 \
+  const int rr = tid & (R - 1), kq = (tid & 255) >> 2;                                                                    \
+  const bool cv = c0 + rr < Cp;                                                                                           \
+  double2* const Gc = reinterpret_cast<double2*>(G) + c0 + rr;
+#define PXM_PFA_RING_LOAD(TT)                                                                                             \
+  { /* all eight loads of the thread in flight together */                                                                \
+    const int tt_ = (TT);                                                                                                 \
+    const bool rv_ = cv && tt_ < a.L;                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                       \
+      const int k = kq + 64 * i;                                                                                          \
+      v[i] = double2{0.0, 0.0};                                                                                           \
+      if (rv_ && k < n) v[i] = Gc[((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + tt_ * Cp];                              \
+    }                                                                                                                     \
   }
-  d5_barrier();  // (also: the LDS copy of the filter spectrum is complete)
-  PXM_D5_STAMP(0)  // rings staged
+  double2 v[8];
+  unsigned epoch = 0;
+  const D5Sync sy{a.err, a.spin_limit};
+  {
+    PXM_PFA_THREAD_SETUP
+    (void)ch; (void)stage; (void)plane; (void)logt; (void)sct; (void)gcnt; (void)x0k; (void)lane;
+    if (tid < 72) B2l[tid] = pt.B2[tid];
+    // fp64 noise: LDS copies of the two Box-Muller tables (129 + 256 entries behind the filter spectrum); behind them the two
+    // group counters: 81 056 B per workgroup
+#if !defined(PXM_NOISE_F64_POLY)
+    if (N64 && out.X && !out.noise && tid < NOISE_LOG_N + 256)  // (385 entries, 512 threads)
+      B2l[72 + tid] = tid < NOISE_LOG_N ? reinterpret_cast<const double2*>(&NOISE_LOG_TAB[0][0])[tid]
+                                        : reinterpret_cast<const double2*>(&NOISE_SINCOS_TAB[0][0])[tid - NOISE_LOG_N];
+#endif
+    if (tid < 2) reinterpret_cast<unsigned*>(B2l + 72 + NOISE_LOG_N + 256)[tid] = 0;
+    PXM_PFA_RING_LOAD((bxw * passes) * 2 + grp)
+  }
+  d5_barrier();  // the tables and the counters are in place (the only workgroup barrier of this body)
+#pragma nounroll
+  for (int ps = 0; ps < passes; ++ps) {
+  PXM_PFA_THREAD_SETUP
+  const int t = (bxw * passes + ps) * 2 + grp;
+  const bool tv = t < a.L;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // conjugated: inverse DFT by conjugation
+    const int k = kq + 64 * i;
+    if (k < n) stage[rr * S + k] = double2{v[i].x, -v[i].y};
+  }
+  pfa_group_sync(gcnt, epoch += 4, lane, sy);
+  PXM_D5_STAMP(0)  // ring staged
   double2 z[8], o1[7], o2[7];
   double2 x0;
   {
-    const char* sb = reinterpret_cast<const char*>(stage + PXM_PFA_SLOT(trs, 0, r));
+    const char* sb = reinterpret_cast<const char*>(stage + r * S);
     const uint4 gv = reinterpret_cast<const uint4*>(pt.gat)[lane];
 #pragma unroll
     for (int q = 0; q < 8; ++q) z[q] = *reinterpret_cast<const double2*>(sb + pfa_u16(gv, q));
     x0 = *reinterpret_cast<const double2*>(sb + 16 * x0k);
   }
-  d5_barrier();  // the stage is dead: the planes may be written
+  pfa_group_sync(gcnt, epoch += 4, lane, sy);  // the stage is dead: the planes may be written
   PXM_D5_STAMP(1)  // unit gathered
   pfa511_core(z, x0, o1, o2, plane, B2l, lane);
   PXM_D5_STAMP(2)  // inverse transform done
@@ -787,17 +813,21 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
 #pragma unroll
   for (int g0 = 0; g0 < 8; g0 += 4) {
     double2 x[4];
+    // (lane 63, p = 7: slot 511, never an element.  In the update branch the four elements stay in the plane until the noise
+    // has been drawn: 16 registers fewer across the fp64 Box-Muller)
+    if (!N64 || !(act && out.X)) {  // (f32 noise: reading early is the allocation without spills)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) D5_PR(x[u], plane[lane + 64 * (g0 + u)]);  // (lane 63, p = 7: slot 511, never an element)
+      for (int u = 0; u < 4; ++u) D5_PR(x[u], plane[lane + 64 * (g0 + u)]);
+    }
     if (act && out.X) {  // fused prox + MYULA update (pxmcmc/mcmc.py:185-201, prior.py:49-50); see ring2px_body5
       double2 xs[4], wn[4], wph[4];
       double Ts[4];
-      int64_t eo[4];
+      int eo[4];  // element offsets from e0 (32 bits: a ring is 511 elements)
       // operand loads FIRST, the noise of the four elements while they are in flight (this body holds four elements, not
       // eight, beside the epilogue's operands: the fp64 Box-Muller fits between the loads and their use without spills --
       // in ring2px_body5 that order cost 250 spilled registers)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) eo[u] = (g0 + u < 7 || last_ok) ? (int64_t)64 * (g0 + u) : -(int64_t)lane;  // (else: the ring's element 0)
+      for (int u = 0; u < 4; ++u) eo[u] = (g0 + u < 7 || last_ok) ? 64 * (g0 + u) : -lane;  // (else: the ring's element 0)
 #pragma unroll
       for (int u = 0; u < 4; ++u) xs[u] = reinterpret_cast<const double2*>(out.X)[ce0 + eo[u]];
       if (out.T) {
@@ -827,6 +857,10 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
 #endif
 #endif
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if (N64) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) D5_PR(x[u], plane[lane + 64 * (g0 + u)]);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -892,9 +926,9 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
   d5_wave_sync();
   pfa511_core(z, x0, o1, o2, plane, B2l, lane);
   PXM_D5_STAMP(5)  // forward transform done
-  d5_barrier();  // every plane of the workgroup is dead: the stage may be written
+  pfa_group_sync(gcnt, epoch += 4, lane, sy);  // every plane of the group is dead: its stage may be written
   {
-    char* sb = reinterpret_cast<char*>(stage + PXM_PFA_SLOT(trs, 0, r));
+    char* sb = reinterpret_cast<char*>(stage + r * S);
     const uint4 kv1 = reinterpret_cast<const uint4*>(pt.kidx)[lane];
     const uint4 kv2 = reinterpret_cast<const uint4*>(pt.kidx)[64 + (lane < 9 ? lane : 8)];
 #pragma unroll
@@ -904,33 +938,32 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
       for (int k = 0; k < 7; ++k) *reinterpret_cast<double2*>(sb + pfa_u16(kv2, k)) = o2[k];
     }
   }
-  d5_barrier();
+  // the next ring's loads are in flight across the stores (unconditional assignment -- zeros behind the last pass: a conditional
+  // one would keep the eight registers of v live through the whole pass)
+  PXM_PFA_RING_LOAD(ps + 1 < passes ? (bxw * passes + ps + 1) * 2 + grp : a.L)
+  pfa_group_sync(gcnt, epoch += 4, lane, sy);
   PXM_D5_STAMP(6)  // results in the stage
-  {  // stage -> G rows of both rings
-    const int rr = tid & (R - 1), kq = tid >> 2, kstep = 128;
-    double2* Gc = reinterpret_cast<double2*>(G) + c0 + rr;
-    if (c0 + rr < Cp) {
-#pragma nounroll
-      for (int trr = 0; trr < TRS; ++trr) {
-        const int tt = bx * TRS + trr;
-        if (tt >= a.L) break;
-        for (int k = kq; k < n; k += kstep) {
-          const int mi = (k < a.L) ? k + a.L - 1 : k - a.L;
-          Gc[mi * mstride + tt * Cp] = stage[PXM_PFA_SLOT(trr, k, rr)];
-        }
-      }
+  if (cv && tv) {  // stage -> G rows of the ring
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = kq + 64 * i;
+      if (k < n) Gc[((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + t * Cp] = stage[rr * S + k];
     }
   }
+  if (ps + 1 < passes) pfa_group_sync(gcnt, epoch += 4, lane, sy);  // the stage has been read: the next ring may be staged
 #ifdef PXM_D5_TRACE
-  d5_barrier();
   if (tid == 0 && g_dft_trace) {
     const unsigned long long slot = atomicAdd(g_dft_trace + 1, 1ull);
     unsigned long long* rr_ = g_dft_trace + 8 + 8 * 4096 + 8 * slot;
-    rr_[0] = 9;  // six phase stamps + the end (bx / by are not recorded for this body)
+    rr_[0] = 9;  // six phase stamps + the end of the pass (bx / by are not recorded for this body)
     for (int k = 0; k < 6; ++k) rr_[1 + k] = d5_stamp[k] - d5_t0;
     rr_[7] = wall_clock64() - d5_t0;
+    d5_t0 = wall_clock64();
   }
 #endif
+  }  // passes
+#undef PXM_PFA_THREAD_SETUP
+#undef PXM_PFA_RING_LOAD
 }
 
 template <int R0>
@@ -1014,11 +1047,7 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5G
                      reinterpret_cast<const double2*>(pb + PFA_TAB_B2)};
     // (pfa_passes = 2: half as many workgroups, each taking two ring pairs in turn -- with one such workgroup per CU the
     // latency-bound workgroups of the small scales are resident from the start instead of forming a second round)
-#pragma nounroll
-    for (int ps = 0; ps < g.pfa_passes; ++ps) {
-      if (ps) d5_barrier();  // the stage of the previous pair has been read by the ring stores
-      ring2px_body_pfa<N64>(a, pt, G, ncol, out, C, bx * g.pfa_passes + ps, by, lds5);
-    }
+    ring2px_body_pfa<N64>(a, pt, G, ncol, out, C, bx, by, g.pfa_passes, lds5);
    }
   }
 #ifndef PXM_D5_ONLY_PFA  // (development aid: an assembly listing of the exact-length body alone)
@@ -1331,6 +1360,39 @@ int dft5_r0(int n) {  // 0: no eight-point path for this ring length
   return Mh / 64;
 }
 
+// Host tables of the exact-length unit (n = 511): idx[(64 + 80) * 8] u16 -- rows 0..63: byte offset 16 k of the element
+// k = (73 j1 + 7 g^-q) mod 511, q = CRT72(q8, q9), that lane (j1, q9) = (row / 9, row % 9) holds in register q8 of the S1 layout
+// (row 63 idle: zeros); rows 64..136: byte offset 16 k of the output k = CRT511(k1, k2) of instance (row - 64), column k1 < 7,
+// k2 = g^CRT72(p8, p9) for instance p9 + 9 p8 and k2 = 0 for instance 72 -- and B2[8][9] = FFT2(b) / 72, b[r] = W_73^(g^r),
+// the spectrum of Rader's filter on Z_8 x Z_9.  g = 5 generates (Z / 73)^*.  Checked against scripts/dev/proto_pfa511.py
+// by the CPU suite (pxm_host_pfa511_tables).
+void pfa511_host_tables(uint16_t* idx, double* b2) {
+  typedef std::complex<long double> cld;
+  const long double PI_L = 3.141592653589793238462643383279502884L;
+  const int n = PFA_N, N2 = 73, g = 5;
+  auto ang = [&](long double num, long double den) { return cld(cosl(-PI_L * num / den), sinl(-PI_L * num / den)); };
+  auto powm = [&](long long b, int e) { long long r_ = 1; for (int i = 0; i < e; ++i) r_ = r_ * b % N2; return (int)r_; };
+  const int ginv = powm(g, 71);  // g^-1 = g^(phi - 1)
+  auto crt72 = [](int q8, int q9) { return (9 * q8 + 64 * q9) % 72; };
+  std::fill(idx, idx + (size_t)(64 + 80) * 8, (uint16_t)0);
+  for (int l = 0; l < 63; ++l)
+    for (int q8 = 0; q8 < 8; ++q8) idx[(size_t)l * 8 + q8] = (uint16_t)(16 * ((73 * (l / 9) + 7 * powm(ginv, crt72(q8, l % 9))) % n));
+  for (int inst = 0; inst < 73; ++inst) {
+    const int k2 = inst < 72 ? powm(g, crt72(inst / 9, inst % 9)) : 0;
+    for (int k1 = 0; k1 < 7; ++k1) idx[(size_t)(64 + inst) * 8 + k1] = (uint16_t)(16 * ((365 * k1 + 147 * k2) % n));
+  }
+  for (int k8 = 0; k8 < 8; ++k8)
+    for (int k9 = 0; k9 < 9; ++k9) {
+      cld acc(0, 0);
+      for (int q8 = 0; q8 < 8; ++q8)
+        for (int q9 = 0; q9 < 9; ++q9)
+          acc += ang(2.0L * powm(g, crt72(q8, q9)), N2) * ang(2.0L * ((q8 * k8) % 8), 8) * ang(2.0L * ((q9 * k9) % 9), 9);
+      acc /= 72.0L;
+      b2[2 * (k8 * 9 + k9)] = (double)acc.real();
+      b2[2 * (k8 * 9 + k9) + 1] = (double)acc.imag();
+    }
+}
+
 int dft5_make_tables(int n, Dft5Tables* t) {
   typedef std::complex<long double> cld;
   const long double PI_L = 3.141592653589793238462643383279502884L;
@@ -1390,34 +1452,8 @@ int dft5_make_tables(int n, Dft5Tables* t) {
   size_t o_pfa = 0;
   if (n == PFA_N && !(getenv("PXM_DFT_PFA") && atoi(getenv("PXM_DFT_PFA")) == 0)) {
     o_pfa = h.size();
-    const int N2 = 73, g = 5;  // 5 generates (Z / 73)^*
-    auto powm = [&](long long b, int e) { long long r_ = 1; for (int i = 0; i < e; ++i) r_ = r_ * b % N2; return (int)r_; };
-    const int ginv = powm(g, 71);  // g^-1 = g^(phi - 1)
-    auto crt72 = [](int q8, int q9) { return (9 * q8 + 64 * q9) % 72; };
-    std::vector<uint16_t> idx((size_t)(64 + 80) * 8, 0);
-    for (int l = 0; l < 63; ++l)      // S1: lane (j1, q9), register q8 -> element (73 j1 + 7 g^-q) mod 511, q = CRT(q8, q9)
-      for (int q8 = 0; q8 < 8; ++q8) idx[(size_t)l * 8 + q8] = (uint16_t)(16 * ((73 * (l / 9) + 7 * powm(ginv, crt72(q8, l % 9))) % n));
-    // (lane 63 is idle in S1: its eight entries stay 0 -- element 0, a valid address)
-    for (int inst = 0; inst < 73; ++inst) {  // S4: instance p9 + 9 p8 holds k2 = g^CRT(p8, p9), instance 72 holds k2 = 0
-      const int k2 = inst < 72 ? powm(g, crt72(inst / 9, inst % 9)) : 0;
-      for (int k1 = 0; k1 < 7; ++k1) idx[(size_t)(64 + inst) * 8 + k1] = (uint16_t)(16 * ((365 * k1 + 147 * k2) % n));
-    }
-    const size_t nd = idx.size() * sizeof(uint16_t) / sizeof(double);
-    h.resize(h.size() + nd);
-    std::memcpy(h.data() + o_pfa, idx.data(), idx.size() * sizeof(uint16_t));
-    // B2[k8][k9] = (1 / 72) sum_(q8, q9) b[CRT(q8, q9)] W_8^(q8 k8) W_9^(q9 k9),  b[r] = W_73^(g^r)
-    for (int k8 = 0; k8 < 8; ++k8)
-      for (int k9 = 0; k9 < 9; ++k9) {
-        cld acc(0, 0);
-        for (int q8 = 0; q8 < 8; ++q8)
-          for (int q9 = 0; q9 < 9; ++q9)
-            acc += ang(2.0L * powm(g, crt72(q8, q9)), N2) * ang(2.0L * ((q8 * k8) % 8), 8) * ang(2.0L * ((q9 * k9) % 9), 9);
-        put(acc / 72.0L);
-      }
-    if (h.size() - o_pfa != (size_t)PFA_TAB_DOUBLES) {
-      set_error("dft5_make_tables: the PFA table block has an unexpected size");
-      return -1;
-    }
+    h.resize(h.size() + PFA_TAB_DOUBLES);
+    pfa511_host_tables(reinterpret_cast<uint16_t*>(h.data() + o_pfa + PFA_TAB_GAT), h.data() + o_pfa + PFA_TAB_B2);
   }
   t->pfa_off = (int)o_pfa;
   if (int rc = dev_alloc(&t->d_all, h.size() * sizeof(double), "phi-DFT tables (8 points per lane)")) return rc;
@@ -1620,9 +1656,8 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
   if (any_pfa) {
     // LDS of the exact-length body: 8 planes of PFA_PLANE slots (aliased by the stage of 2 rings x 511 x 4 slots) + the filter
     // spectrum: 74 880 B, inside the 81 920 B of the Bluestein workgroups (two workgroups per CU either way)
-    static_assert(((size_t)8 * PFA_PLANE + 72 + NOISE_LOG_N + 256) * 16 <= (size_t)2 * D5_RMAX * D5_PLANE * 16 + (size_t)D5_TW * 16, "PFA workgroup LDS");
-    static_assert(2 * 4 * PFA_STAGE_S <= 8 * PFA_PLANE, "the stage of two rings fits in the planes");
-    if (int rc = dev_alloc(&out->d_fused, vf.size() * sizeof(Dft5Group), "DFT group entries (fused launch)")) return rc;
+    static_assert(((size_t)8 * PFA_PLANE + 72 + NOISE_LOG_N + 256 + 1) * 16 <= (size_t)2 * D5_RMAX * D5_PLANE * 16 + (size_t)D5_TW * 16, "PFA workgroup LDS");
+        if (int rc = dev_alloc(&out->d_fused, vf.size() * sizeof(Dft5Group), "DFT group entries (fused launch)")) return rc;
     if (int rc = dev_upload(out->d_fused, vf.data(), vf.size() * sizeof(Dft5Group))) return rc;
     out->blocks_fused = b0f;
   }

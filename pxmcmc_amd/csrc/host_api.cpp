@@ -262,6 +262,17 @@ int pxm_host_sht_tables(int L, int spin, int m, double* Binv, double* Afwd) {
 }
 
 
+}  // extern "C"
+namespace pxm {
+void pfa511_host_tables(uint16_t* idx, double* b2);  // dft5.hip
+}
+extern "C" {
+int pxm_host_pfa511_tables(uint16_t* idx, double* b2) {
+  PXM_REQUIRE(idx && b2, "pxm_host_pfa511_tables: null output");
+  pxm::pfa511_host_tables(idx, b2);
+  return 0;
+}
+
 int pxm_host_rec_table(int L, int spin, int m, double* Brec) {
   PXM_REQUIRE(L >= 1 && std::abs(m) < L && Brec, "pxm_host_rec_table: need |m| < L and an output array");
   pxm::rec_emulate_table(L, spin, m, Brec, L);

@@ -292,6 +292,7 @@ void dft_group_destroy(DftGroupList* g);
 // eight-points-per-lane path (dft5.hip)
 int dft5_r0(int n);  // Mh / 64 for ring length n, 0 = not covered (n > 512)
 int dft5_make_tables(int n, Dft5Tables* t);
+void pfa511_host_tables(uint16_t* idx, double* b2);  // exact-length unit of n = 511 (dft_pfa.h): idx[(64 + 80) * 8], b2[144]
 void dft5_geometry(int n, int* R, int* TR, size_t* lds);
 int dft5_px2ring(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st);
 int dft5_ring2px(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out = false);

@@ -257,3 +257,39 @@ def test_bench_tuned_iteration_window_rule():
     assert not ok and n == 250 and a == 1.0
     n, a, ok = bench.tuned_iteration(np.tile([1, 0], 300), window=200, lap=50, timed=150)
     assert ok and n == 200 and a == 0.5                      # tuned from the start: the first full window
+
+
+def test_pfa511_tables_match_the_numpy_model():
+    """The host tables of the exact-length phi-DFT unit (csrc/dft_pfa.h: 511 = 7 x 73, Good-Thomas + Rader over Z_8 x Z_9) against
+    the lane / register-exact numpy model scripts/dev/proto_pfa511.py, which is itself checked against numpy.fft here: gather
+    offsets of the S1 layout, output offsets of the 73 DFT7 instances, the spectrum of Rader's filter."""
+    import ctypes as C
+
+    from pxmcmc_amd._lib import check, lib
+
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts", "dev"))
+    import proto_pfa511 as proto
+
+    idx = np.zeros((64 + 80) * 8, dtype=np.uint16)
+    b2 = np.zeros(144)
+    check(lib.pxm_host_pfa511_tables(idx.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p)))
+    idx = idx.reshape(144, 8)
+    T = proto.tables()
+    gat = T["gat"].T.copy()            # [lane][q8]
+    gat[63] = 0                        # (lane 63 idles in the kernel: the model parks the x0 elements there)
+    assert np.array_equal(idx[:64], 16 * gat)
+    kk = (T["kb"][:, None] + 365 * np.arange(7)[None, :]) % proto.N
+    assert np.array_equal(idx[64:64 + 73, :7], 16 * kk) and not idx[64 + 73:].any() and not idx[64:, 7].any()
+    # every element of the ring is gathered exactly once (504 by the lanes + the seven j2 = 0 elements), every output written once
+    got = sorted((idx[:63].ravel() // 16).tolist() + [(73 * j1) % proto.N for j1 in range(7)])
+    assert got == list(range(proto.N)) and sorted((idx[64:64 + 73, :7].ravel() // 16).tolist()) == list(range(proto.N))
+    B2 = (b2[0::2] + 1j * b2[1::2]).reshape(8, 9)
+    assert np.abs(B2 - T["B2"]).max() < 1e-15  # (long-double sums against numpy.fft.fft2: |B2| ~ 0.12)
+    # and the model is a DFT
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=proto.N) + 1j * rng.normal(size=proto.N)
+    out, _ = proto.pfa511(proto.gather_s1(x, T), T, proto.Lds(520))
+    y = np.concatenate([out[r] for r in range(8)])[: proto.N]
+    assert np.abs(y - np.fft.fft(x)).max() < 1e-13 * np.abs(y).max()
