@@ -310,6 +310,11 @@ int pxm_reduce_l2(const void* preds, const void* data, const void* invcov, int i
  * full (sparse) matrix applied with pxm_csr_matvec (pxmcmc/forward.py:75-78, mcmc.py:78-79) */
 int pxm_reduce_vdot(const void* a, const void* b, double* out, double* scratch, int64_t n, int C, int dtype,
                     pxm_stream_t stream);
+/* uncertainty.credible_interval_range (pxmcmc/uncertainty.py:7-16) of a chain resident on the device: out[j] = Q(1 - alpha/2) -
+ * Q(alpha/2) over the nsamples rows of column j of chain[nsamples][ld >= nparams] (float64), numpy.quantile's default "linear"
+ * method reproduced (exact order statistics by radix select + numpy's lerp) */
+int pxm_quantile_range(const double* chain, int64_t nsamples, int64_t nparams, int64_t ld, double alpha, double* out,
+                       pxm_stream_t stream);
 /* PxMALA.calc_logtransition, literal (pxmcmc/mcmc.py:281-289): out[c] = (re, im) */
 int pxm_logtransition(const void* X1, const void* X2, const void* proxf, const void* gradg,
                       const double* delta_dev, double delta, double lmda, double* out, double* scratch,

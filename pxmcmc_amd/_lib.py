@@ -51,6 +51,7 @@ SIGNATURES = {
     "pxm_host_sht_tables": (c_int, [c_int, c_int, c_int, c_vp, c_vp]),
     "pxm_host_rec_table": (c_int, [c_int, c_int, c_int, c_vp]),
     "pxm_host_pfa511_tables": (c_int, [c_vp, c_vp]),
+    "pxm_quantile_range": (c_int, [c_vp, c_i64, c_i64, c_i64, c_dbl, c_vp, c_vp]),
     "pxm_sht_uses_recursion": (c_int, [c_vp]),
     "pxm_rec_reduce_selftest": (c_int, [c_vp]),
     "pxm_sht_plan_create": (c_int, [c_int, c_int, c_int, C.c_uint, C.POINTER(c_vp)]),

@@ -569,6 +569,78 @@ using namespace pxm;
   if (n == 0) return 0;                                                           \
   hipStream_t st = (hipStream_t)stream
 
+
+// ---- quantile credible-interval range of a chain resident on the device (pxmcmc/uncertainty.py:7-16) ------------------------
+// out[j] = Q(1 - alpha/2) - Q(alpha/2) of column j of chain[ns][np] (numpy's default "linear" quantile: virtual index q (ns - 1),
+// the two order statistics around it, numpy's lerp).  One thread per column -- adjacent threads read adjacent columns, every
+// pass over the samples is a fully coalesced sweep of the chain -- and an exact radix select on the order-preserving 64-bit
+// key of a double, two bits per pass, both quantiles in the same sweep: 32 sweeps for the two lower order statistics, one more
+// for their upper neighbours (the smallest key above, unless the statistic is repeated).  No sorting, no scratch memory.
+__device__ __forceinline__ uint64_t qkey(double x) {
+  const uint64_t u = (uint64_t)__double_as_longlong(x);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double qval(uint64_t k) {
+  const uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+__device__ __forceinline__ double np_lerp(double a, double b, double t) {  // numpy/lib/_function_base_impl.py: _lerp
+  const double d = b - a;
+  return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+}
+__global__ __launch_bounds__(256) void k_quantile_range(const double* __restrict__ chain, int64_t ns, int64_t np, int64_t ld,
+                                                        int64_t i_lo, double g_lo, int64_t i_hi, double g_hi, double* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= np) return;
+  const double* col = chain + j;
+  uint64_t pre[2] = {0, 0};                 // key prefixes found so far
+  int64_t rank[2] = {i_lo, i_hi};           // rank of the wanted statistic among the keys that share the prefix
+  for (int shift = 62; shift >= 0; shift -= 2) {
+    int64_t c[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    const uint64_t hi_mask = shift == 62 ? 0ull : (~0ull << (shift + 2));
+    for (int64_t s_ = 0; s_ < ns; ++s_) {
+      const uint64_t k = qkey(col[s_ * ld]);
+      const int d = (int)((k >> shift) & 3);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const bool m = (k & hi_mask) == pre[q];
+        c[q][0] += m && d == 0;
+        c[q][1] += m && d == 1;
+        c[q][2] += m && d == 2;
+        c[q][3] += m && d == 3;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int d = 0;
+      int64_t r_ = rank[q];
+      while (d < 3 && r_ >= c[q][d]) r_ -= c[q][d++];
+      rank[q] = r_;
+      pre[q] |= (uint64_t)d << shift;
+    }
+  }
+  // upper neighbours: the same value when it is repeated beyond the wanted rank, else the smallest key above
+  int64_t le[2] = {0, 0};
+  uint64_t up[2] = {~0ull, ~0ull};
+  for (int64_t s_ = 0; s_ < ns; ++s_) {
+    const uint64_t k = qkey(col[s_ * ld]);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      le[q] += k <= pre[q];
+      if (k > pre[q] && k < up[q]) up[q] = k;
+    }
+  }
+  const int64_t idx[2] = {i_lo, i_hi};
+  double v[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const double a = qval(pre[q]);
+    const double b = (le[q] > idx[q] + 1 || idx[q] + 1 >= ns) ? a : qval(up[q]);
+    v[q] = np_lerp(a, b, q ? g_hi : g_lo);
+  }
+  out[j] = v[1] - v[0];
+}
+
 extern "C" {
 
 int64_t pxm_reduce_scratch_doubles(int C) { return C >= 1 ? (int64_t)red_scratch_doubles(C) : -1; }
@@ -925,6 +997,29 @@ int pxm_wl_mask_scatter(const void* g, const int64_t* idx, const double* w, void
   PXM_REQUIRE(g && idx, "pxm_wl_mask_scatter: null buffer");
   hipLaunchKernelGGL(k_wl_scatter, ew_grid(ndata, C), dim3(256), 0, (hipStream_t)stream, (const double2*)g, idx, w,
                      (double2*)f, npix, ndata);
+  PXM_HIP(hipGetLastError());
+  return 0;
+}
+
+int pxm_quantile_range(const double* chain, int64_t nsamples, int64_t nparams, int64_t ld, double alpha, double* out,
+                       pxm_stream_t stream) {
+  PXM_REQUIRE(chain && out, "pxm_quantile_range: null buffer");
+  PXM_REQUIRE(nsamples >= 1 && nparams >= 1 && ld >= nparams, "pxm_quantile_range: bad shape");
+  PXM_REQUIRE(alpha >= 0.0 && alpha <= 1.0, "pxm_quantile_range: alpha must lie in [0, 1]");
+  // numpy.quantile, method "linear": virtual index q (n - 1), the order statistics floor and floor + 1, gamma the fraction
+  auto split = [&](double q, int64_t* i, double* g) {
+    const double vi = q * (double)(nsamples - 1);
+    double fl = std::floor(vi);
+    if (fl > (double)(nsamples - 1)) fl = (double)(nsamples - 1);
+    *i = (int64_t)fl;
+    *g = vi - fl;
+  };
+  int64_t i_lo, i_hi;
+  double g_lo, g_hi;
+  split(alpha / 2, &i_lo, &g_lo);
+  split(1 - alpha / 2, &i_hi, &g_hi);
+  hipLaunchKernelGGL(k_quantile_range, dim3((unsigned)((nparams + 255) / 256)), dim3(256), 0, (hipStream_t)stream, chain, nsamples,
+                     nparams, ld, i_lo, g_lo, i_hi, g_hi, out);
   PXM_HIP(hipGetLastError());
   return 0;
 }

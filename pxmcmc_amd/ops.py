@@ -231,6 +231,22 @@ def reduce_l1(X, w=None):
     return out
 
 
+def quantile_range(chain, alpha=0.05):
+    """Q(1 - alpha/2) - Q(alpha/2) of every column of a float64 [nsamples, nparams] tensor on the device
+    (pxmcmc/uncertainty.py:7-16; numpy.quantile's default method) -> float64 [nparams]."""
+    require_gpu()
+    c = chain if isinstance(chain, torch.Tensor) else as_device(np.asarray(chain, dtype=np.float64), _REAL)
+    if c.dim() != 2 or c.dtype != _REAL:
+        raise TypeError("quantile_range: a float64 [nsamples, nparams] array is expected")
+    if not c.is_cuda:
+        c = c.to(device())
+    if c.stride(1) != 1:
+        c = c.contiguous()
+    out = torch.empty(c.shape[1], dtype=_REAL, device=c.device)
+    check(lib.pxm_quantile_range(_p(c), c.shape[0], c.shape[1], c.stride(0), float(alpha), _p(out), _stream()))
+    return out
+
+
 def reduce_l2(preds, data, invcov):
     """vdot(d, invcov d), d = data - preds (pxmcmc/mcmc.py:78-79) -> complex128 [C]."""
     p, _ = _batched(as_device(preds))

@@ -352,3 +352,52 @@ def test_generic_engine_complex_noise_and_identity_operators():
     np.testing.assert_array_equal(np.asarray(g.chain), np.asarray(e.chain))
     Xc = np.asarray(g.X_curr.cpu())
     assert np.iscomplexobj(Xc) and Xc.imag.std() > 0.3 * Xc.real.std() > 0
+
+
+@pytest.mark.parametrize("ns,npar", [(1, 5), (2, 300), (37, 1000), (500, 257), (1001, 64)])
+def test_quantile_range_on_the_device_equals_numpy(ns, npar):
+    """uncertainty.credible_interval_range of a chain that is resident on the device (`pxm_quantile_range`: radix select of the two
+    order statistics around numpy's virtual index + numpy's lerp) against numpy.quantile (pxmcmc/uncertainty.py:7-16): the same
+    doubles, for several confidence levels, with repeated values, signed zeros, huge / tiny magnitudes and a strided view"""
+    import torch
+
+    from pxmcmc_amd import ops
+    from pxmcmc_amd.uncertainty import credible_interval_range, wavelet_credible_interval_range
+
+    rng = np.random.default_rng(ns * 7 + npar)
+    chain = rng.normal(size=(ns, npar)) * np.exp(rng.normal(size=npar) * 8)
+    chain[:, : npar // 4] = np.round(chain[:, : npar // 4] / np.abs(chain[:, : npar // 4]).max(axis=0) * 3)  # many ties, +-0.0
+    if npar > 8:
+        chain[:, 5] = 0.0
+        chain[::2, 6] = -0.0
+        chain[:, 7] = -1e300 * (np.arange(ns) % 3)
+    dev = torch.as_tensor(chain, device="cuda")
+    for alpha in (0.05, 0.3, 0.5, 1.0, 0.0, 1e-9):
+        want = np.diff(np.quantile(chain, (alpha / 2, 1 - alpha / 2), axis=0), axis=0)[0]
+        got = credible_interval_range(dev, alpha)
+        assert isinstance(got, torch.Tensor) and got.is_cuda
+        g = got.cpu().numpy()
+        assert np.array_equal(g, want), (alpha, np.abs(g - want).max())
+    # a strided view (every second column of a wider array)
+    wide = torch.as_tensor(np.repeat(chain, 2, axis=1), device="cuda")
+    assert np.array_equal(ops.quantile_range(wide[:, ::2], 0.05).cpu().numpy(), credible_interval_range(chain, 0.05))
+    # leading dimension larger than the row length (a column window of a contiguous array): no copy inside
+    win = wide[:, : npar]
+    assert win.stride(0) == 2 * npar
+    assert np.array_equal(ops.quantile_range(win, 0.1).cpu().numpy(), credible_interval_range(np.repeat(chain, 2, axis=1)[:, :npar], 0.1))
+
+
+def test_wavelet_credible_interval_maps_from_a_device_chain():
+    """uncertainty.wavelet_credible_interval_range (pxmcmc/uncertainty.py:19-40) on a device-resident chain == on the host copy"""
+    import torch
+
+    from pxmcmc_amd.uncertainty import wavelet_credible_interval_range
+
+    L, B, J = 10, 2, 2
+    rng = np.random.default_rng(3)
+    chain = rng.normal(size=(60, 528))
+    host = wavelet_credible_interval_range(chain, L, B, J)
+    devm = wavelet_credible_interval_range(torch.as_tensor(chain, device="cuda"), L, B, J)
+    assert len(host) == len(devm) == 4
+    for a, b in zip(host, devm):
+        assert a.shape == b.shape and np.array_equal(a, b)
