@@ -585,8 +585,11 @@ __device__ __forceinline__ double qval(uint64_t k) {
   return __longlong_as_double((long long)u);
 }
 __device__ __forceinline__ double np_lerp(double a, double b, double t) {  // numpy/lib/_function_base_impl.py: _lerp
+#pragma clang fp contract(off)  // separately rounded product and sum, as numpy evaluates them (hipcc contracts a + d * t by default)
   const double d = b - a;
-  return t >= 0.5 ? b - d * (1.0 - t) : a + d * t;
+  const double up = a + d * t;
+  const double dn = b - d * (1.0 - t);
+  return t >= 0.5 ? dn : up;
 }
 __global__ __launch_bounds__(256) void k_quantile_range(const double* __restrict__ chain, int64_t ns, int64_t np, int64_t ld,
                                                         int64_t i_lo, double g_lo, int64_t i_hi, double g_hi, double* __restrict__ out) {
