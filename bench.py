@@ -1006,8 +1006,9 @@ def main():
             # second kernel of the iteration, the larger share of its time: the grouped phi-DFT + prox + update + Philox
             # kernel is bound by fp64 VALU issue (Bluestein butterflies), not by HBM -- reported for completeness
             out["dft_kernel"] = {
-                "kernel": "k_ring2px_group5 (rings -> X' -> rings of every wavelet scale, one grid)",
-                "bound": "fp64 VALU issue + LDS transposes (4 waves per SIMD)",
+                "kernel": "k_ring2px_group5 (rings -> X' -> rings of every wavelet scale, one grid; the two 511-point scales by the "
+                          "exact-length unit 511 = 7 x 73 of csrc/dft_pfa.h, the smaller ones by Bluestein)",
+                "bound": "fp64 VALU issue (transforms + Philox / Box-Muller) and LDS transposes, 4 waves per SIMD: work per CU, no tail round",
                 "avg_launch_us": dms.value * 1e3 / dnl.value,
                 "launches": int(dnl.value),
                 "alg_bytes_per_launch": dnb.value / dnl.value,
