@@ -162,6 +162,8 @@ int pxm_wav_status(pxm_wav_plan_t plan, int clear, pxm_stream_t stream);
 int pxm_sht_status(pxm_sht_plan_t plan, int clear, pxm_stream_t stream);
 int pxm_wav_flow_status(pxm_wav_plan_t plan, pxm_stream_t stream);
 int pxm_wav_flow_enabled(pxm_wav_plan_t plan);
+/* scales whose 511-point rings the fused rings -> X' -> rings launch takes through the exact-length phi-DFT unit (0: Bluestein) */
+int pxm_wav_exact_dft_scales(pxm_wav_plan_t plan);
 
 /* Live kernel timing of one plan (bench.py roofline leg).  pxm_wav_profile_enable(plan, n) with n > 0 creates
  * n event pairs per kernel class; while enabled every SHT ring-GEMM launch and every grouped phi-DFT launch of

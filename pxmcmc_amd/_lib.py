@@ -35,6 +35,7 @@ SIGNATURES = {
     "pxm_wav_iter_counter_add": (c_int, [c_vp, c_u64, c_vp]),
     "pxm_wav_flow_status": (c_int, [c_vp, c_vp]),
     "pxm_wav_flow_enabled": (c_int, [c_vp]),
+    "pxm_wav_exact_dft_scales": (c_int, [c_vp]),
     "pxm_wav_status": (c_int, [c_vp, c_int, c_vp]),
     "pxm_sht_status": (c_int, [c_vp, c_int, c_vp]),
     "pxm_wav_profile_enable": (c_int, [c_vp, c_int]),

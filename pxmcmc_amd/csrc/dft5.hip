@@ -1592,6 +1592,7 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
     Dft5Group f = g;
     if (p.t5.pfa_off && p.R5 == 4) {
       any_pfa = true;
+      ++out->n_pfa;
       f.r0 = 9;
       f.pfa_off = p.t5.pfa_off;
       f.pfa_passes = (getenv("PXM_PFA_PASSES") && atoi(getenv("PXM_PFA_PASSES")) == 1) ? 1 : 2;
@@ -1678,6 +1679,7 @@ void dft_group_destroy(DftGroupList* g) {
   if (g->d_fused) deferred_free(g->d_fused);
   g->d = g->d_fused = nullptr;
   g->blocks_fused = 0;
+  g->n_pfa = 0;
   g->n = 0;
 }
 

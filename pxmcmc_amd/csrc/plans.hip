@@ -934,6 +934,13 @@ int pxm_wav_flow_enabled(pxm_wav_plan_t p) {
   return p->use_flow ? 1 : 0;
 }
 
+// number of scales whose rings the fused rings -> X' -> rings launch of this plan transforms with the exact-length unit
+// (csrc/dft_pfa.h: ring length 511), 0 when the launch is not grouped or PXM_DFT_PFA=0
+int pxm_wav_exact_dft_scales(pxm_wav_plan_t p) {
+  PXM_REQUIRE(p, "pxm_wav_exact_dft_scales: null plan");
+  return p->dft_group.d ? p->dft_group.n_pfa : 0;
+}
+
 int pxm_tables_trim(void) {
   const int64_t freed = tables_trim();
   return (int)std::min<int64_t>(freed >> 20, 1 << 30);  // MiB released

@@ -279,6 +279,7 @@ struct DftGroupList {
   // two rings per workgroup, other block counts); null = the list above
   void* d_fused = nullptr;
   int blocks_fused = 0;
+  int n_pfa = 0;  // member scales that take the exact-length unit in the fused launch
   bool five = false;  // descriptors of the eight-points-per-lane kernel (dft5.hip)
   int threads = 512;  // ... and its workgroup size
   int n = 0, blocks = 0;

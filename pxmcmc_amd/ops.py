@@ -672,6 +672,10 @@ class WavPlan:
         """0: every wait of the dataflow GEMM launches of this plan was satisfied (include/pxmcmc_amd.h); synchronises"""
         return int(check(lib.pxm_wav_flow_status(self._h, _stream())))
 
+    def exact_dft_scales(self):
+        """scales whose 511-point rings the fused step transforms with the exact-length unit (csrc/dft_pfa.h); 0 = Bluestein"""
+        return int(check(lib.pxm_wav_exact_dft_scales(self._h)))
+
     def flow_enabled(self):
         """True when the ring-space step of this plan takes the dataflow launch (PXM_FLOW=1; known after ring_set_data)"""
         return bool(check(lib.pxm_wav_flow_enabled(self._h)))

@@ -730,3 +730,61 @@ def test_config5_logtransition_and_propose_at_full_state_size():
         for got in (lt[c], lt2[c]):
             assert abs(got - want) <= 1e-12 * abs(want), (c, got, want)
             assert abs(got - want_exact) <= 1e-12 * abs(want_exact), (c, got, want_exact)
+
+
+# ---- (vii) the exact-length phi-DFT unit (511 = 7 x 73, csrc/dft_pfa.h) against the Bluestein unit it replaces ------------------
+@pytest.mark.parametrize("C,pairs", [(1, False), (3, False), (5, True), (8, True), (13, False)])
+def test_exact_length_dft_unit_equals_bluestein_unit_L256(monkeypatch, C, pairs):
+    """The fused rings -> X' -> rings launch at L = 256 takes the two 511-point scales through the exact-length unit (Good-Thomas
+    7 x 73 + Rader on Z_8 x Z_9; the phi stage of pys2let.synthesis_wav2px / synthesis_adjoint_px2wav, pxmcmc/transforms.py:126,138)
+    -- default --, through the Bluestein unit with PXM_DFT_PFA=0, and with one ring pair per workgroup with PXM_PFA_PASSES=1.
+    Three plans of each kind step the same states: slot counts that leave chain slots of the last group of four dead (1, 3, 5, 13)
+    and full groups (8); injected noise (complex slots / real pairs), the device Philox stream in both Box-Muller precisions
+    (same counters => the same deviates whichever unit draws them), several steps so that the rings carried in the plan are the
+    previous step's output.  The oracle comparison of both units is test_fused_myula_*_L256; this is unit against unit at
+    round-off: 1e-12 of the state scale."""
+    import torch
+
+    from pxmcmc_amd import ops
+
+    L, B, J_min, K = 256, 2, 2, 3
+    P = L * (2 * L - 1)
+    rng = np.random.default_rng(100 + C)
+    lmda, delta = 1e-6, 1e-7
+    plans = {}
+    for name, env in (("pfa", {}), ("bluestein", {"PXM_DFT_PFA": "0"}), ("one_pass", {"PXM_PFA_PASSES": "1"})):
+        for k in ("PXM_DFT_PFA", "PXM_PFA_PASSES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plans[name] = ops.WavPlan(L, B, J_min, max_chains=C)
+    assert [plans[k].exact_dft_scales() for k in ("pfa", "bluestein", "one_pass")] == [2, 0, 2]
+    N = plans["pfa"].ncoefs
+    data = rng.normal(size=P) + (0 if pairs else 1j * rng.normal(size=P))
+    dc = ops.as_device(np.asarray(data, dtype=complex), torch.complex128)
+    if pairs:
+        dc = torch.complex(dc.real, dc.real).contiguous()
+    T_dev = ops.as_device(np.abs(rng.normal(size=N)) * 1e-7, torch.float64)
+    X0 = ops.as_device((rng.normal(size=(C, N)) + 1j * rng.normal(size=(C, N))) * 1e-3, torch.complex128)
+    w = complex(400.0, -35.0) if not pairs else complex(400.0)
+    noise_c = [ops.as_device(rng.normal(size=(C, N))) for _ in range(K)]                 # real noise, complex slots
+    noise_p = [ops.as_device(rng.normal(size=(2 * C, N))) for _ in range(K)]             # one row per real chain
+    for mode in ("injected", "philox64", "philox32"):
+        res = {}
+        for name, plan in plans.items():
+            plan.ring_set_data(dc)
+            X = X0.clone()
+            out = torch.empty_like(X)
+            plan.ring_init(X)
+            for k in range(K):
+                if mode == "injected":
+                    plan.ring_step(X, w, T_dev, delta, lmda, noise=(noise_p if pairs else noise_c)[k], out=out, pairs=pairs)
+                else:
+                    plan.ring_step(X, w, T_dev, delta, lmda, seed=77, chain0=4, it=k, out=out, pairs=pairs, noise64=mode == "philox64")
+                X, out = out, X
+            res[name] = (X.cpu().numpy(), plan.ring_preds(C).cpu().numpy())
+            assert plan.status() == 0
+        for other in ("bluestein", "one_pass"):
+            for a, b in zip(res["pfa"], res[other]):
+                assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (mode, other, np.abs(a - b).max() / np.abs(b).max())
+        assert np.array_equal(res["pfa"][0], res["one_pass"][0])  # (the same arithmetic, other workgroup shapes)
