@@ -109,7 +109,7 @@ def raise_on_status(status, what):
     if status:
         bits = []
         if status & STATUS_PAIR_SYNC:
-            bits.append("a wave-pair wait of the fused phi-DFT kernels expired (csrc/dft5.hip, d5_pair_sync)")
+            bits.append("a wave-pair wait or ring-group wait of the fused phi-DFT kernels expired (csrc/dft5.hip: d5_pair_sync, pfa_group_sync)")
         if status & STATUS_FLOW_WAIT:
             bits.append("a wait of the dataflow GEMM launch expired (PXM_FLOW=1)")
         if status & ~(STATUS_PAIR_SYNC | STATUS_FLOW_WAIT):

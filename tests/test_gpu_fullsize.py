@@ -788,3 +788,33 @@ def test_exact_length_dft_unit_equals_bluestein_unit_L256(monkeypatch, C, pairs)
             for a, b in zip(res["pfa"], res[other]):
                 assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (mode, other, np.abs(a - b).max() / np.abs(b).max())
         assert np.array_equal(res["pfa"][0], res["one_pass"][0])  # (the same arithmetic, other workgroup shapes)
+
+
+def test_exact_length_dft_unit_reports_an_expired_group_wait(monkeypatch):
+    """The four waves of a ring group of the exact-length unit synchronise through an LDS counter with a BOUNDED spin; a wait that
+    expires must set the plan's status word (PXM_STATUS_PAIR_SYNC), which the samplers poll -- never a hang, never a silently
+    corrupted chain (pxmcmc/mcmc.py:104-109: the reference raises on bad state).  PXM_DEBUG_PAIR_SYNC_LIMIT=0 forces every wait to
+    expire; a plan created without it reports 0 for the same step."""
+    import torch
+
+    from pxmcmc_amd import ops
+    from pxmcmc_amd._lib import STATUS_PAIR_SYNC, PxmError
+
+    L, B, J_min, C = 256, 2, 2, 4
+    rng = np.random.default_rng(9)
+    good = ops.WavPlan(L, B, J_min, max_chains=C)
+    monkeypatch.setenv("PXM_DEBUG_PAIR_SYNC_LIMIT", "0")
+    bad = ops.WavPlan(L, B, J_min, max_chains=C)
+    monkeypatch.delenv("PXM_DEBUG_PAIR_SYNC_LIMIT")
+    assert good.exact_dft_scales() == 2 and bad.exact_dft_scales() == 2
+    d = ops.as_device(rng.normal(size=L * (2 * L - 1)) + 0j, torch.complex128)
+    X = ops.as_device(rng.normal(size=(C, good.ncoefs)) * 1e-3 + 0j, torch.complex128)
+    for plan in (good, bad):
+        plan.ring_set_data(d)
+        plan.ring_init(X)
+        plan.ring_step(X, 400.0, 1e-7, 1e-7, 1e-6, seed=1, it=0)
+    assert good.status() == 0
+    assert bad.status() & STATUS_PAIR_SYNC
+    with pytest.raises(PxmError, match="wait"):
+        bad.raise_on_fault()
+    assert bad.status() == 0  # (read-and-cleared by raise_on_fault)
