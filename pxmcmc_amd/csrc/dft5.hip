@@ -703,7 +703,7 @@ __device__ __forceinline__ void pfa_group_sync(unsigned* cnt, unsigned target, i
 // bxw: workgroup index along the rings; the workgroup takes the ring pairs bxw * passes + ps, ps < passes, one after the
 // other (passes = 2: half as many workgroups -- with one such workgroup per CU the latency-bound workgroups of the small
 // scales are resident from the start of the launch instead of forming a second round).
-template <bool N64>
+template <bool RING_OUT, bool N64>
 __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTabs& pt, double* __restrict__ G, int ncol,
                                                  const PxOut& out, int C, int bxw, int by, int passes, double2* lds5) {
   if ((by << 2) >= C) return;
@@ -908,11 +908,18 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
 #pragma unroll
       for (int u = 0; u < 4; ++u) x[u] = double2{0.0, 0.0};  // padding chains / rings: their rings are kept at zero
     }
+    if (RING_OUT) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) D5_PW(plane[lane + 64 * (g0 + u)], x[u]);
+      for (int u = 0; u < 4; ++u) D5_PW(plane[lane + 64 * (g0 + u)], x[u]);
+    }
 #ifdef PXM_D5_TRACE
     if (g0 == 0) PXM_D5_STAMP(3) else PXM_D5_STAMP(4)  // first / second half of the epilogue done
 #endif
+  }
+  if (!RING_OUT) {  // plain rings -> pixels: the pass ends here; the next ring may be staged once every plane of the group is dead
+    PXM_PFA_RING_LOAD(ps + 1 < passes ? (bxw * passes + ps + 1) * 2 + grp : a.L)
+    if (ps + 1 < passes) pfa_group_sync(gcnt, epoch += 4, lane, sy);
+    continue;
   }
   // ---- forward transform of the updated ring: natural order -> S1 layout through the plane
   d5_wave_sync();
@@ -964,6 +971,107 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
   }  // passes
 #undef PXM_PFA_THREAD_SETUP
 #undef PXM_PFA_RING_LOAD
+}
+
+// pixels -> rings of the same unit (the plain forward phi-DFT of a 511-point scale: px2ring_body5's job): every wave loads its
+// ring in natural order straight into its plane, gathers the S1 layout, transforms, and the four waves of a ring group put the
+// result through the group's stage into 64-B segments of the ring array.  ZFILL as in PXM_D5_STORE_RINGS(true): the last live
+// chain group also zeroes the padding slots of its (m, ring) lines.
+__device__ __forceinline__ void px2ring_body_pfa(const Dft5Args& a, const PfaTabs& pt, const PxIn& in, double* __restrict__ G, int ncol,
+                                                 int C, int bxw, int by, int passes, double2* lds5) {
+  if ((by << 2) >= C) return;
+  constexpr int n = PFA_N, R = 4, S = PFA_STAGE_S;
+  unsigned epoch = 0;
+  const D5Sync sy{a.err, a.spin_limit};
+  {
+    const int tid = threadIdx.x;
+    double2* B2l = lds5 + 8 * PFA_PLANE;
+    if (tid < 72) B2l[tid] = pt.B2[tid];
+    if (tid < 2) reinterpret_cast<unsigned*>(B2l + 72 + NOISE_LOG_N + 256)[tid] = 0;
+  }
+  d5_barrier();
+#pragma nounroll
+  for (int ps = 0; ps < passes; ++ps) {
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // (see ring2px_body_pfa: nothing derived from the thread id is hoisted out of the pass loop)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int r = wave & 3, grp = wave >> 2;
+    const int c0 = by * R, ch = c0 + r;
+    const int Cp = ncol >> 1;
+    double2* stage = lds5 + grp * (4 * PFA_PLANE);
+    double2* plane = lds5 + wave * PFA_PLANE;
+    const double2* B2l = lds5 + 8 * PFA_PLANE;
+    unsigned* const gcnt = reinterpret_cast<unsigned*>(lds5 + 8 * PFA_PLANE + 72 + NOISE_LOG_N + 256) + grp;
+    const int j1m = lane >> 3;
+    const int x0k = (73 * (j1m < 7 ? j1m : 6)) % n;
+    const int t = (bxw * passes + ps) * 2 + grp;
+    const bool tv = t < a.L;
+    const bool act = ch < C && tv;
+    const int64_t e_ring = in.ring0 + (int64_t)(tv ? t : 0) * n;
+#pragma unroll
+    for (int g0 = 0; g0 < 8; g0 += 4) {  // the lane's elements lane + 64 p, four at a time (see px2ring_body5)
+      int64_t ev[4];
+      bool ok[4];
+      double2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = lane + 64 * (g0 + u);
+        ok[u] = act && j < n;
+        ev[u] = e_ring + (j < n ? j : 0);
+      }
+      if (ch < C) px_in_load_n<4>(in, ch, ev, ok, v);
+      else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = double2{0.0, 0.0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) D5_PW(plane[lane + 64 * (g0 + u)], v[u]);  // (lane 63, p = 7: slot 511, a zero)
+    }
+    d5_wave_sync();
+    double2 z[8], o1[7], o2[7];
+    double2 x0;
+    {
+      const char* pb_ = reinterpret_cast<const char*>(plane);
+      const uint4 gv = reinterpret_cast<const uint4*>(pt.gat)[lane];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) D5_PR(z[q], *reinterpret_cast<const double2*>(pb_ + pfa_u16(gv, q)));
+      D5_PR(x0, plane[x0k]);
+    }
+    d5_wave_sync();
+    pfa511_core(z, x0, o1, o2, plane, B2l, lane);
+    pfa_group_sync(gcnt, epoch += 4, lane, sy);  // every plane of the group is dead: its stage may be written
+    {
+      char* sb = reinterpret_cast<char*>(stage + r * S);
+      const uint4 kv1 = reinterpret_cast<const uint4*>(pt.kidx)[lane];
+      const uint4 kv2 = reinterpret_cast<const uint4*>(pt.kidx)[64 + (lane < 9 ? lane : 8)];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) *reinterpret_cast<double2*>(sb + pfa_u16(kv1, k)) = o1[k];
+      if (lane < 9) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) *reinterpret_cast<double2*>(sb + pfa_u16(kv2, k)) = o2[k];
+      }
+    }
+    pfa_group_sync(gcnt, epoch += 4, lane, sy);
+    {  // stage -> G rows of the ring
+      const int rr = tid & (R - 1), kq = (tid & 255) >> 2;
+      const int mstride = a.Rp * Cp;
+      double2* const Gc = reinterpret_cast<double2*>(G) + c0 + rr;
+      const bool zf = c0 + R >= C;
+      if (c0 + rr < Cp && tv) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int k = kq + 64 * i;
+          if (k < n) {
+            double2* line = Gc + ((k < a.L) ? k + a.L - 1 : k - a.L) * mstride + t * Cp;
+            *line = stage[rr * S + k];
+            if (zf)
+              for (int zz = R; c0 + rr + zz < Cp; zz += R) line[zz] = double2{0.0, 0.0};
+          }
+        }
+      }
+    }
+    if (ps + 1 < passes) pfa_group_sync(gcnt, epoch += 4, lane, sy);  // the stage has been read
+  }
 }
 
 template <int R0>
@@ -1040,15 +1148,13 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px_group5(const Dft5G
     for (int i = threadIdx.x; i < n_zero; i += 512) zero_words[i] = 0;
   PXM_D5_GROUP_DECODE
   out.ring0 = g.ring0;
-  if constexpr (RING_OUT) {
-   if (g.r0 == 9) {  // exact-length unit (entries of the fused launch's own list only)
+  if (g.r0 == 9) {  // exact-length unit (entries of the lists with the workgroup shape of that unit: DftGroupList::d_fused)
     const double* pb = ws + g.tbase + g.pfa_off;
     const PfaTabs pt{reinterpret_cast<const uint16_t*>(pb + PFA_TAB_GAT), reinterpret_cast<const uint16_t*>(pb + PFA_TAB_KIDX),
                      reinterpret_cast<const double2*>(pb + PFA_TAB_B2)};
     // (pfa_passes = 2: half as many workgroups, each taking two ring pairs in turn -- with one such workgroup per CU the
     // latency-bound workgroups of the small scales are resident from the start instead of forming a second round)
-    ring2px_body_pfa<N64>(a, pt, G, ncol, out, C, bx, by, g.pfa_passes, lds5);
-   }
+    ring2px_body_pfa<RING_OUT, N64>(a, pt, G, ncol, out, C, bx, by, g.pfa_passes, lds5);
   }
 #ifndef PXM_D5_ONLY_PFA  // (development aid: an assembly listing of the exact-length body alone)
   switch (g.r0) {
@@ -1080,6 +1186,13 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_px2ring_group5(const Dft5G
   if (in.bump && blockIdx.x == 0 && threadIdx.x == 0) *in.bump += 1;
   PXM_D5_GROUP_DECODE
   in.ring0 = g.ring0;
+  if (g.r0 == 9) {
+    const double* pb = ws + g.tbase + g.pfa_off;
+    const PfaTabs pt{reinterpret_cast<const uint16_t*>(pb + PFA_TAB_GAT), reinterpret_cast<const uint16_t*>(pb + PFA_TAB_KIDX),
+                     reinterpret_cast<const double2*>(pb + PFA_TAB_B2)};
+    px2ring_body_pfa(a, pt, in, G, ncol, C, bx, by, g.pfa_passes, lds5);
+    return;
+  }
   switch (g.r0) {
     case 8: px2ring_body5<8>(a, in, G, ncol, C, bx, by, lds5); break;
     case 4: px2ring_body5<4>(a, in, G, ncol, C, bx, by, lds5); break;
@@ -1590,7 +1703,7 @@ int dft5_group_create(const std::vector<const DftPlan*>& plans, const std::vecto
     // the fused launch's entry of the same scale: n = 511 takes the exact-length body (one wave per ring unit: two rings
     // x four chain slots per workgroup, half the workgroups)
     Dft5Group f = g;
-    if (p.t5.pfa_off && p.R5 == 4) {
+    if (p.t5.pfa_off && p.R5 == 4 && ncol >= 8) {  // (eight-slot lines only: the narrow arrays of one-chain plans keep the Bluestein unit)
       any_pfa = true;
       ++out->n_pfa;
       f.r0 = 9;
@@ -1705,20 +1818,22 @@ int dft5_group_launch(const DftGroupList& g, double* ws, int ncol, const PxOut& 
 
 int dft5_group_px2ring(const DftGroupList& g, double* ws, int ncol, const PxIn& in, int C, hipStream_t st) {
   PXM_REQUIRE(in.gidx || g.ring_end <= in.chain_stride, "dft5_group_px2ring: a scale's coefficient block ends past chain_stride");
-  hipLaunchKernelGGL(k_px2ring_group5, dim3(g.blocks), dim3(g.threads), g.lds, st, reinterpret_cast<const Dft5Group*>(g.d), g.n,
-                     ws, ncol, in, C);
+  hipLaunchKernelGGL(k_px2ring_group5, dim3(g.d_fused ? g.blocks_fused : g.blocks), dim3(g.threads), g.lds, st,
+                     reinterpret_cast<const Dft5Group*>(g.d_fused ? g.d_fused : g.d), g.n, ws, ncol, in, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }
 
 int dft5_group_ring2px(const DftGroupList& g, double* ws, int ncol, const PxOut& out, int C, hipStream_t st) {
   PXM_REQUIRE(out.gidx || g.ring_end <= out.chain_stride, "dft5_group_ring2px: a scale's coefficient block ends past chain_stride");
+  const Dft5Group* ents = reinterpret_cast<const Dft5Group*>(g.d_fused ? g.d_fused : g.d);
+  const int blocks = g.d_fused ? g.blocks_fused : g.blocks;
   if (out.X && !out.noise && out.noise64)
-    hipLaunchKernelGGL((k_ring2px_group5<false, true>), dim3(g.blocks), dim3(g.threads), g.lds, st,
-                       reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, (unsigned*)nullptr, 0);
+    hipLaunchKernelGGL((k_ring2px_group5<false, true>), dim3(blocks), dim3(g.threads), g.lds, st, ents, g.n, ws, ncol, out, C,
+                       (unsigned*)nullptr, 0);
   else
-    hipLaunchKernelGGL((k_ring2px_group5<false, false>), dim3(g.blocks), dim3(g.threads), g.lds, st,
-                       reinterpret_cast<const Dft5Group*>(g.d), g.n, ws, ncol, out, C, (unsigned*)nullptr, 0);
+    hipLaunchKernelGGL((k_ring2px_group5<false, false>), dim3(blocks), dim3(g.threads), g.lds, st, ents, g.n, ws, ncol, out, C,
+                       (unsigned*)nullptr, 0);
   PXM_HIP(hipGetLastError());
   return 0;
 }

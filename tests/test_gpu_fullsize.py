@@ -788,6 +788,22 @@ def test_exact_length_dft_unit_equals_bluestein_unit_L256(monkeypatch, C, pairs)
             for a, b in zip(res["pfa"], res[other]):
                 assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (mode, other, np.abs(a - b).max() / np.abs(b).max())
         assert np.array_equal(res["pfa"][0], res["one_pass"][0])  # (the same arithmetic, other workgroup shapes)
+    # the plain launches of the same unit (blocks -> rings of every scale in one grid and back: the four wavelet transforms,
+    # pxmcmc/transforms.py:101-154) and the image-space step (its grouped launches; the L-level launches keep the Bluestein unit)
+    f = ops.as_device(rng.normal(size=(C, P)) + 1j * rng.normal(size=(C, P)), torch.complex128)
+    ops_out = {}
+    for name, plan in plans.items():
+        ops_out[name] = [t.cpu().numpy() for t in (plan.synthesis(X0), plan.synthesis_adjoint(f), plan.analysis(f), plan.analysis_adjoint(X0))]
+        invc = ops.as_device(400.0 * (1 + 0.3 * np.cos(np.arange(P) * 0.01)), torch.float64)
+        Pd = plan.synthesis(X0)
+        plan.image_init(Pd, dc, invc)
+        Xn = torch.empty_like(X0)
+        plan.image_step(X0, dc, invc, T_dev, delta, lmda, noise=(noise_p if pairs else noise_c)[0], out=Xn, preds_out=Pd, pairs=pairs)
+        ops_out[name] += [Xn.cpu().numpy(), Pd.cpu().numpy()]
+        assert plan.status() == 0
+    for other in ("bluestein", "one_pass"):
+        for a, b in zip(ops_out["pfa"], ops_out[other]):
+            assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (other, np.abs(a - b).max() / np.abs(b).max())
 
 
 def test_exact_length_dft_unit_reports_an_expired_group_wait(monkeypatch):
