@@ -79,6 +79,7 @@ struct Dft5Args {
   const double2* bO;    // [r0][64] the odd bins
   unsigned* err;        // status word of the owning plan (bit PXM_STATUS_PAIR_SYNC: a pair wait expired) or null
   unsigned spin_limit;  // bound of the pair wait (1 << 18; PXM_DEBUG_PAIR_SYNC_LIMIT at plan creation forces an expiry)
+  const double* pfa;    // n = 511: table block of the exact-length unit (dft_pfa.h) for the single-scale launches, or null
 };
 
 // one scale of a grouped launch
@@ -1079,6 +1080,14 @@ __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_px2ring5(Dft5Args a, PxIn 
                                                                                  int ncol, int C) {
   extern __shared__ double2 lds5[];
   if (in.bump && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *in.bump += 1;
+  if constexpr (R0 == 8) {
+    if (a.pfa && ncol >= 8) {  // exact-length unit (the launch wrapper sized the grid for it: one ring pair per workgroup)
+      const PfaTabs pt{reinterpret_cast<const uint16_t*>(a.pfa + PFA_TAB_GAT), reinterpret_cast<const uint16_t*>(a.pfa + PFA_TAB_KIDX),
+                       reinterpret_cast<const double2*>(a.pfa + PFA_TAB_B2)};
+      px2ring_body_pfa(a, pt, in, G, ncol, C, blockIdx.x, blockIdx.y, 1, lds5);
+      return;
+    }
+  }
   px2ring_body5<R0>(a, in, G, ncol, C, blockIdx.x, blockIdx.y, lds5);
 }
 
@@ -1086,6 +1095,14 @@ template <int R0, bool RING_OUT, bool N64>
 __global__ __launch_bounds__(128 * D5_RMAX, 4) void k_ring2px5(Dft5Args a, double* __restrict__ G, int ncol,
                                                                                  PxOut out, int C) {
   extern __shared__ double2 lds5[];
+  if constexpr (R0 == 8) {
+    if (a.pfa && ncol >= 8) {
+      const PfaTabs pt{reinterpret_cast<const uint16_t*>(a.pfa + PFA_TAB_GAT), reinterpret_cast<const uint16_t*>(a.pfa + PFA_TAB_KIDX),
+                       reinterpret_cast<const double2*>(a.pfa + PFA_TAB_B2)};
+      ring2px_body_pfa<RING_OUT, N64>(a, pt, G, ncol, out, C, blockIdx.x, blockIdx.y, 1, lds5);
+      return;
+    }
+  }
   ring2px_body5<R0, RING_OUT, N64>(a, G, ncol, out, C, blockIdx.x, blockIdx.y, lds5);
 }
 
@@ -1600,7 +1617,7 @@ static Dft5Args dft5_args(const DftPlan& p) {
   const Dft5Tables& t = p.t5;
   auto c = [](const double* x) { return reinterpret_cast<const double2*>(x); };
   return Dft5Args{p.L, p.n, p.Rp, p.R5 == 4 ? 2 : (p.R5 == 2 ? 1 : 0), c(t.cE), c(t.cO), c(t.dO), c(t.tw1), c(t.wt), c(t.bE), c(t.bO),
-                  p.d_status, p.spin_limit};
+                  p.d_status, p.spin_limit, (t.pfa_off && p.R5 == 4) ? t.d_all + t.pfa_off : nullptr};
 }
 
 template <int R0>
@@ -1619,9 +1636,10 @@ static int dft5_attr() {
 template <int R0>
 static int px2ring5_r(const DftPlan& p, const PxIn& in, double* G, int ncol, int C, hipStream_t st) {
   if (int rc = dft5_attr<R0>()) return rc;
-  const int Cp = ncol / 2, rings = p.TR5 * (8 / R0);
+  const Dft5Args da = dft5_args(p);
+  const int Cp = ncol / 2, rings = (R0 == 8 && da.pfa && ncol >= 8) ? 2 : p.TR5 * (8 / R0);  // (exact-length unit: two rings per workgroup)
   dim3 grid((p.L + rings - 1) / rings, (Cp + p.R5 - 1) / p.R5), block(128 * p.R5);
-  hipLaunchKernelGGL((k_px2ring5<R0>), grid, block, p.lds5, st, dft5_args(p), in, G, ncol, C);
+  hipLaunchKernelGGL((k_px2ring5<R0>), grid, block, p.lds5, st, da, in, G, ncol, C);
   PXM_HIP(hipGetLastError());
   return 0;
 }
@@ -1629,7 +1647,7 @@ static int px2ring5_r(const DftPlan& p, const PxIn& in, double* G, int ncol, int
 template <int R0>
 static int ring2px5_r(const DftPlan& p, const double* G, int ncol, const PxOut& out, int C, hipStream_t st, bool ring_out) {
   if (int rc = dft5_attr<R0>()) return rc;
-  const int rings = p.TR5 * (8 / R0);
+  const int rings = (R0 == 8 && dft5_args(p).pfa && ncol >= 8) ? 2 : p.TR5 * (8 / R0);  // (exact-length unit: two rings per workgroup)
   dim3 grid((p.L + rings - 1) / rings, (C + p.R5 - 1) / p.R5), block(128 * p.R5);
   // (the fp64-noise instantiations only where the launch draws Philox noise in double precision)
   const bool n64 = out.X && !out.noise && out.noise64;

@@ -789,7 +789,8 @@ def test_exact_length_dft_unit_equals_bluestein_unit_L256(monkeypatch, C, pairs)
                 assert np.isfinite(a).all() and np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), (mode, other, np.abs(a - b).max() / np.abs(b).max())
         assert np.array_equal(res["pfa"][0], res["one_pass"][0])  # (the same arithmetic, other workgroup shapes)
     # the plain launches of the same unit (blocks -> rings of every scale in one grid and back: the four wavelet transforms,
-    # pxmcmc/transforms.py:101-154) and the image-space step (its grouped launches; the L-level launches keep the Bluestein unit)
+    # pxmcmc/transforms.py:101-154) and the image-space step (grouped launches and the single-scale L-level launches, incl. the
+    # rings -> image -> residual -> rings kernel)
     f = ops.as_device(rng.normal(size=(C, P)) + 1j * rng.normal(size=(C, P)), torch.complex128)
     ops_out = {}
     for name, plan in plans.items():
