@@ -846,6 +846,25 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
         for (int u = 0; u < 4; ++u) wn[u] = double2{0.0, 0.0};
       }
       __builtin_amdgcn_sched_barrier(0);
+#if !(PXM_D5_ABLATE & 1) && !defined(PXM_NOISE_F64_POLY) && !defined(PXM_PFA_NO_SPLIT_NOISE)
+      // fp64 noise of a chain pair (the benchmarked mode): the Philox bits of the four elements first -- four independent
+      // integer chains --, then the fp64 Box-Muller step element by element (its ~40 live registers are why the elements
+      // are not interleaved there)
+      if (N64 && !out.noise && out.mode == PXM_MODE_REAL_PAIRS && !(out.chain0 & 1)) {
+        uint4 pbits[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          pbits[u] = philox_bits(out.seed + PXM_PAIR_TWEAK, (out.chain0 >> 1) + ch_s, (uint64_t)(e0 + 64 * (g0 + u)), it_eff);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const NormalPair q_ = normal_pair_from_bits_tabs(pbits[u], logt, sct);
+          wph[u] = double2{q_.z0, q_.z1};
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else
+#endif
+      {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         wph[u] = double2{0.0, 0.0};
@@ -858,6 +877,7 @@ __device__ __forceinline__ void ring2px_body_pfa(const Dft5Args& a, const PfaTab
 #endif
 #endif
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
       if (N64) {
 #pragma unroll

@@ -194,6 +194,21 @@ __device__ inline NormalPair philox_normal_pair_t(uint64_t seed, uint64_t chain,
   if (F64) return box_muller_f64(u1, u2);
   return box_muller_fast(u1, u2);
 }
+// The two halves of philox_normal_pair_tabs as separate calls: the counter-based bits of a draw (integer pipeline: 20 dependent
+// 32 x 32 -> 64-bit products) and the Box-Muller step on them.  A kernel that draws several elements per lane forms the bits of
+// all of them first -- independent chains the scheduler interleaves, four registers per element -- and runs the register-hungry
+// fp64 step one element at a time.
+__device__ inline uint4 philox_bits(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter) {
+  const uint64_t key = seed + chain * 0x9E3779B97F4A7C15ull;
+  uint32_t c[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)iter, (uint32_t)(iter >> 32)};
+  philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+  return uint4{c[0], c[1], c[2], c[3]};
+}
+__device__ inline NormalPair normal_pair_from_bits_tabs(const uint4 c, const double2* logt, const double2* sct) {
+  const uint64_t a = (((uint64_t)c.y << 32) | c.x) >> 11;
+  const uint64_t b = (((uint64_t)c.w << 32) | c.z) >> 11;
+  return box_muller_f64_tab(((double)a + 0.5) * 0x1.0p-53, ((double)b + 0.5) * 0x1.0p-53, logt, sct);
+}
 // the fp64 form with the caller's copies of the Box-Muller tables (same deviates, bit for bit)
 __device__ inline NormalPair philox_normal_pair_tabs(uint64_t seed, uint64_t chain, uint64_t index, uint64_t iter, const double2* logt,
                                                      const double2* sct) {
