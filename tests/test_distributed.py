@@ -176,8 +176,28 @@ RANKS8_WORKER = textwrap.dedent(
     per_rank = D.all_gather_float(0.001 * (1 + rank))
     seen = D.count_ranks()
     D.barrier()
+    # BASELINE configs[4] on N ranks: bench.config5_multirank_leg itself (its all-gathers, in its order) with the GPU work of a
+    # rank replaced by a stand-in -- every rank "runs" its own chain (chain id = rank) and reports its own figures
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_w", os.path.join(os.environ["PXM_ROOT"], "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class _Op:
+        def _wl_plan(self):
+            return object()
+
+    bench.config5_problem = lambda: (_Op(), None, None, None, 5e-7)
+    bench.config5_tuned = lambda op, reg, tr, lmda, chain_offset=0, cap=0: {
+        "ms_per_iteration": 0.5 + 0.01 * chain_offset, "acceptance_in_timed_stretch": 0.4 + 0.01 * chain_offset,
+        "delta_at_start_of_stretch": 1e-10 * (1 + chain_offset), "iterations_before_timed_stretch": 700 + 50 * chain_offset,
+        "tuned": chain_offset != 3, "finite": True}
+    torch.cuda.synchronize = lambda: None
+    leg = bench.config5_multirank_leg(rank, world, D, cap=1234)
+    D.barrier()
     if rank == 0:
-        print(json.dumps({"ranks_seen": seen, "max": dt, "per_rank": per_rank}), flush=True)
+        print(json.dumps({"ranks_seen": seen, "max": dt, "per_rank": per_rank, "config5": leg}), flush=True)
     """
 )
 
@@ -215,6 +235,13 @@ def test_eight_rank_rendezvous_through_bench_self_launch(tmp_path, capfd):
     out = json.loads(line[0])
     assert out["ranks_seen"] == 8 and abs(out["max"] - 0.008) < 1e-12
     assert np.allclose(out["per_rank"], 0.001 * np.arange(1, 9))
+    c5 = out["config5"]  # one PxMALA chain per rank ("8 chains on 8 GPUs"): per-rank figures in rank order, max / sum rules
+    assert c5["ranks_seen"] == 8 and "error" not in c5 and c5["finite"] is True and c5["iterations_run"] == 1234
+    assert np.allclose(c5["per_rank_ms_per_iteration"], 0.5 + 0.01 * np.arange(8)) and abs(c5["ms_per_iteration"] - 0.57) < 1e-12
+    assert abs(c5["samples_per_s"] - 8e3 / 0.57) < 1e-6 and abs(c5["samples_per_s_sum_of_ranks"] - sum(1e3 / (0.5 + 0.01 * k) for k in range(8))) < 1e-6
+    assert np.allclose(c5["per_rank_acceptance"], 0.4 + 0.01 * np.arange(8)) and np.allclose(c5["per_rank_delta"], 1e-10 * np.arange(1, 9))
+    assert c5["per_rank_iterations_before_timed_stretch"] == [700 + 50 * k for k in range(8)]
+    assert c5["per_rank_tuned"] == [k != 3 for k in range(8)]
 
 
 def test_bench_leg_failures_turn_the_exit_code_red():
