@@ -664,9 +664,11 @@ __device__ __forceinline__ void ring2px_body5(const Dft5Args& a, double* __restr
 
 // =============================================================================================================
 // Exact-length path for n = 511 (bandlimit 256): ONE wave per ring unit, Good-Thomas 7 x 73 + Rader over 8 x 9 (dft_pfa.h).
-// Workgroup = 8 waves = 2 rings x 4 chain slots; the rings are staged in LDS like above (64-B segments of the ring
-// arrays), every transpose of the transform is local to a wave.  Only the fused rings -> X' -> rings launch takes this
-// body (RING_OUT); PXM_DFT_PFA=0 at plan creation keeps the Bluestein unit for A/B runs and the variant tests.
+// Workgroup = 8 waves = two ring groups of four waves (one ring x four chain slots each); a group stages its ring in LDS
+// (64-B segments of the ring arrays) and synchronises through its own LDS counter, every transpose of the transform is
+// local to a wave.  Every launch of a 511-point scale on eight-slot lines takes these bodies (fused rings -> X' -> rings,
+// plain rings -> pixels, pixels -> rings; grouped and single-scale); PXM_DFT_PFA=0 at plan creation keeps the Bluestein
+// unit for A/B runs and the unit-against-unit test; the narrow arrays of one-chain plans keep it too.
 // =============================================================================================================
 }  // namespace pxm
 #include "dft_pfa.h"
