@@ -20,6 +20,10 @@ transpose wave-local:
   S4  DFT7 j1 -> k1:          y[k], k = CRT511(k1, k2(inst))
   T5  plane[k]                                   -> natural order, lane + 64 r   (pixel stage / ring stage of the kernel)
 
+(The kernel, csrc/dft_pfa.h, differs from this model in one piece of plumbing: lane 63 idles through S1 / S3 and the seven x0
+elements are read by the S2 lanes (j1, k8 = 0) where they gather their inputs -- the same arithmetic, seven predicated LDS
+writes fewer per transpose.  Its host tables are compared with `tables()` below by tests/test_host_and_abi.py.)
+
 `python scripts/dev/proto_pfa511.py` checks the model against numpy.fft (<= 1e-13), prints the fp64 operation count per
 ring transform (FMA = 1, as issued) beside the 2 x 552 per lane of the Bluestein pair, the LDS instructions and their
 array cycles with the bank rules of MI355X_MICROARCH.md (ds_write_b128: groups of 8 contiguous lanes, banks mod 32;
