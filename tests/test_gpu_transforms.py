@@ -158,7 +158,9 @@ def test_dft_kernel_variants_agree_and_match_oracle(L, monkeypatch):
     """The phi-DFT of every L <= 256 has two kernels: eight points per lane, one half-size convolution per wave
     (default, csrc/dft5.hip; also with 2 chains per workgroup, PXM_DFT_R=2), and the independent radix-2 in-LDS
     kernels (PXM_DFT_NO_W=1, csrc/dft.hip).  All four SHT operators through each of them match the oracle; L covers every
-    Mh = 64 ... 512 (8, 4, 2, 1 rings per wave pair) and lengths that are not powers of two."""
+    Mh = 64 ... 512 (8, 4, 2, 1 rings per wave pair) and lengths that are not powers of two.  At L = 256 (ring length 511 =
+    7 x 73) the default is the exact-length unit (csrc/dft_pfa.h) and PXM_DFT_PFA=0 the Bluestein unit: both are held to the
+    oracle here."""
     from oracle import ssht
     from pxmcmc_amd import ops
 
@@ -173,7 +175,7 @@ def test_dft_kernel_variants_agree_and_match_oracle(L, monkeypatch):
         "forward": np.stack([T.forward(x) for x in f]),
         "inverse_adjoint": np.stack([T.inverse_adjoint(x) for x in f]),
     }
-    for env in ({}, {"PXM_DFT_R": "2"}, {"PXM_DFT_NO_W": "1"}):
+    for env in ({}, {"PXM_DFT_R": "2"}, {"PXM_DFT_NO_W": "1"}) + (({"PXM_DFT_PFA": "0"},) if L == 256 else ()):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         plan = ops.ShtPlan(L, spin, max_chains=C)
